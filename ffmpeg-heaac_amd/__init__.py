@@ -1,0 +1,256 @@
+"""ffmpeg-heaac_amd -- MI355X-native HE-AAC decode DSP (host-side Python mirror).
+
+The product is the C-ABI shared library `libheaac_amd.so` (include/heaac_dsp.h,
+include/heaac_fft.h, include/heaac_codec.h): hand-written HIP kernels for
+gfx950 plus C host code.  This module only binds it with ctypes so that tests
+and bench.py can drive it; PyTorch supplies device memory and streams, nothing
+else.  There is NO CPU fallback: if the library is missing, or no gfx950 device
+is visible when a compute entry point is called, an exception is raised.
+
+The directory name contains a hyphen; load it with
+    import importlib.util  (see __graft_entry__.load_package)
+or simply `from __graft_entry__ import load_package; heaac = load_package()`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libheaac_amd.so")
+
+# ---- constants (include/heaac_dsp.h) ----
+ONLY_LONG_SEQUENCE, LONG_START_SEQUENCE, EIGHT_SHORT_SEQUENCE, LONG_STOP_SEQUENCE = 0, 1, 2, 3
+CFG_LC_MONO, CFG_LC_STEREO, CFG_HEV1, CFG_HEV2, CFG_HEV1_MONO = 0, 1, 2, 3, 4
+PCM_F32, PCM_S16 = 0, 1
+ADD_BIAS = 385.0
+
+ST_SAVED, ST_SBR, ST_SYNTH, ST_PS = 512, 1972, 1152, 4500
+STATE_WORDS = {
+    CFG_LC_MONO: ST_SAVED,
+    CFG_LC_STEREO: 2 * ST_SAVED,
+    CFG_HEV1: 2 * ST_SAVED + 2 * ST_SBR + 2 * ST_SYNTH,
+    CFG_HEV1_MONO: ST_SAVED + ST_SBR + ST_SYNTH,
+    CFG_HEV2: ST_SAVED + ST_SBR + 2 * ST_SYNTH + ST_PS,
+}
+CORE_CH = {CFG_LC_MONO: 1, CFG_LC_STEREO: 2, CFG_HEV1: 2, CFG_HEV2: 1, CFG_HEV1_MONO: 1}
+OUT_CH = {CFG_LC_MONO: 1, CFG_LC_STEREO: 2, CFG_HEV1: 2, CFG_HEV2: 2, CFG_HEV1_MONO: 1}
+OUT_LEN = {CFG_LC_MONO: 1024, CFG_LC_STEREO: 1024, CFG_HEV1: 2048, CFG_HEV2: 2048, CFG_HEV1_MONO: 2048}
+
+# Algorithmic HBM bytes per frame, SURVEY.md s8(d) / BASELINE.md s3 (f32 PCM out).
+ALGO_BYTES = {CFG_LC_STEREO: 24584, CFG_HEV1: 83976, CFG_HEV2: 85284}
+
+# ---- record dtypes (include/heaac_dsp.h) ----
+ICS_DT = np.dtype([("window_sequence", "u1", (2,)), ("use_kb_window", "u1", (2,))])
+SBR_HDR_DT = np.dtype([
+    ("k0", "u1"), ("k2", "u1"), ("kx", "u1"), ("m", "u1"),
+    ("n", "u1", (2,)), ("n_q", "u1"), ("n_lim", "u1"),
+    ("n_master", "u1"), ("num_patches", "u1"), ("bs_limiter_gains", "u1"),
+    ("bs_interpol_freq", "u1"), ("bs_smoothing_mode", "u1"), ("bs_amp_res_header", "u1"),
+    ("pad0", "u1", (2,)),
+    ("patch_num_subbands", "u1", (6,)), ("patch_start_subband", "u1", (6,)),
+    ("f_tablenoise", "u1", (6,)), ("pad1", "u1", (2,)),
+    ("f_tablelow", "u1", (28,)), ("f_tablehigh", "u1", (52,)), ("f_tablelim", "u1", (32,)),
+])
+SBR_CH_DT = np.dtype([
+    ("bs_num_env", "u1"), ("bs_num_noise", "u1"), ("bs_amp_res", "u1"), ("bs_add_harmonic_flag", "u1"),
+    ("bs_freq_res", "u1", (8,)), ("t_env", "u1", (8,)), ("t_q", "u1", (3,)),
+    ("t_env_num_env_old", "u1"), ("e_a", "i1", (2,)),
+    ("bs_invf_mode", "u1", (2, 5)), ("bs_add_harmonic", "u1", (48,)),
+    ("env_facs_q", "u1", (5, 48)), ("noise_facs_q", "u1", (2, 5)), ("pad", "u1", (2,)),
+])
+SBR_FRAME_DT = np.dtype([
+    ("hdr", "<u2"), ("start", "u1"), ("reset", "u1"), ("kx_old", "u1"), ("m_old", "u1"),
+    ("bs_coupling", "u1"), ("pad", "u1"), ("ch", SBR_CH_DT, (2,)),
+])
+PS_FRAME_DT = np.dtype([
+    ("start", "u1"), ("is34bands", "u1"), ("is34bands_old", "u1"), ("num_env", "u1"),
+    ("num_env_old", "u1"), ("enable_ipdopd", "u1"), ("iid_quant", "u1"), ("icc_mode", "u1"),
+    ("nr_iid_par", "u1"), ("nr_icc_par", "u1"), ("nr_ipdopd_par", "u1"), ("pad", "u1"),
+    ("border_position", "i1", (8,)),
+    ("iid_par", "i1", (5, 34)), ("icc_par", "i1", (5, 34)),
+    ("ipd_par", "i1", (5, 17)), ("opd_par", "i1", (5, 17)), ("pad2", "u1", (2,)),
+])
+assert SBR_HDR_DT.itemsize == 148 and SBR_CH_DT.itemsize == 336
+assert SBR_FRAME_DT.itemsize == 680 and PS_FRAME_DT.itemsize == 532
+
+# Every symbol include/*.h declares (checked by tests/test_abi.py).
+EXPORTED = [
+    # heaac_dsp.h
+    "heaac_device_create", "heaac_device_destroy", "heaac_device_workspace_bytes",
+    "heaac_strerror", "heaac_imdct_half_batch", "heaac_lc_decode_batch",
+    "heaac_he_decode_batch", "heaac_qmf_analysis_batch", "heaac_qmf_synthesis_batch",
+    "heaac_sbr_make_header", "heaac_build_info",
+    # heaac_fft.h
+    "ff_fft_init", "ff_fft_end", "ff_fft_permute", "ff_fft_calc",
+    "ff_mdct_init", "ff_mdct_end", "ff_imdct_half", "ff_imdct_calc",
+    "ff_kbd_window_init", "ff_sine_window_init", "ff_init_ff_sine_windows",
+    "av_mdct_init", "av_imdct_half", "av_imdct_calc", "av_mdct_end",
+    # heaac_codec.h
+    "heaac_aac_decoder", "heaac_codec_open", "heaac_codec_decode", "heaac_codec_close",
+]
+
+
+class HeaacError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libheaac_amd.so; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HeaacError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C ffmpeg-heaac_amd/csrc). There is no CPU fallback." % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.heaac_strerror.restype = C.c_char_p
+        _lib.heaac_build_info.restype = C.c_char_p
+        _lib.heaac_device_workspace_bytes.restype = C.c_size_t
+        _lib.heaac_get_table.argtypes = [C.c_char_p, C.c_void_p, C.c_int]
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise HeaacError("%s failed: %s (%d)" % (what, lib().heaac_strerror(rc).decode(), rc))
+
+
+def get_table(name, n=4096):
+    """Host-built table by name (for table-parity tests; no GPU needed)."""
+    buf = np.zeros(n, np.float32)
+    r = lib().heaac_get_table(name.encode(), buf.ctypes.data_as(C.c_void_p), n)
+    if r < 0:
+        raise KeyError(name)
+    return buf[:r].copy()
+
+
+def sbr_make_header(sample_rate=48000, start_freq=5, stop_freq=9, xover=0, freq_scale=2,
+                    alter_scale=1, noise_bands=2, limiter_bands=2, limiter_gains=2,
+                    interpol_freq=1, smoothing_mode=1, amp_res=1):
+    """heaac_sbr_make_header(): SBR header -> band tables (host C, no GPU)."""
+    h = np.zeros(1, SBR_HDR_DT)
+    rc = lib().heaac_sbr_make_header(h.ctypes.data_as(C.c_void_p), sample_rate, start_freq, stop_freq,
+                                     xover, freq_scale, alter_scale, noise_bands, limiter_bands,
+                                     limiter_gains, interpol_freq, smoothing_mode, amp_res)
+    if rc != 0:
+        raise ValueError("invalid SBR header (%d)" % rc)
+    return h
+
+
+def _ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def to_device(a, device="cuda"):
+    """numpy (possibly structured) array -> uint8/float32 torch tensor on the GPU."""
+    import torch
+    a = np.ascontiguousarray(a)
+    if a.dtype.names is not None or a.dtype.kind not in "fiu":
+        return torch.from_numpy(a.view(np.uint8).reshape(-1)).to(device)
+    return torch.from_numpy(a).to(device)
+
+
+class Device:
+    """HeaacDevice: per-GPU immutable tables (+ workspace)."""
+
+    def __init__(self, max_frames=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise HeaacError("no HIP device visible: the HE-AAC DSP path has no CPU fallback")
+        self._h = C.c_void_p()
+        _check(lib().heaac_device_create(C.byref(self._h), C.c_size_t(max_frames)), "heaac_device_create")
+
+    def close(self):
+        if self._h:
+            lib().heaac_device_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- transforms --
+    def imdct_half(self, which, x):
+        import torch
+        n_half = {0: 1024, 1: 128, 2: 64, 3: 64}[which]
+        assert x.dtype == torch.float32 and x.shape[-1] == n_half
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        _check(lib().heaac_imdct_half_batch(self._h, which, _ptr(out), _ptr(x),
+                                            C.c_size_t(x.numel() // n_half), _stream()),
+               "heaac_imdct_half_batch")
+        return out
+
+    # -- AAC-LC --
+    def lc_decode(self, channels, coeffs, ics, state_in, state_out=None, pcm=None, pcm_format=PCM_F32):
+        import torch
+        n = coeffs.shape[0]
+        assert coeffs.dtype == torch.float32 and coeffs.numel() == n * channels * 1024
+        assert ics.numel() == n * channels * 4 and ics.dtype == torch.uint8
+        assert state_in.numel() == n * channels * 512
+        if state_out is None:
+            state_out = torch.empty_like(state_in)
+        if pcm is None:
+            if pcm_format == PCM_F32:
+                pcm = torch.empty((n, channels, 1024), dtype=torch.float32, device=coeffs.device)
+            else:
+                pcm = torch.empty((n, 1024, channels), dtype=torch.int16, device=coeffs.device)
+        _check(lib().heaac_lc_decode_batch(self._h, channels, _ptr(coeffs), _ptr(ics), _ptr(state_in),
+                                           _ptr(state_out), _ptr(pcm), pcm_format, C.c_size_t(n), _stream()),
+               "heaac_lc_decode_batch")
+        return pcm, state_out
+
+    # -- HE-AAC --
+    def he_decode(self, cfg, coeffs, ics, sbr, hdr, ps, state_in, state_out=None, pcm=None,
+                  pcm_format=PCM_F32):
+        import torch
+        n = coeffs.shape[0]
+        assert state_in.numel() == n * STATE_WORDS[cfg]
+        if state_out is None:
+            state_out = torch.empty_like(state_in)
+        if pcm is None:
+            if pcm_format == PCM_F32:
+                pcm = torch.empty((n, OUT_CH[cfg], 2048), dtype=torch.float32, device=coeffs.device)
+            else:
+                pcm = torch.empty((n, 2048, OUT_CH[cfg]), dtype=torch.int16, device=coeffs.device)
+        n_hdr = hdr.numel() // SBR_HDR_DT.itemsize
+        _check(lib().heaac_he_decode_batch(self._h, cfg, _ptr(coeffs), _ptr(ics), _ptr(sbr), _ptr(hdr),
+                                           C.c_size_t(n_hdr), _ptr(ps), _ptr(state_in), _ptr(state_out),
+                                           _ptr(pcm), pcm_format, C.c_size_t(n), _stream()),
+               "heaac_he_decode_batch")
+        return pcm, state_out
+
+    def qmf_analysis(self, x, xhist, scale=32768.0):
+        import torch
+        n = x.shape[0]
+        W = torch.empty((n, 32, 32, 2), dtype=torch.float32, device=x.device)
+        xh = torch.empty_like(xhist)
+        _check(lib().heaac_qmf_analysis_batch(self._h, _ptr(x), _ptr(xhist), _ptr(xh), _ptr(W),
+                                              C.c_float(scale), C.c_size_t(n), _stream()),
+               "heaac_qmf_analysis_batch")
+        return W, xh
+
+    def qmf_synthesis(self, X, v, scale=2.0 ** -15, bias=385.0):
+        import torch
+        n = X.shape[0]
+        out = torch.empty((n, 2048), dtype=torch.float32, device=X.device)
+        vo = torch.empty_like(v)
+        _check(lib().heaac_qmf_synthesis_batch(self._h, _ptr(X), _ptr(v), _ptr(vo), _ptr(out),
+                                               C.c_float(scale), C.c_float(bias), C.c_size_t(n), _stream()),
+               "heaac_qmf_synthesis_batch")
+        return out, vo

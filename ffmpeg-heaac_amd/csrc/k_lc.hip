@@ -1,0 +1,203 @@
+// k_lc.hip -- batched AAC-LC channel-element synthesis and batched IMDCT.
+//
+// spectral_to_sample() for an SCE/CPE without SBR (aacdec.c:1903-1933):
+// imdct_and_windowing() per channel with bias 385, then (optionally)
+// float_to_int16_interleave (dsputil.c:3989-4001).
+//
+// Persistent workgroups of 4 wavefronts; each wavefront owns one frame at a
+// time (all its channels), tables live in LDS for the life of the workgroup.
+// HBM traffic per frame is exactly the algorithmic minimum: coefficients and
+// overlap read once with 16-byte loads, PCM and overlap written once.
+#include "k_core.h"
+#include "kernels.h"
+
+#define LC_WAVES 4
+
+struct LcWaveLds {
+    float sbuf[1024];
+    float zbuf[1024];
+    float svd[512];
+    uint16_t pcm0[1024];
+};
+
+template <int CH, int FMT>
+__global__ __launch_bounds__(LC_WAVES * WAVE)
+void k_lc_decode(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_rev,
+                 const float *__restrict__ g_coeffs, const HeaacIcs *__restrict__ g_ics,
+                 const float *g_state_in, float *g_state_out,
+                 void *__restrict__ g_pcm, unsigned long long n)
+{
+    __shared__ CoreLds L;
+    __shared__ LcWaveLds W[LC_WAVES];
+    core_lds_init(L, g_tab, g_rev);
+    __syncthreads();
+
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    LcWaveLds &w = W[wave];
+
+    for (unsigned long long f = (unsigned long long)blockIdx.x * LC_WAVES + wave; f < n;
+         f += (unsigned long long)gridDim.x * LC_WAVES) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const unsigned long long u = f * CH + c;
+            const HeaacIcs ics = g_ics[u];
+            core_channel(L, g_coeffs + u * 1024, g_state_in + u * 512, g_state_out + u * 512,
+                         ics, HEAAC_ADD_BIAS, w.sbuf, w.zbuf, w.svd, lane);
+            if (FMT == HEAAC_PCM_F32_PLANAR) {
+                float4 *o4 = reinterpret_cast<float4 *>(reinterpret_cast<float *>(g_pcm) + u * 1024);
+                const float4 *s4 = reinterpret_cast<const float4 *>(w.sbuf);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    o4[lane + 64 * i] = s4[lane + 64 * i];
+            } else if (CH == 1) {
+                // 4 samples -> 8 bytes per lane per step
+                uint2 *o2 = reinterpret_cast<uint2 *>(reinterpret_cast<int16_t *>(g_pcm) + u * 1024);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float4 v = reinterpret_cast<const float4 *>(w.sbuf)[lane + 64 * i];
+                    const unsigned a = (unsigned)(float_to_int16_one(v.x) & 0xffff) |
+                                       ((unsigned)(float_to_int16_one(v.y) & 0xffff) << 16);
+                    const unsigned b = (unsigned)(float_to_int16_one(v.z) & 0xffff) |
+                                       ((unsigned)(float_to_int16_one(v.w) & 0xffff) << 16);
+                    o2[lane + 64 * i] = make_uint2(a, b);
+                }
+            } else if (c == 0) {
+                for (int i = lane; i < 1024; i += WAVE)
+                    w.pcm0[i] = (uint16_t)float_to_int16_one(w.sbuf[i]);
+            } else {
+                // interleave L (kept in LDS) with R: 4 stereo samples = 16 bytes per lane
+                uint4 *o4 = reinterpret_cast<uint4 *>(reinterpret_cast<int16_t *>(g_pcm) + f * 2048);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int s = (lane + 64 * i) * 4;
+                    const float4 v = reinterpret_cast<const float4 *>(w.sbuf)[lane + 64 * i];
+                    uint4 q;
+                    q.x = w.pcm0[s + 0] | ((unsigned)(float_to_int16_one(v.x) & 0xffff) << 16);
+                    q.y = w.pcm0[s + 1] | ((unsigned)(float_to_int16_one(v.y) & 0xffff) << 16);
+                    q.z = w.pcm0[s + 2] | ((unsigned)(float_to_int16_one(v.z) & 0xffff) << 16);
+                    q.w = w.pcm0[s + 3] | ((unsigned)(float_to_int16_one(v.w) & 0xffff) << 16);
+                    o4[lane + 64 * i] = q;
+                }
+            }
+            wave_sync();
+        }
+    }
+}
+
+// Batched ff_imdct_half for the two AAC sizes (LDS split-radix) -------------
+template <int WHICH>
+__global__ __launch_bounds__(LC_WAVES * WAVE)
+void k_imdct_half_core(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_rev,
+                       float *__restrict__ g_out, const float *__restrict__ g_in,
+                       unsigned long long n)
+{
+    __shared__ CoreLds L;
+    __shared__ LcWaveLds W[LC_WAVES];
+    core_lds_init(L, g_tab, g_rev);
+    __syncthreads();
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    LcWaveLds &w = W[wave];
+    // WHICH 0: one 1024-sample transform per unit; WHICH 1: eight 128-sample
+    // transforms per unit (tail handled by clamping the copy).
+    const unsigned long long per = WHICH == 0 ? 1 : 8;
+    const unsigned long long units = (n + per - 1) / per;
+    for (unsigned long long u = (unsigned long long)blockIdx.x * LC_WAVES + wave; u < units;
+         u += (unsigned long long)gridDim.x * LC_WAVES) {
+        const unsigned long long base = u * 1024;
+        const unsigned long long total = n * (WHICH == 0 ? 1024 : 128);
+        for (int i = lane; i < 1024; i += WAVE)
+            w.sbuf[i] = base + i < total ? g_in[base + i] : 0.0f;
+        wave_sync();
+        if (WHICH == 0)
+            imdct2048_lds(L, w.sbuf, w.zbuf, lane);
+        else
+            imdct256x8_lds(L, w.sbuf, w.zbuf, lane);
+        for (int i = lane; i < 1024; i += WAVE)
+            if (base + i < total)
+                g_out[base + i] = w.zbuf[i];
+        wave_sync();
+    }
+}
+
+// Batched ff_imdct_half N = 128, one transform per lane (register FFT) ------
+template <int WHICH>   // 2: scale 1/64, 3: scale -2
+__global__ __launch_bounds__(256)
+void k_imdct_half_128(const float *__restrict__ g_tab, float *__restrict__ g_out,
+                      const float *__restrict__ g_in, unsigned long long n)
+{
+    __shared__ float rot[64];
+    __shared__ float c16[8];
+    __shared__ float c32[12];
+    if (threadIdx.x < 64) rot[threadIdx.x] = g_tab[(WHICH == 2 ? TB_ROT128S : TB_ROT128A) + threadIdx.x];
+    if (threadIdx.x < 5) c16[threadIdx.x] = g_tab[TB_COS16 + threadIdx.x];
+    if (threadIdx.x < 9) c32[threadIdx.x] = g_tab[TB_COS32 + threadIdx.x];
+    __syncthreads();
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+         t += (unsigned long long)gridDim.x * blockDim.x) {
+        const float *x = g_in + t * 64;
+        float o[64];
+        imdct128_reg([&](int i) { return x[i]; }, o, rot, c16, c32);
+        float4 *o4 = reinterpret_cast<float4 *>(g_out + t * 64);
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            o4[i] = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+static int grid_for(unsigned long long units, int per_block, int blocks_per_cu)
+{
+    unsigned long long g = (units + per_block - 1) / per_block;
+    const unsigned long long cap = 256ull * blocks_per_cu;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int heaac_launch_lc(const float *d_tab, const uint16_t *d_rev, int channels,
+                               const float *d_coeffs, const HeaacIcs *d_ics,
+                               const float *d_state_in, float *d_state_out,
+                               void *d_pcm, int pcm_format, size_t n, hipStream_t s)
+{
+    if (n == 0) return HEAAC_OK;
+    const int grid = grid_for(n, LC_WAVES, 2);
+    const dim3 b(LC_WAVES * WAVE);
+#define LAUNCH(CH, FMT) \
+    hipLaunchKernelGGL((k_lc_decode<CH, FMT>), dim3(grid), b, 0, s, d_tab, d_rev, d_coeffs, d_ics, \
+                       d_state_in, d_state_out, d_pcm, (unsigned long long)n)
+    if (channels == 1 && pcm_format == HEAAC_PCM_F32_PLANAR) LAUNCH(1, HEAAC_PCM_F32_PLANAR);
+    else if (channels == 1 && pcm_format == HEAAC_PCM_S16_INTERLEAVED) LAUNCH(1, HEAAC_PCM_S16_INTERLEAVED);
+    else if (channels == 2 && pcm_format == HEAAC_PCM_F32_PLANAR) LAUNCH(2, HEAAC_PCM_F32_PLANAR);
+    else if (channels == 2 && pcm_format == HEAAC_PCM_S16_INTERLEAVED) LAUNCH(2, HEAAC_PCM_S16_INTERLEAVED);
+    else return HEAAC_ERR_ARG;
+#undef LAUNCH
+    return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
+}
+
+extern "C" int heaac_launch_imdct_half(const float *d_tab, const uint16_t *d_rev, int which,
+                                       float *d_out, const float *d_in, size_t n, hipStream_t s)
+{
+    if (n == 0) return HEAAC_OK;
+    const unsigned long long nn = n;
+    switch (which) {
+    case 0:
+        hipLaunchKernelGGL((k_imdct_half_core<0>), dim3(grid_for(n, LC_WAVES, 2)), dim3(LC_WAVES * WAVE),
+                           0, s, d_tab, d_rev, d_out, d_in, nn);
+        break;
+    case 1:
+        hipLaunchKernelGGL((k_imdct_half_core<1>), dim3(grid_for((n + 7) / 8, LC_WAVES, 2)),
+                           dim3(LC_WAVES * WAVE), 0, s, d_tab, d_rev, d_out, d_in, nn);
+        break;
+    case 2:
+        hipLaunchKernelGGL((k_imdct_half_128<2>), dim3(grid_for(n, 256, 4)), dim3(256), 0, s,
+                           d_tab, d_out, d_in, nn);
+        break;
+    case 3:
+        hipLaunchKernelGGL((k_imdct_half_128<3>), dim3(grid_for(n, 256, 4)), dim3(256), 0, s,
+                           d_tab, d_out, d_in, nn);
+        break;
+    default:
+        return HEAAC_ERR_ARG;
+    }
+    return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
+}

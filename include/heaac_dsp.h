@@ -1,0 +1,312 @@
+/* heaac_dsp.h -- batched HE-AAC decode DSP, C ABI (MI355X / gfx950 build).
+ *
+ * This is the drop-in boundary for the ONE hot path this repo accelerates: the
+ * post-parse float DSP of the reference AAC decoder,
+ *   spectral_to_sample()            libavcodec/aacdec.c:1903-1933
+ *     imdct_and_windowing()         libavcodec/aacdec.c:1741-1806
+ *     ff_sbr_apply()                libavcodec/aacsbr.c:1716-1771
+ *       ff_ps_apply()               libavcodec/aacps.c:973-992
+ *   float_to_int16_interleave       libavcodec/dsputil.c:3972-4001
+ *
+ * The reference runs that path for ONE frame of ONE stream per call, on state
+ * held inside AACContext/ChannelElement/SpectralBandReplication/PSContext.
+ * Here every (state, frame) pair is an independent unit: state is an explicit
+ * input and output record, so thousands of units run per kernel launch and a
+ * batch shards across GPUs by index with no communication.
+ *
+ * Plain C: POD records, plain pointers, sizes, int status.  No torch types.
+ * Pointers named d_* are DEVICE pointers (HBM); `stream` is a hipStream_t
+ * passed as void* (NULL = default stream).  Nothing here allocates or
+ * synchronises, so calls may be captured in a hipGraph.
+ */
+#ifndef HEAAC_DSP_H
+#define HEAAC_DSP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ */
+/* Constants of the path                                               */
+/* ------------------------------------------------------------------ */
+
+/* enum WindowSequence, libavcodec/aac.h:66-71 */
+enum {
+    HEAAC_ONLY_LONG_SEQUENCE   = 0,
+    HEAAC_LONG_START_SEQUENCE  = 1,
+    HEAAC_EIGHT_SHORT_SEQUENCE = 2,
+    HEAAC_LONG_STOP_SEQUENCE   = 3,
+};
+
+/* The reference's pure-C float path (aacdec.c:573-576): samples carry a
+ * +385.0 bias and a 2^-15 scale so that float_to_int16_one() can read the
+ * int16 straight out of the mantissa. */
+#define HEAAC_ADD_BIAS   385.0f
+#define HEAAC_SF_SCALE   (-1.0f / (1024.0f * 32768.0f))   /* ac->sf_scale */
+
+/* Workload kinds (BASELINE.json configs) */
+enum {
+    HEAAC_CFG_LC_MONO   = 0,  /* SCE, AAC-LC                    -> 1 x 1024 */
+    HEAAC_CFG_LC_STEREO = 1,  /* CPE, AAC-LC                    -> 2 x 1024 */
+    HEAAC_CFG_HEV1      = 2,  /* CPE + SBR x2                   -> 2 x 2048 */
+    HEAAC_CFG_HEV2      = 3,  /* SCE + SBR + Parametric Stereo  -> 2 x 2048 */
+    HEAAC_CFG_HEV1_MONO = 4,  /* SCE + SBR                      -> 1 x 2048 */
+};
+
+/* PCM output formats */
+enum {
+    HEAAC_PCM_F32_PLANAR = 0, /* the reference's `ret[]` floats (bias included),
+                                 [frame][ch][len]                          */
+    HEAAC_PCM_S16_INTERLEAVED = 1, /* avcodec_decode_audio3 output:
+                                 [frame][len][ch] int16 (dsputil.c:3989)   */
+};
+
+/* ------------------------------------------------------------------ */
+/* P: per-frame parameters produced by the (host) parsers              */
+/* ------------------------------------------------------------------ */
+
+/* IndividualChannelStream fields the DSP reads (aac.h:137-138). */
+typedef struct HeaacIcs {
+    uint8_t window_sequence[2];   /* [0] this frame, [1] previous frame */
+    uint8_t use_kb_window[2];     /* [0] this frame, [1] previous frame */
+} HeaacIcs;                       /* 4 bytes */
+
+/* Header-derived SBR tables (sbr.h:122-156), one record per distinct SBR
+ * header; frames refer to it by index.  All band borders are <= 64. */
+typedef struct HeaacSbrHeader {
+    uint8_t k0;                   /* sbr->k[0]                              */
+    uint8_t k2;                   /* sbr->k[2]                              */
+    uint8_t kx;                   /* sbr->kx[1]                             */
+    uint8_t m;                    /* sbr->m[1]                              */
+    uint8_t n[2];                 /* N_low, N_high                          */
+    uint8_t n_q;                  /* noise floor bands  (<= 5)              */
+    uint8_t n_lim;                /* limiter bands      (<= 28)             */
+    uint8_t n_master;
+    uint8_t num_patches;          /* <= 6                                   */
+    uint8_t bs_limiter_gains;     /* 0..3                                   */
+    uint8_t bs_interpol_freq;
+    uint8_t bs_smoothing_mode;
+    uint8_t bs_amp_res_header;
+    uint8_t pad0[2];
+    uint8_t patch_num_subbands[6];
+    uint8_t patch_start_subband[6];
+    uint8_t f_tablenoise[6];
+    uint8_t pad1[2];
+    uint8_t f_tablelow[28];       /* 25 used */
+    uint8_t f_tablehigh[52];      /* 49 used */
+    uint8_t f_tablelim[32];       /* 29 used */
+} HeaacSbrHeader;                 /* 148 bytes */
+
+/* Per-channel SBR frame data (SBRData bitstream fields, sbr.h:64-73,84,99-105)
+ * exactly as read_sbr_grid()/read_sbr_envelope()/read_sbr_noise() leave them
+ * BEFORE sbr_dequant(): env/noise scalefactors are still the accumulated
+ * integers. */
+typedef struct HeaacSbrChannel {
+    uint8_t bs_num_env;           /* 1..5                                   */
+    uint8_t bs_num_noise;         /* 1..2                                   */
+    uint8_t bs_amp_res;
+    uint8_t bs_add_harmonic_flag;
+    uint8_t bs_freq_res[8];       /* [1..bs_num_env]; [0] = previous frame  */
+    uint8_t t_env[8];             /* [0..bs_num_env]                        */
+    uint8_t t_q[3];
+    uint8_t t_env_num_env_old;    /* t_env[bs_num_env] of the previous frame*/
+    int8_t  e_a[2];               /* l_APrev, l_A                           */
+    uint8_t bs_invf_mode[2][5];   /* [0] this frame, [1] previous frame     */
+    uint8_t bs_add_harmonic[48];
+    uint8_t env_facs_q[5][48];    /* env_facs[1..5][k] before dequant       */
+    uint8_t noise_facs_q[2][5];   /* noise_facs[1..2][k] before dequant     */
+    uint8_t pad[2];
+} HeaacSbrChannel;                /* 336 bytes */
+
+typedef struct HeaacSbrFrame {
+    uint16_t hdr;                 /* index into the HeaacSbrHeader table    */
+    uint8_t  start;               /* sbr->start                             */
+    uint8_t  reset;               /* sbr->reset (header changed this frame) */
+    uint8_t  kx_old;              /* sbr->kx[0]                             */
+    uint8_t  m_old;               /* sbr->m[0]                              */
+    uint8_t  bs_coupling;
+    uint8_t  pad;
+    HeaacSbrChannel ch[2];
+} HeaacSbrFrame;                  /* 680 bytes */
+
+/* PSContext bitstream fields (aacps.h:41-61) as ff_ps_read_data() leaves them. */
+typedef struct HeaacPsFrame {
+    uint8_t start;                /* ps->start; 0 = copy mono to both       */
+    uint8_t is34bands;
+    uint8_t is34bands_old;
+    uint8_t num_env;              /* 1..5 after the envelope fix-up         */
+    uint8_t num_env_old;
+    uint8_t enable_ipdopd;
+    uint8_t iid_quant;
+    uint8_t icc_mode;
+    uint8_t nr_iid_par;           /* 10, 20, 34                             */
+    uint8_t nr_icc_par;
+    uint8_t nr_ipdopd_par;        /* 5, 11, 17                              */
+    uint8_t pad;
+    int8_t  border_position[8];   /* [0..num_env]; [0] = -1                 */
+    int8_t  iid_par[5][34];
+    int8_t  icc_par[5][34];
+    int8_t  ipd_par[5][17];
+    int8_t  opd_par[5][17];
+    uint8_t pad2[2];
+} HeaacPsFrame;                   /* 532 bytes */
+
+/* ------------------------------------------------------------------ */
+/* S: inter-frame state records (float32 words; ints stored bit-exact)  */
+/* ------------------------------------------------------------------ */
+/* Every record is the minimal live state, not the reference's padded arrays.
+ * Offsets are in 32-bit words inside one frame's record.                  */
+
+/* --- one AAC core channel: sce->saved[0..511] (aac.h:214) --- */
+#define HEAAC_ST_SAVED            512
+
+/* --- one SBR channel (SBRData state, sbr.h:80-105) --- */
+#define HEAAC_SBR_XHIST           0      /* 288: analysis_filterbank_samples tail   */
+#define HEAAC_SBR_WTAIL           288    /* 8*32*2: W[1][24..31][k][re,im]          */
+#define HEAAC_SBR_YTAIL           800    /* 6*64*2: Y[1][32..37][k][re,im]          */
+#define HEAAC_SBR_GTAIL           1568   /* 4*48: g_temp rows 2*t_env[L]+0..3       */
+#define HEAAC_SBR_QTAIL           1760   /* 4*48: q_temp rows                       */
+#define HEAAC_SBR_BW              1952   /* 5: bw_array                             */
+#define HEAAC_SBR_IDXNOISE        1957   /* 1 (u32): f_indexnoise                   */
+#define HEAAC_SBR_IDXSINE         1958   /* 1 (u32): f_indexsine                    */
+#define HEAAC_SBR_SIDX            1959   /* 12 words = 48 bytes: s_indexmapped[0]   */
+#define HEAAC_SBR_PAD             1971
+#define HEAAC_ST_SBR              1972
+
+/* --- one synthesis filterbank (output channel): the 9 most recent v slots,
+ *     newest first = synthesis_filterbank_samples[v_off .. v_off+1151] --- */
+#define HEAAC_ST_SYNTH            1152
+
+/* --- Parametric Stereo (PSContext state, aacps.h:63-74) --- */
+#define HEAAC_PS_INBUF            0      /* 5*6*2: in_buf[i][0..5]                  */
+#define HEAAC_PS_DELAY            60     /* 91*14*2: delay[k][32..45]               */
+#define HEAAC_PS_APDELAY          2608   /* 50*3*5*2: ap_delay[k][m][32..36]        */
+#define HEAAC_PS_PEAK             4108   /* 34: peak_decay_nrg                      */
+#define HEAAC_PS_PSMOOTH          4142   /* 34: power_smooth                        */
+#define HEAAC_PS_PDIFF            4176   /* 34: peak_decay_diff_smooth              */
+#define HEAAC_PS_H                4210   /* 4*2*34: H11,H12,H21,H22 [re/im][b] of the last envelope */
+#define HEAAC_PS_HIST             4482   /* 18 words: opd_hist[34], ipd_hist[34] (int8) + pad */
+#define HEAAC_ST_PS               4500
+
+/* Per-frame state record sizes (32-bit words) by workload. */
+#define HEAAC_STATE_WORDS_LC_MONO   (HEAAC_ST_SAVED)
+#define HEAAC_STATE_WORDS_LC_STEREO (2 * HEAAC_ST_SAVED)
+/* HEv1 stereo: [saved0|saved1|sbr0|sbr1|synth0|synth1] */
+#define HEAAC_STATE_WORDS_HEV1      (2 * HEAAC_ST_SAVED + 2 * HEAAC_ST_SBR + 2 * HEAAC_ST_SYNTH)
+/* HEv1 mono:   [saved0|sbr0|synth0] */
+#define HEAAC_STATE_WORDS_HEV1_MONO (HEAAC_ST_SAVED + HEAAC_ST_SBR + HEAAC_ST_SYNTH)
+/* HEv2:        [saved0|sbr0|synthL|synthR|ps] */
+#define HEAAC_STATE_WORDS_HEV2      (HEAAC_ST_SAVED + HEAAC_ST_SBR + 2 * HEAAC_ST_SYNTH + HEAAC_ST_PS)
+
+/* ------------------------------------------------------------------ */
+/* Batched entry points                                                */
+/* ------------------------------------------------------------------ */
+
+/* Opaque device-side context: immutable tables (twiddles, windows, QMF
+ * prototype, noise table, PS filters) resident in HBM for one device, plus a
+ * scratch workspace sized for `max_frames`.  One per GPU/process. */
+typedef struct HeaacDevice HeaacDevice;
+
+/* Create the context on the current HIP device.  Returns 0 on success,
+ * a negative HEAAC_ERR_* otherwise.  Replaces the table set-up done by
+ * aac_decode_init() (aacdec.c:583-598), ff_aac_sbr_init() (aacsbr.c:86-126),
+ * ff_aac_sbr_ctx_init() (aacsbr.c:128-137) and ps_tableinit()
+ * (aacps_tablegen.h:80-209). */
+int heaac_device_create(HeaacDevice **out, size_t max_frames);
+void heaac_device_destroy(HeaacDevice *dev);
+
+/* Bytes of device workspace heaac_device_create() allocates for max_frames. */
+size_t heaac_device_workspace_bytes(size_t max_frames);
+
+enum {
+    HEAAC_OK            =  0,
+    HEAAC_ERR_ARG       = -1,   /* bad argument / unsupported configuration */
+    HEAAC_ERR_HIP       = -2,   /* a HIP runtime call failed               */
+    HEAAC_ERR_NOMEM     = -3,
+    HEAAC_ERR_NODEVICE  = -4,   /* no gfx950 device visible                */
+};
+const char *heaac_strerror(int err);
+
+/* Batched ff_imdct_half (mdct.c:124-159): n independent transforms.
+ * which: 0 = (11,1,1.0)  AAC long      aacdec.c:590
+ *        1 = (8,1,1.0)   AAC short     aacdec.c:591
+ *        2 = (7,1,1/64)  SBR synthesis aacsbr.c:134
+ *        3 = (7,1,-2.0)  SBR analysis  aacsbr.c:135
+ * d_in / d_out: [n][N/2] floats, must not alias. */
+int heaac_imdct_half_batch(HeaacDevice *dev, int which,
+                           float *d_out, const float *d_in,
+                           size_t n, void *stream);
+
+/* Batched AAC-LC channel-element synthesis = imdct_and_windowing() for every
+ * channel (+ float_to_int16_interleave when pcm_format is S16).
+ *   d_coeffs   [n][channels][1024]  sce->coeffs after the spectral tools
+ *   d_ics      [n][channels]        HeaacIcs
+ *   d_state_in/out [n][channels*512] saved[]  (may alias each other)
+ *   d_pcm      F32: [n][channels][1024] floats (bias 385 included)
+ *              S16: [n][1024][channels] int16
+ */
+int heaac_lc_decode_batch(HeaacDevice *dev, int channels,
+                          const float *d_coeffs, const HeaacIcs *d_ics,
+                          const float *d_state_in, float *d_state_out,
+                          void *d_pcm, int pcm_format,
+                          size_t n, void *stream);
+
+/* Batched HE-AAC channel-element synthesis = imdct_and_windowing() (bias 0)
+ * + ff_sbr_apply() (+ ff_ps_apply()) (+ float_to_int16_interleave).
+ *   cfg        HEAAC_CFG_HEV1 (CPE), HEAAC_CFG_HEV1_MONO (SCE) or HEAAC_CFG_HEV2 (SCE+PS)
+ *   d_coeffs   [n][core_channels][1024]
+ *   d_ics      [n][core_channels]
+ *   d_sbr      [n] HeaacSbrFrame ; d_hdr: header table (n_hdr records)
+ *   d_ps       [n] HeaacPsFrame (HEV2 only, else NULL)
+ *   d_state_in/out [n][HEAAC_STATE_WORDS_*] (may alias each other)
+ *   d_pcm      F32: [n][out_channels][2048] ; S16: [n][2048][out_channels]
+ */
+int heaac_he_decode_batch(HeaacDevice *dev, int cfg,
+                          const float *d_coeffs, const HeaacIcs *d_ics,
+                          const HeaacSbrFrame *d_sbr,
+                          const HeaacSbrHeader *d_hdr, size_t n_hdr,
+                          const HeaacPsFrame *d_ps,
+                          const float *d_state_in, float *d_state_out,
+                          void *d_pcm, int pcm_format,
+                          size_t n, void *stream);
+
+/* Stage-level entry points (same kernels, exposed for parity tests and for
+ * hosts that keep part of the pipeline themselves). */
+
+/* sbr_qmf_analysis (aacsbr.c:1136-1169) for n channels:
+ *   d_in [n][1024] core samples (bias 0), d_xhist_in/out [n][288],
+ *   d_W [n][32][32][2]; scale = 1/(-1024*sf_scale) = 32768 on the C path. */
+int heaac_qmf_analysis_batch(HeaacDevice *dev, const float *d_in,
+                             const float *d_xhist_in, float *d_xhist_out,
+                             float *d_W, float scale, size_t n, void *stream);
+
+/* sbr_qmf_synthesis (aacsbr.c:1175-1230), div = 0, for n channels:
+ *   d_X [n][2][32][64] (re plane, im plane; slots 0..31 of X[2][38][64]),
+ *   d_v_in/out [n][1152], d_out [n][2048]; out = acc*scale + bias. */
+int heaac_qmf_synthesis_batch(HeaacDevice *dev, const float *d_X,
+                              const float *d_v_in, float *d_v_out,
+                              float *d_out, float scale, float bias,
+                              size_t n, void *stream);
+
+/* Host-side helper (no GPU): derive the frequency-band tables of one SBR
+ * header -- sbr_make_f_master/f_derived/hf_calc_npatches/f_tablelim
+ * (aacsbr.c:146-205, 296-593).  sample_rate is the SBR (output) rate.
+ * Returns 0, or HEAAC_ERR_ARG where the reference logs an error and falls
+ * back to "pure upsampling mode" (aacsbr.c:1029-1033). */
+int heaac_sbr_make_header(HeaacSbrHeader *h, int sample_rate,
+                          int bs_start_freq, int bs_stop_freq, int bs_xover_band,
+                          int bs_freq_scale, int bs_alter_scale, int bs_noise_bands,
+                          int bs_limiter_bands, int bs_limiter_gains,
+                          int bs_interpol_freq, int bs_smoothing_mode,
+                          int bs_amp_res_header);
+
+/* Library identification; also the "is the HIP code object present" probe. */
+const char *heaac_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEAAC_DSP_H */

@@ -1,0 +1,121 @@
+/* oracle.h -- CPU restatement of the reference HE-AAC decode DSP path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under ffmpeg-heaac_amd/ may include, link
+ * or call this.  It is used by tests/ (parity checker), by
+ * __graft_entry__.smoke() and by bench.py's cpu_baseline leg.
+ *
+ * Pinning status
+ *   IMDCT (a2-a6): pinned by the reference's own known-answer test,
+ *     libavcodec/fft-test.c (LFG seed 1 inputs, O(N^2) double-precision
+ *     imdct_ref, |err| < 1e-3): tests/test_oracle_fft.py restates that test.
+ *   Windowing / SBR / PS (a7-a27): PARITY UNPINNED by the reference -- its
+ *     tree holds no test, golden vector or sample for them, and
+ *     the reference cannot be built here without its configure-generated
+ *     config.h.  These stages are checked by domain
+ *     properties instead (QMF analysis->synthesis reconstruction against
+ *     O(N^2) double-precision filterbanks, TDAC reconstruction, PS energy
+ *     preservation), see tests/test_oracle_props.py.
+ *
+ * Every function cites the reference lines whose arithmetic it follows:
+ * same operation order, no FMA contraction (-ffp-contract=off), tables built
+ * in double with libm and rounded to float exactly where the reference does.
+ */
+#ifndef HEAAC_ORACLE_H
+#define HEAAC_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include "heaac_dsp.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float re, im; } or_cpx;
+
+/* One MDCT instance = ff_mdct_init(nbits, 1, scale) (mdct.c:61-105). */
+typedef struct {
+    int nbits;            /* mdct_bits: n = 1 << nbits                */
+    int n;                /* transform size (2048, 256, 128)          */
+    uint16_t *revtab;     /* n/4 entries (fft.c:121-122)              */
+    float *tcos, *tsin;   /* n/4 entries each (mdct.c:94-100)         */
+} or_mdct;
+
+typedef struct {
+    int ready;
+    float *cos_tab[10];   /* cos_tab[b] = ff_cos_(1<<b), b = 4..9     */
+    or_mdct mdct[4];      /* 0: (11,1.0) 1: (8,1.0) 2: (7,1/64) 3: (7,-2.0) */
+    float kbd_long[1024], kbd_short[128];   /* aacdec.c:593-594 */
+    float sine_long[1024], sine_short[128]; /* aacdec.c:595-596 */
+    float qmf_us[640], qmf_ds[320];         /* aacsbr.c:117-123 */
+    float noise[512][2];                    /* aacsbrdata.h:355 */
+    /* PS tables, aacps_tablegen.h:80-209 */
+    float pd_re_smooth[512], pd_im_smooth[512];
+    float HA[46][8][4], HB[46][8][4];
+    float f20_0_8[8][7][2], f34_0_12[12][7][2], f34_1_8[8][7][2], f34_2_4[4][7][2];
+    float Q_fract_allpass[2][50][3][2];
+    float phi_fract[2][50][2];
+} or_tables;
+
+/* Build (once) and return the table set. */
+const or_tables *oracle_tables(void);
+
+/* Copy a named table out as float32 (for table-checksum tests).  Returns the
+ * number of floats written, or -1 for an unknown name. */
+int oracle_get_table(const char *name, float *dst, int max);
+
+/* ---- transforms (a2-a6) ---- */
+void oracle_fft_calc(int nbits, or_cpx *z);                       /* fft.c:364 */
+void oracle_imdct_half(int which, float *out, const float *in);   /* mdct.c:124 */
+void oracle_imdct_calc(int which, float *out, const float *in);   /* mdct.c:166 */
+
+/* ---- AAC-LC (a8, a9) ---- */
+void oracle_imdct_and_windowing(const float *coeffs, const HeaacIcs *ics,
+                                float *saved /*512 in/out*/, float *out /*1024*/,
+                                float bias);                       /* aacdec.c:1741 */
+
+/* ---- float -> int16 (a27) ---- */
+int  oracle_float_to_int16_one(float f);                           /* dsputil.c:3972 */
+
+/* ---- SBR stages on plain arrays (a11, a20), for stage tests ---- */
+void oracle_qmf_analysis(const float *in /*1024*/, float *xhist /*288 in/out*/,
+                         float *W /*[32][32][2]*/, float scale);    /* aacsbr.c:1136 */
+void oracle_qmf_synthesis(const float *X /*[2][32][64]*/, float *v /*1152 in/out*/,
+                          float *out /*2048*/, float scale, float bias); /* aacsbr.c:1175 */
+
+/* ---- whole-frame batch drivers: same records as include/heaac_dsp.h ---- */
+int oracle_lc_decode_batch(int channels, const float *coeffs, const HeaacIcs *ics,
+                           const float *state_in, float *state_out,
+                           void *pcm, int pcm_format, size_t n);
+
+int oracle_he_decode_batch(int cfg, const float *coeffs, const HeaacIcs *ics,
+                           const HeaacSbrFrame *sbr, const HeaacSbrHeader *hdr, size_t n_hdr,
+                           const HeaacPsFrame *ps,
+                           const float *state_in, float *state_out,
+                           void *pcm, int pcm_format, size_t n);
+
+/* Same, but also dumps stage boundaries of frame 0 of the batch (NULL = skip):
+ *   dump_W    [ch][32][32][2]   after sbr_qmf_analysis
+ *   dump_X    [2][2][38][64]    X[ch][re/im][slot][band] before synthesis
+ */
+int oracle_he_decode_debug(int cfg, const float *coeffs, const HeaacIcs *ics,
+                           const HeaacSbrFrame *sbr, const HeaacSbrHeader *hdr,
+                           const HeaacPsFrame *ps,
+                           const float *state_in, float *state_out,
+                           float *pcm_f32, float *dump_W, float *dump_Xlow,
+                           float *dump_Xhigh, float *dump_Y, float *dump_Xsbr,
+                           float *dump_X);
+
+/* Host-side SBR header derivation, independent restatement of
+ * aacsbr.c:146-205,296-593 (used to cross-check heaac_sbr_make_header). */
+int oracle_sbr_make_header(HeaacSbrHeader *h, int sample_rate,
+                           int bs_start_freq, int bs_stop_freq, int bs_xover_band,
+                           int bs_freq_scale, int bs_alter_scale, int bs_noise_bands,
+                           int bs_limiter_bands, int bs_limiter_gains,
+                           int bs_interpol_freq, int bs_smoothing_mode,
+                           int bs_amp_res_header);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
