@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- HE-AAC decode DSP throughput on MI355X (driver contract).
+
+  python bench.py --gpus N --steps K --warmup W [--workload hev2|hev1|lc_stereo]
+
+A "step" is one pass of the hot path over one batch of synthetic frames, inputs
+resident in HBM, state chained from step to step.  N > 1 is launched by
+torch.distributed.run, one rank per GPU; the batch is per-GPU (weak scaling), no
+data-path collective (frames are independent).
+
+Prints ONE JSON line on rank 0 with `roofline` (algorithmic bytes / kernel time,
+HIP-event timed on the launch stream) and `cpu_baseline` (the oracle, timed on the
+host on a bounded sample of the same workload; rank 0, N = 1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (cfg attr, frames per GPU, BASELINE.json config)
+    "lc_stereo": ("CFG_LC_STEREO", 64 * 1024, "AAC-LC stereo 48 kHz, 64 k-frame batch"),
+    "hev1": ("CFG_HEV1", 64 * 1024, "HE-AACv1 stereo 48 kHz, 64 k-frame batch"),
+    "hev2": ("CFG_HEV2", 256 * 1024, "HE-AACv2 stereo 48 kHz, 256 k-frame batch"),
+}
+
+
+def make_inputs(pkg, synth, torch, cfg, n, seed, pool=4096):
+    """Synthetic per-frame inputs on the GPU.  Parameters for `pool` independent
+    streams are generated on the host for 3 consecutive frames (2 warm-up frames
+    build a realistic state, the third is the timed one) and tiled to n frames;
+    coefficients are drawn per frame on the device."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    pool = min(pool, n)
+    reps = (n + pool - 1) // pool
+    steps = []
+    if cfg == pkg.CFG_LC_STEREO:
+        gen = synth.lc_stream(rng, pool, 3, channels=2)
+        for coeffs, ics in gen:
+            steps.append(dict(ics=pkg.to_device(ics).repeat(reps)[: n * 2 * 4].contiguous()))
+        hdr = None
+    else:
+        hdr = synth.default_headers(pkg)
+        for fr in synth.he_stream(rng, cfg, pool, 3, hdr):
+            d = dict(ics=pkg.to_device(fr["ics"]).repeat(reps)[: n * pkg.CORE_CH[cfg] * 4].contiguous(),
+                     sbr=pkg.to_device(fr["sbr"]).repeat(reps)[: n * 680].contiguous(),
+                     ps=None)
+            if fr["ps"] is not None:
+                d["ps"] = pkg.to_device(fr["ps"]).repeat(reps)[: n * 532].contiguous()
+            d["ws_short"] = torch.from_numpy(
+                (fr["ics"]["window_sequence"][:, :, 0] == 2)).cuda().repeat(reps, 1)[:n]
+            steps.append(d)
+        hdr = pkg.to_device(hdr)
+    # coefficients: uniform +-4096*|sf_scale|, band-limited for the 24 kHz HE core
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    ch = pkg.CORE_CH[cfg]
+    amp = 4096.0 / (1024.0 * 32768.0)
+    coeffs = []
+    for s in range(3):
+        c = (torch.rand((n, ch, 1024), generator=g, device="cuda", dtype=torch.float32) * 2 - 1) * amp
+        if cfg != pkg.CFG_LC_STEREO:
+            k = torch.arange(1024, device="cuda")
+            long_mask = (k < 400).float()
+            short_mask = ((k % 128) < 50).float()
+            m = torch.where(steps[s]["ws_short"][:, :, None], short_mask, long_mask)
+            c = c * m
+        coeffs.append(c.contiguous())
+    return steps, coeffs, hdr
+
+
+def run_step(pkg, dev, cfg, step, coeffs, hdr, st_in, st_out, pcm, fmt):
+    if cfg == pkg.CFG_LC_STEREO:
+        dev.lc_decode(2, coeffs, step["ics"], st_in, state_out=st_out, pcm=pcm, pcm_format=fmt)
+    else:
+        dev.he_decode(cfg, coeffs, step["ics"], step["sbr"], hdr, step["ps"], st_in,
+                      state_out=st_out, pcm=pcm, pcm_format=fmt)
+
+
+def cpu_baseline(pkg, synth, cfg, seconds=12.0):
+    """Time the oracle (scalar C port of the reference path, 1 thread) on the host."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    rng = np.random.default_rng(5)
+    n = 2048 if cfg == pkg.CFG_LC_STEREO else 256
+    if cfg == pkg.CFG_LC_STEREO:
+        frames = list(synth.lc_stream(rng, n, 3, channels=2))
+        state = np.zeros((n, 1024), np.float32)
+        run = lambda fr, st: O.lc_decode_batch(2, fr[0], fr[1], st, O.PCM_F32)
+    else:
+        hdr = synth.default_headers(pkg)
+        frames = list(synth.he_stream(rng, cfg, n, 3, hdr))
+        state = np.zeros((n, pkg.STATE_WORDS[cfg]), np.float32)
+        run = lambda fr, st: O.he_decode_batch(cfg, fr["coeffs"], fr["ics"], fr["sbr"], hdr, fr["ps"], st,
+                                               O.PCM_F32)
+    for fr in frames[:2]:
+        _, state = run(fr, state)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        run(frames[2], state)
+        done += n
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    return dict(value=done / dt, unit="frames/s", cores=1, kind="port",
+                sample="%d frames (%d-frame synthetic set repeated) in %.1f s, oracle C port, gcc -O3 "
+                       "-fno-tree-vectorize -ffp-contract=off, 1 thread" % (done, n, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU (default: BASELINE config)")
+    ap.add_argument("--pcm", default="f32", choices=["f32", "s16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    synth = importlib.import_module(g.PKG_NAME + ".synth")
+
+    workload = args.workload or ("hev2" if hasattr(synth, "he_stream") else "lc_stereo")
+    cfg_name, frames, cfg_desc = WORKLOADS[workload]
+    cfg = getattr(pkg, cfg_name)
+    n = args.frames or frames
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local)
+
+    dev = pkg.Device(n)
+    steps_in, coeffs, hdr = make_inputs(pkg, synth, torch, cfg, n, seed=1234 + rank)
+    fmt = pkg.PCM_F32 if args.pcm == "f32" else pkg.PCM_S16
+    words = pkg.STATE_WORDS[cfg]
+    st = [torch.zeros((n, words), device="cuda"), torch.zeros((n, words), device="cuda")]
+    if fmt == pkg.PCM_F32:
+        pcm = torch.empty((n, pkg.OUT_CH[cfg], pkg.OUT_LEN[cfg]), device="cuda")
+    else:
+        pcm = torch.empty((n, pkg.OUT_LEN[cfg], pkg.OUT_CH[cfg]), dtype=torch.int16, device="cuda")
+
+    # two state-building frames (not warm-up steps: they make state_in realistic)
+    run_step(pkg, dev, cfg, steps_in[0], coeffs[0], hdr, st[0], st[1], pcm, fmt)
+    run_step(pkg, dev, cfg, steps_in[1], coeffs[1], hdr, st[1], st[0], pcm, fmt)
+    torch.cuda.synchronize()
+
+    def one(i):
+        # the timed frame: same parameters every step, state ping-pongs
+        run_step(pkg, dev, cfg, steps_in[2], coeffs[2], hdr, st[i & 1], st[(i + 1) & 1], pcm, fmt)
+
+    for i in range(args.warmup):
+        one(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        one(i)
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    if dist is not None:
+        t = torch.tensor([elapsed, kern_ms], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kern_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        total_frames = n * world * args.steps
+        value = total_frames / elapsed
+        bytes_per_frame = pkg.ALGO_BYTES[cfg]
+        if fmt == pkg.PCM_S16:      # int16 PCM out instead of f32: 2 bytes/sample less
+            bytes_per_frame -= pkg.OUT_CH[cfg] * pkg.OUT_LEN[cfg] * 2
+        achieved = bytes_per_frame * n / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("%s_%s" % (workload, args.pcm))
+        out = {
+            "metric": "HE-AAC frames/s (batched)", "value": value, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg_desc, "frames_per_gpu": n, "pcm": args.pcm,
+                       "bytes_per_frame": bytes_per_frame, "parallelism": "frames sharded by index, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms": kern_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, synth, cfg)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -93,7 +93,11 @@ extern "C" void heaac_device_destroy(HeaacDevice *d)
 extern "C" int heaac_imdct_half_batch(HeaacDevice *dev, int which, float *d_out, const float *d_in,
                                       size_t n, void *stream)
 {
-    if (!dev || !d_out || !d_in || d_out == d_in || which < 0 || which > 3)
+    if (!dev || which < 0 || which > 3)
+        return HEAAC_ERR_ARG;
+    if (n == 0)
+        return HEAAC_OK;
+    if (!d_out || !d_in || d_out == d_in)
         return HEAAC_ERR_ARG;
     return heaac_launch_imdct_half(dev->d_tab, dev->d_rev, which, d_out, d_in, n, (hipStream_t)stream);
 }
@@ -103,9 +107,12 @@ extern "C" int heaac_lc_decode_batch(HeaacDevice *dev, int channels,
                                      const float *d_state_in, float *d_state_out,
                                      void *d_pcm, int pcm_format, size_t n, void *stream)
 {
-    if (!dev || !d_coeffs || !d_ics || !d_state_in || !d_state_out || !d_pcm)
+    if (!dev || channels < 1 || channels > 2 ||
+        (pcm_format != HEAAC_PCM_F32_PLANAR && pcm_format != HEAAC_PCM_S16_INTERLEAVED))
         return HEAAC_ERR_ARG;
-    if (channels < 1 || channels > 2)
+    if (n == 0)
+        return HEAAC_OK;
+    if (!d_coeffs || !d_ics || !d_state_in || !d_state_out || !d_pcm)
         return HEAAC_ERR_ARG;
     return heaac_launch_lc(dev->d_tab, dev->d_rev, channels, d_coeffs, d_ics, d_state_in, d_state_out,
                            d_pcm, pcm_format, n, (hipStream_t)stream);
