@@ -17,6 +17,7 @@ struct HeaacDevice {
     void *d_work;
     size_t work_bytes;
     size_t max_frames;
+    size_t chunk;
 };
 
 extern "C" const char *heaac_build_info(void)
@@ -36,10 +37,18 @@ extern "C" const char *heaac_strerror(int err)
     return "unknown error";
 }
 
+// HE pipeline stages exchange W[ncore][32][32][2] and X[2][2][38][64] per frame
+// through this workspace.  Frames are processed in chunks so that it stays
+// resident in the 256 MiB Infinity Cache instead of travelling to HBM.
+#define HE_CHUNK_FRAMES 2048
+#define WS_W_FLOATS (2 * 2048)
+#define WS_X_FLOATS (2 * 2 * 38 * 64)
+
 extern "C" size_t heaac_device_workspace_bytes(size_t max_frames)
 {
-    (void)max_frames;
-    return 0;
+    size_t chunk = max_frames < HE_CHUNK_FRAMES ? max_frames : HE_CHUNK_FRAMES;
+    if (chunk < 64) chunk = 64;
+    return chunk * (WS_W_FLOATS + WS_X_FLOATS) * sizeof(float);
 }
 
 extern "C" int heaac_device_create(HeaacDevice **out, size_t max_frames)
@@ -63,6 +72,7 @@ extern "C" int heaac_device_create(HeaacDevice **out, size_t max_frames)
     heaac_build_tables(t);
     d->max_frames = max_frames;
     d->work_bytes = heaac_device_workspace_bytes(max_frames);
+    d->chunk = d->work_bytes / ((WS_W_FLOATS + WS_X_FLOATS) * sizeof(float));
     int rc = HEAAC_OK;
     if (hipMalloc((void **)&d->d_tab, sizeof(t->f)) != hipSuccess ||
         hipMalloc((void **)&d->d_rev, sizeof(t->rev)) != hipSuccess ||
@@ -116,4 +126,76 @@ extern "C" int heaac_lc_decode_batch(HeaacDevice *dev, int channels,
         return HEAAC_ERR_ARG;
     return heaac_launch_lc(dev->d_tab, dev->d_rev, channels, d_coeffs, d_ics, d_state_in, d_state_out,
                            d_pcm, pcm_format, n, (hipStream_t)stream);
+}
+
+extern "C" int heaac_he_decode_batch(HeaacDevice *dev, int cfg,
+                                     const float *d_coeffs, const HeaacIcs *d_ics,
+                                     const HeaacSbrFrame *d_sbr,
+                                     const HeaacSbrHeader *d_hdr, size_t n_hdr,
+                                     const HeaacPsFrame *d_ps,
+                                     const float *d_state_in, float *d_state_out,
+                                     void *d_pcm, int pcm_format,
+                                     size_t n, void *stream)
+{
+    if (!dev || (cfg != HEAAC_CFG_HEV1 && cfg != HEAAC_CFG_HEV1_MONO && cfg != HEAAC_CFG_HEV2) ||
+        (pcm_format != HEAAC_PCM_F32_PLANAR && pcm_format != HEAAC_PCM_S16_INTERLEAVED))
+        return HEAAC_ERR_ARG;
+    if (n == 0)
+        return HEAAC_OK;
+    if (!d_coeffs || !d_ics || !d_sbr || !d_hdr || !n_hdr || !d_state_in || !d_state_out || !d_pcm ||
+        (cfg == HEAAC_CFG_HEV2 && !d_ps))
+        return HEAAC_ERR_ARG;
+    const int ncore = cfg == HEAAC_CFG_HEV1 ? 2 : 1;
+    const int nout  = cfg == HEAAC_CFG_HEV1_MONO ? 1 : 2;
+    const size_t words = cfg == HEAAC_CFG_HEV1 ? HEAAC_STATE_WORDS_HEV1 :
+                         cfg == HEAAC_CFG_HEV2 ? HEAAC_STATE_WORDS_HEV2 : HEAAC_STATE_WORDS_HEV1_MONO;
+    const size_t pcm_bytes = (size_t)nout * 2048 * (pcm_format == HEAAC_PCM_F32_PLANAR ? 4 : 2);
+    float *ws_W = (float *)dev->d_work;
+    float *ws_X = ws_W + dev->chunk * WS_W_FLOATS;
+    for (size_t f0 = 0; f0 < n; f0 += dev->chunk) {
+        const size_t nc = n - f0 < dev->chunk ? n - f0 : dev->chunk;
+        int rc = heaac_launch_he(dev->d_tab, dev->d_rev, cfg,
+                                 d_coeffs + f0 * ncore * 1024, d_ics + f0 * ncore,
+                                 d_sbr + f0, d_hdr, d_ps ? d_ps + f0 : NULL,
+                                 d_state_in + f0 * words, d_state_out + f0 * words,
+                                 (char *)d_pcm + f0 * pcm_bytes, pcm_format,
+                                 ws_W, ws_X, nc, 0, (hipStream_t)stream);
+        if (rc != HEAAC_OK)
+            return rc;
+    }
+    return HEAAC_OK;
+}
+
+extern "C" int heaac_qmf_analysis_batch(HeaacDevice *dev, const float *d_in,
+                                        const float *d_xhist_in, float *d_xhist_out,
+                                        float *d_W, float scale, size_t n, void *stream)
+{
+    if (!dev) return HEAAC_ERR_ARG;
+    if (n == 0) return HEAAC_OK;
+    if (!d_in || !d_xhist_in || !d_xhist_out || !d_W) return HEAAC_ERR_ARG;
+    return heaac_launch_qmf_analysis(dev->d_tab, d_in, d_xhist_in, d_xhist_out, d_W, scale, n,
+                                     (hipStream_t)stream);
+}
+
+extern "C" int heaac_qmf_synthesis_batch(HeaacDevice *dev, const float *d_X,
+                                         const float *d_v_in, float *d_v_out,
+                                         float *d_out, float scale, float bias,
+                                         size_t n, void *stream)
+{
+    if (!dev) return HEAAC_ERR_ARG;
+    if (n == 0) return HEAAC_OK;
+    if (!d_X || !d_v_in || !d_v_out || !d_out) return HEAAC_ERR_ARG;
+    return heaac_launch_qmf_synthesis(dev->d_tab, d_X, d_v_in, d_v_out, d_out, scale, bias, n,
+                                      (hipStream_t)stream);
+}
+
+// Debug/test hook: device pointers of the stage workspace of the LAST chunk
+// (W[chunk][2][32][32][2], X[chunk][2][2][38][64]).  Not part of include/*.h.
+extern "C" int heaac_debug_workspace(HeaacDevice *dev, float **d_W, float **d_X, size_t *chunk)
+{
+    if (!dev) return HEAAC_ERR_ARG;
+    if (d_W) *d_W = (float *)dev->d_work;
+    if (d_X) *d_X = (float *)dev->d_work + dev->chunk * WS_W_FLOATS;
+    if (chunk) *chunk = dev->chunk;
+    return HEAAC_OK;
 }

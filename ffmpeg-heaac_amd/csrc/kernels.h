@@ -15,3 +15,25 @@ int heaac_launch_lc(const float *d_tab, const uint16_t *d_rev, int channels,
 int heaac_launch_imdct_half(const float *d_tab, const uint16_t *d_rev, int which,
                             float *d_out, const float *d_in, size_t n, hipStream_t s);
 }
+
+extern "C" {
+int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cfg,
+                    const float *d_coeffs, const HeaacIcs *d_ics,
+                    const HeaacSbrFrame *d_sbr, const HeaacSbrHeader *d_hdr,
+                    const HeaacPsFrame *d_ps,
+                    const float *d_state_in, float *d_state_out,
+                    void *d_pcm, int pcm_format,
+                    float *d_ws_W, float *d_ws_X,
+                    size_t n, size_t pcm_frame0, hipStream_t s);
+
+int heaac_launch_ps(const float *d_tab, const HeaacPsFrame *d_ps, const HeaacSbrFrame *d_sbr,
+                    const HeaacSbrHeader *d_hdr, const float *d_state_in, float *d_state_out,
+                    int state_words, int off_ps, float *d_ws_X, size_t n, hipStream_t s);
+
+int heaac_launch_qmf_analysis(const float *d_tab, const float *d_in, const float *d_xh_in,
+                              float *d_xh_out, float *d_W, float scale, size_t n, hipStream_t s);
+
+int heaac_launch_qmf_synthesis(const float *d_tab, const float *d_X, const float *d_v_in,
+                               float *d_v_out, float *d_out, float scale, float bias,
+                               size_t n, hipStream_t s);
+}

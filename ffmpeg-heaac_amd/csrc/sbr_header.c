@@ -226,6 +226,11 @@ static int build_patches(FreqTables *t)
 
     if (t->n_patch > 1 && t->patch_len[t->n_patch - 1] < 3)
         t->n_patch--;
+    /* ISO/IEC 14496-3 allows at most 5 patches.  The reference lets 6 through
+     * (aacsbr.c:516-519) and then writes past f_tablelim[29]; undefined there,
+     * rejected here. */
+    if (t->n_patch > 5)
+        return -1;
     return 0;
 }
 

@@ -66,3 +66,199 @@ def lc_stream(rng, n, steps, channels=2):
         ics = np.stack([ch.step() for ch in chains], axis=1)
         coeffs = np.stack([_coeffs(rng, ics[:, c], 1024) for c in range(channels)], axis=1)
         yield np.ascontiguousarray(coeffs), np.ascontiguousarray(ics)
+
+
+# ---------------------------------------------------------------------------
+# HE-AAC (SBR + PS) parameter streams
+# ---------------------------------------------------------------------------
+def default_headers(pkg, extra=False):
+    """SBR header table.  Entry 0 is the survey's probe header (48 kHz SBR rate:
+    k0=13, kx=13, m=32, 3 patches); `extra` adds variants (smoothing on,
+    non-interpolated envelopes, limiter off, other band layouts)."""
+    hs = [pkg.sbr_make_header()]
+    if extra:
+        hs += [
+            pkg.sbr_make_header(smoothing_mode=0),
+            pkg.sbr_make_header(interpol_freq=0, limiter_bands=1, limiter_gains=0),
+            pkg.sbr_make_header(start_freq=2, stop_freq=8, xover=2, freq_scale=0, alter_scale=1,
+                                noise_bands=1, limiter_bands=2, limiter_gains=3, smoothing_mode=0, amp_res=0),
+            pkg.sbr_make_header(start_freq=2, stop_freq=7, xover=0, freq_scale=0, alter_scale=0,
+                                noise_bands=2, limiter_bands=0, limiter_gains=1),
+            pkg.sbr_make_header(start_freq=0, stop_freq=3, xover=1, freq_scale=0, alter_scale=1,
+                                noise_bands=3, limiter_bands=2, interpol_freq=0, smoothing_mode=0),
+            pkg.sbr_make_header(start_freq=2, stop_freq=1, xover=0, freq_scale=3, alter_scale=0,
+                                noise_bands=3, limiter_bands=3),
+        ]
+    return np.concatenate(hs)
+
+
+class _SbrChain:
+    """Per-stream SBR grid/envelope state machine producing what read_sbr_grid(),
+    read_sbr_envelope(), read_sbr_noise(), read_sbr_invf() and
+    read_sbr_sinusoidal_coding() leave in SBRData (aacsbr.c:609-889)."""
+
+    def __init__(self, rng, hdr, hdr_idx, varfrac=0.15):
+        self.rng, self.hdr, self.hdr_idx, self.varfrac = rng, hdr, hdr_idx, varfrac
+        self.first = True
+        self.num_env = 0
+        self.t_env_last = 16        # t_env[bs_num_env] of the previous frame
+        self.t_env = [0] * 8
+        self.freq_res_last = 0
+        self.e_a1 = -1
+        self.invf = np.zeros(5, np.uint8)
+
+    def step(self, out):
+        rng, h = self.rng, self.hdr
+        num_env_old = self.num_env
+        t_old = self.t_env_last if not self.first else 0
+        out["t_env_num_env_old"] = t_old
+        out["bs_freq_res"][0] = self.freq_res_last
+        carry = max(t_old - 16, 0)
+        pointer = 0
+        if carry == 0 and rng.random() >= self.varfrac:
+            cls = 0                                              # FIXFIX
+            num_env = int(rng.choice([1, 2, 4]))
+            t = [0] + [((16 + (num_env >> 1)) // num_env) * (i + 1) for i in range(num_env - 1)] + [16]
+            fr = [int(rng.integers(0, 2))] * num_env
+            amp = 0 if num_env == 1 else int(h["bs_amp_res_header"])
+        elif carry == 0:
+            cls = 1                                              # FIXVAR
+            trail = 16 + int(rng.integers(0, 4))
+            nrt = int(rng.integers(0, 4))
+            num_env = nrt + 1
+            t = [0] * (num_env + 1)
+            t[num_env] = trail
+            for i in range(nrt):
+                t[num_env - 1 - i] = t[num_env - i] - 2 * int(rng.integers(0, 2)) - 2
+            pointer = int(rng.integers(0, num_env + 2))
+            fr = [int(x) for x in rng.integers(0, 2, num_env)]
+            amp = int(h["bs_amp_res_header"])
+        else:
+            cls = 2                                              # VARFIX
+            nrl = int(rng.integers(0, 4))
+            num_env = nrl + 1
+            t = [carry] + [0] * num_env
+            for i in range(nrl):
+                t[i + 1] = t[i] + 2 * int(rng.integers(0, 2)) + 2
+            t[num_env] = 16
+            pointer = int(rng.integers(0, num_env + 2))
+            fr = [int(x) for x in rng.integers(0, 2, num_env)]
+            amp = int(h["bs_amp_res_header"])
+        out["bs_num_env"] = num_env
+        out["bs_amp_res"] = amp
+        out["t_env"][: num_env + 1] = t
+        out["bs_freq_res"][1: num_env + 1] = fr
+        num_noise = 2 if num_env > 1 else 1
+        out["bs_num_noise"] = num_noise
+        tq = [t[0], t[num_env]]
+        if num_noise > 1:
+            if cls == 0:
+                idx = num_env >> 1
+            elif cls == 1:
+                idx = num_env - max(pointer - 1, 1)
+            else:
+                idx = 1 if pointer == 0 else (num_env - 1 if pointer == 1 else pointer - 1)
+            tq = [t[0], t[idx], t[num_env]]
+        out["t_q"][: len(tq)] = tq
+        # l_APrev / l_A (aacsbr.c:737-743)
+        e_a0 = -1 if (self.e_a1 != num_env_old) else 0
+        e_a1 = -1
+        if cls == 1 and pointer:
+            e_a1 = num_env + 1 - pointer
+        elif cls == 2 and pointer > 1:
+            e_a1 = pointer - 1
+        out["e_a"][:] = [e_a0, e_a1]
+        # scalefactors, still integers (dequantised on the GPU)
+        lo, hi = (8, 24) if amp else (16, 47)
+        out["env_facs_q"][:num_env, :] = rng.integers(lo, hi, (num_env, 48))
+        out["noise_facs_q"][:num_noise, :] = rng.integers(4, 12, (num_noise, 5))
+        out["bs_invf_mode"][1] = self.invf
+        out["bs_invf_mode"][0] = rng.integers(0, 4, 5)
+        if rng.random() < 0.25:
+            out["bs_add_harmonic_flag"] = 1
+            out["bs_add_harmonic"][:] = rng.random(48) < 0.15
+        self.first = False
+        self.num_env, self.t_env_last, self.e_a1 = num_env, t[num_env], e_a1
+        self.freq_res_last = fr[-1]
+        self.invf = out["bs_invf_mode"][0].copy()
+
+
+class _PsChain:
+    def __init__(self, rng, mode):
+        self.rng, self.mode = rng, mode        # mode: "20", "34", "mix"
+        self.num_env = 0
+        self.is34 = 0
+
+    def step(self, out):
+        rng = self.rng
+        out["start"] = 1
+        out["num_env_old"] = self.num_env
+        out["is34bands_old"] = self.is34
+        if self.mode == "20":
+            layout = 1
+        elif self.mode == "34":
+            layout = 2
+        else:
+            layout = int(rng.integers(0, 3))
+        nr = [10, 20, 34][layout]
+        fine = int(rng.integers(0, 2)) if self.mode != "20" else 0
+        out["nr_iid_par"] = nr
+        out["nr_icc_par"] = nr if self.mode != "mix" else [10, 20, 34][int(rng.integers(0, 3))]
+        out["nr_ipdopd_par"] = [5, 11, 17][layout]
+        out["iid_quant"] = fine
+        out["icc_mode"] = 1 if self.mode == "20" else int(rng.choice([0, 1, 2, 3, 4, 5]))
+        out["enable_ipdopd"] = 0 if self.mode == "20" else 1
+        is34 = int(out["nr_iid_par"] == 34 or out["nr_icc_par"] == 34)
+        out["is34bands"] = is34
+        if self.mode == "20" or rng.random() < 0.7:
+            num_env = int(rng.choice([1, 2, 4]))
+            border = [-1] + [(e * 32 >> {1: 0, 2: 1, 4: 2}[num_env]) - 1 for e in range(1, num_env + 1)]
+        else:
+            # frame_class 1: explicit borders; the parser's fix-up appends one ending at 31
+            num_env = int(rng.integers(1, 5))
+            cuts = sorted(rng.choice(np.arange(1, 31), size=num_env, replace=False).tolist())
+            border = [-1] + cuts
+            if border[-1] < 31:
+                num_env += 1
+                border.append(31)
+        out["num_env"] = num_env
+        out["border_position"][: num_env + 1] = border
+        lim = 15 if fine else 7
+        out["iid_par"][:num_env, :nr] = rng.integers(-lim, lim + 1, (num_env, nr))
+        out["icc_par"][:num_env, : int(out["nr_icc_par"])] = rng.integers(0, 8, (num_env, int(out["nr_icc_par"])))
+        if out["enable_ipdopd"]:
+            out["ipd_par"][:num_env, : int(out["nr_ipdopd_par"])] = rng.integers(0, 8, (num_env, int(out["nr_ipdopd_par"])))
+            out["opd_par"][:num_env, : int(out["nr_ipdopd_par"])] = rng.integers(0, 8, (num_env, int(out["nr_ipdopd_par"])))
+        self.num_env, self.is34 = num_env, is34
+
+
+def he_stream(rng, cfg, n, steps, hdr, ps_mode="20", hdr_choice=None, core_bins=400):
+    """Yield dicts {coeffs, ics, sbr, ps} per step for n streams.
+    hdr: header table; hdr_choice: per-stream header index (default all 0)."""
+    ncore = 2 if cfg == CFG_HEV1 else 1
+    if hdr_choice is None:
+        hdr_choice = np.zeros(n, int)
+    ics_chains = [_IcsChain(rng, n) for _ in range(ncore)]
+    sbr_chains = [[_SbrChain(rng, hdr[hdr_choice[s]], hdr_choice[s]) for _ in range(ncore)] for s in range(n)]
+    ps_chains = [_PsChain(rng, ps_mode) for _ in range(n)] if cfg == CFG_HEV2 else None
+    first = True
+    for _ in range(steps):
+        ics = np.stack([ch.step() for ch in ics_chains], axis=1)
+        coeffs = np.stack([_coeffs(rng, ics[:, c], core_bins) for c in range(ncore)], axis=1)
+        sbr = np.zeros(n, SBR_FRAME_DT)
+        ps = np.zeros(n, PS_FRAME_DT) if cfg == CFG_HEV2 else None
+        for s in range(n):
+            h = hdr[hdr_choice[s]]
+            fr = sbr[s]
+            fr["hdr"] = hdr_choice[s]
+            fr["start"] = 1
+            fr["reset"] = 1 if first else 0
+            # kx[0]/m[0]: previous frame's kx/m; 32/0 before the first header (aacsbr.c:130)
+            fr["kx_old"] = 32 if first else h["kx"]
+            fr["m_old"] = 0 if first else h["m"]
+            for c in range(ncore):
+                sbr_chains[s][c].step(fr["ch"][c])
+            if ps is not None:
+                ps_chains[s].step(ps[s])
+        first = False
+        yield dict(coeffs=np.ascontiguousarray(coeffs), ics=np.ascontiguousarray(ics), sbr=sbr, ps=ps)

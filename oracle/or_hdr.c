@@ -271,6 +271,11 @@ static int hf_calc_npatches(hdr_ctx *s)
 
     if (s->patch_num_subbands[s->num_patches - 1] < 3 && s->num_patches > 1)
         s->num_patches--;
+    /* The reference tolerates a final count of 6 (comment at aacsbr.c:516-519)
+     * but then overruns f_tablelim[29] in sbr_make_f_tablelim; that case is
+     * undefined there and rejected here and in the product. */
+    if (s->num_patches > 5)
+        return -1;
     return 0;
 }
 

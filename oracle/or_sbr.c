@@ -678,6 +678,12 @@ static int he_frame(int cfg, const float *coeffs, const HeaacIcs *ics,
     if (n_hdr && fr->hdr >= n_hdr)
         return HEAAC_ERR_ARG;
     h = &hdr_tab[fr->hdr];
+    /* The reference keeps these arrays in the per-stream context (av_mallocz'ed,
+     * sbr.h:140-177).  Entries no stage writes this frame -- e.g. gain[e][m] for
+     * bands above the last limiter border when the last patch was dropped
+     * (aacsbr.c:538-539) -- are therefore zero in a fresh context; the oracle
+     * and the HIP path define them as zero. */
+    memset(&s, 0, sizeof(s));
 
     if (cpe) {
         off_saved[0] = 0; off_saved[1] = 512;
