@@ -182,8 +182,8 @@ typedef struct HeaacPsFrame {
 
 /* --- Parametric Stereo (PSContext state, aacps.h:63-74) --- */
 #define HEAAC_PS_INBUF            0      /* 5*6*2: in_buf[i][0..5]                  */
-#define HEAAC_PS_DELAY            60     /* 91*14*2: delay[k][32..45]               */
-#define HEAAC_PS_APDELAY          2608   /* 50*3*5*2: ap_delay[k][m][32..36]        */
+#define HEAAC_PS_DELAY            60     /* 14*91*2: delay[k][32+j] stored [j][k][re,im] (band-fastest) */
+#define HEAAC_PS_APDELAY          2608   /* 3*5*50*2: ap_delay[k][m][32+j] stored [m][j][k][re,im]     */
 #define HEAAC_PS_PEAK             4108   /* 34: peak_decay_nrg                      */
 #define HEAAC_PS_PSMOOTH          4142   /* 34: power_smooth                        */
 #define HEAAC_PS_PDIFF            4176   /* 34: peak_decay_diff_smooth              */

@@ -604,11 +604,18 @@ void or_ps_apply(const HeaacPsFrame *p, float *st, float L[2][38][64], float R[2
     /* unpack */
     for (i = 0; i < 5; i++)
         memcpy(ps.in_buf[i], st + HEAAC_PS_INBUF + i * 12, 12 * sizeof(float));
+    /* state layout is band-fastest: delay[j][k][re,im], ap_delay[m][j][k][re,im] */
     for (k = 0; k < 91; k++)
-        memcpy(ps.delay[k] + 32, st + HEAAC_PS_DELAY + k * 28, 28 * sizeof(float));
+        for (j = 0; j < 14; j++) {
+            ps.delay[k][32 + j][0] = st[HEAAC_PS_DELAY + (j * 91 + k) * 2];
+            ps.delay[k][32 + j][1] = st[HEAAC_PS_DELAY + (j * 91 + k) * 2 + 1];
+        }
     for (k = 0; k < 50; k++)
         for (m = 0; m < 3; m++)
-            memcpy(ps.ap_delay[k][m] + 32, st + HEAAC_PS_APDELAY + (k * 3 + m) * 10, 10 * sizeof(float));
+            for (j = 0; j < 5; j++) {
+                ps.ap_delay[k][m][32 + j][0] = st[HEAAC_PS_APDELAY + ((m * 5 + j) * 50 + k) * 2];
+                ps.ap_delay[k][m][32 + j][1] = st[HEAAC_PS_APDELAY + ((m * 5 + j) * 50 + k) * 2 + 1];
+            }
     memcpy(ps.peak_decay_nrg, st + HEAAC_PS_PEAK, 34 * sizeof(float));
     memcpy(ps.power_smooth, st + HEAAC_PS_PSMOOTH, 34 * sizeof(float));
     memcpy(ps.peak_decay_diff_smooth, st + HEAAC_PS_PDIFF, 34 * sizeof(float));
@@ -638,10 +645,16 @@ void or_ps_apply(const HeaacPsFrame *p, float *st, float L[2][38][64], float R[2
     for (i = 0; i < 5; i++)
         memcpy(st + HEAAC_PS_INBUF + i * 12, ps.in_buf[i], 12 * sizeof(float));
     for (k = 0; k < 91; k++)
-        memcpy(st + HEAAC_PS_DELAY + k * 28, ps.delay[k] + 32, 28 * sizeof(float));
+        for (j = 0; j < 14; j++) {
+            st[HEAAC_PS_DELAY + (j * 91 + k) * 2]     = ps.delay[k][32 + j][0];
+            st[HEAAC_PS_DELAY + (j * 91 + k) * 2 + 1] = ps.delay[k][32 + j][1];
+        }
     for (k = 0; k < 50; k++)
         for (m = 0; m < 3; m++)
-            memcpy(st + HEAAC_PS_APDELAY + (k * 3 + m) * 10, ps.ap_delay[k][m] + 32, 10 * sizeof(float));
+            for (j = 0; j < 5; j++) {
+                st[HEAAC_PS_APDELAY + ((m * 5 + j) * 50 + k) * 2]     = ps.ap_delay[k][m][32 + j][0];
+                st[HEAAC_PS_APDELAY + ((m * 5 + j) * 50 + k) * 2 + 1] = ps.ap_delay[k][m][32 + j][1];
+            }
     memcpy(st + HEAAC_PS_PEAK, ps.peak_decay_nrg, 34 * sizeof(float));
     memcpy(st + HEAAC_PS_PSMOOTH, ps.power_smooth, 34 * sizeof(float));
     memcpy(st + HEAAC_PS_PDIFF, ps.peak_decay_diff_smooth, 34 * sizeof(float));

@@ -96,3 +96,27 @@ def test_hev1_mono_s16(pkg, oracle, dev):
 def test_hev1_s16_stereo(pkg, oracle, dev):
     hdr = _synth().default_headers(pkg)
     _run_chain(pkg, oracle, dev, pkg.CFG_HEV1, 17, 3, 24, hdr, fmt=pkg.PCM_S16)
+
+
+def test_hev2_chain_20band(pkg, oracle, dev):
+    hdr = _synth().default_headers(pkg)
+    _run_chain(pkg, oracle, dev, pkg.CFG_HEV2, 40, 6, 31, hdr, ps_mode="20")
+
+
+def test_hev2_chain_34band_ipdopd(pkg, oracle, dev):
+    hdr = _synth().default_headers(pkg, extra=True)
+    n = 35
+    _run_chain(pkg, oracle, dev, pkg.CFG_HEV2, n, 5, 32, hdr, ps_mode="34", hdr_choice=np.arange(n) % len(hdr))
+
+
+def test_hev2_chain_mixed_layouts(pkg, oracle, dev):
+    """10/20/34-band parameter layouts switching from frame to frame (20<->34 remap of the
+    H history, delay-line resets), IPD/OPD on, mode A and mode B mixing."""
+    hdr = _synth().default_headers(pkg, extra=True)
+    n = 70
+    _run_chain(pkg, oracle, dev, pkg.CFG_HEV2, n, 8, 33, hdr, ps_mode="mix", hdr_choice=np.arange(n) % len(hdr))
+
+
+def test_hev2_s16(pkg, oracle, dev):
+    hdr = _synth().default_headers(pkg)
+    _run_chain(pkg, oracle, dev, pkg.CFG_HEV2, 19, 3, 34, hdr, fmt=pkg.PCM_S16)
