@@ -84,7 +84,7 @@ EXPORTED = [
     # heaac_fft.h
     "ff_fft_init", "ff_fft_end", "ff_fft_permute", "ff_fft_calc",
     "ff_mdct_init", "ff_mdct_end", "ff_imdct_half", "ff_imdct_calc",
-    "ff_kbd_window_init", "ff_sine_window_init", "ff_init_ff_sine_windows",
+    "ff_kbd_window_init", "ff_sine_window_init", "ff_init_ff_sine_windows", "ff_sine_windows",
     "av_mdct_init", "av_imdct_half", "av_imdct_calc", "av_mdct_end",
     # heaac_codec.h
     "heaac_aac_decoder", "heaac_codec_open", "heaac_codec_decode", "heaac_codec_close",

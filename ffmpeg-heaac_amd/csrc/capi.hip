@@ -199,3 +199,10 @@ extern "C" int heaac_debug_workspace(HeaacDevice *dev, float **d_W, float **d_X,
     if (chunk) *chunk = dev->chunk;
     return HEAAC_OK;
 }
+
+// internal: device table pointers for shim.hip
+extern "C" const float *heaac_device_tables(HeaacDevice *dev, const uint16_t **rev)
+{
+    if (rev) *rev = dev->d_rev;
+    return dev->d_tab;
+}

@@ -144,6 +144,58 @@ void k_imdct_half_128(const float *__restrict__ g_tab, float *__restrict__ g_out
     }
 }
 
+// Batched ff_fft_calc (fft.c:364-367) for nbits 5, 6, 9: in-place on permuted input.
+__device__ constexpr SrSchedule kSched32 = sr_make(5);
+
+template <int BITS>
+__global__ __launch_bounds__(LC_WAVES * WAVE)
+void k_fft_calc(const float *__restrict__ g_tab, float *g_z, unsigned long long n)
+{
+    constexpr int N = 1 << BITS;
+    __shared__ float cosb[276];
+    __shared__ uint16_t sched[10][88];
+    __shared__ float zb[LC_WAVES][2 * 512];
+    for (int i = threadIdx.x; i < 276; i += blockDim.x) cosb[i] = g_tab[i];
+    for (int i = threadIdx.x; i < 10 * 88; i += blockDim.x) {
+        const SrSchedule &S = BITS == 9 ? kSched512 : BITS == 6 ? kSched64 : kSched32;
+        sched[i / 88][i % 88] = S.off[i / 88][i % 88];
+    }
+    __syncthreads();
+    constexpr SrSchedule S = BITS == 9 ? kSched512 : BITS == 6 ? kSched64 : kSched32;
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    cpx *z = reinterpret_cast<cpx *>(zb[wave]);
+    for (unsigned long long u = (unsigned long long)blockIdx.x * LC_WAVES + wave; u < n;
+         u += (unsigned long long)gridDim.x * LC_WAVES) {
+        float *g = g_z + u * 2 * N;
+        for (int i = lane; i < 2 * N; i += WAVE) zb[wave][i] = g[i];
+        wave_sync();
+        lds_leaves(z, sched[2], S.cnt[2], sched[3], S.cnt[3], 1, 0, cosb[TB_COS16 + 2], lane);
+        lds_pass<4>(z, cosb + TB_COS16, sched[4], S.cnt[4], 1, 0, lane);
+        lds_pass<5>(z, cosb + TB_COS32, sched[5], S.cnt[5], 1, 0, lane);
+        if (BITS >= 6) lds_pass<6>(z, cosb + TB_COS64, sched[6], S.cnt[6], 1, 0, lane);
+        if (BITS >= 9) {
+            lds_pass<7>(z, cosb + TB_COS128, sched[7], S.cnt[7], 1, 0, lane);
+            lds_pass<8>(z, cosb + TB_COS256, sched[8], S.cnt[8], 1, 0, lane);
+            lds_pass<9>(z, cosb + TB_COS512, sched[9], S.cnt[9], 1, 0, lane);
+        }
+        for (int i = lane; i < 2 * N; i += WAVE) g[i] = zb[wave][i];
+        wave_sync();
+    }
+}
+
+// ff_imdct_calc's symmetry extension (mdct.c:175-178): out[n] from out[n/4 .. 3n/4)
+__global__ void k_imdct_mirror(float *g_out, int n, unsigned long long count)
+{
+    const int n2 = n >> 1, n4 = n >> 2;
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < count * n4;
+         t += (unsigned long long)gridDim.x * blockDim.x) {
+        float *o = g_out + (t / n4) * n;
+        const int k = (int)(t % n4);
+        o[k] = -o[n2 - k - 1];
+        o[n - k - 1] = o[n2 + k];
+    }
+}
+
 // ---------------------------------------------------------------------------
 static int grid_for(unsigned long long units, int per_block, int blocks_per_cu)
 {
@@ -199,5 +251,26 @@ extern "C" int heaac_launch_imdct_half(const float *d_tab, const uint16_t *d_rev
     default:
         return HEAAC_ERR_ARG;
     }
+    return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
+}
+
+extern "C" int heaac_launch_fft_calc(const float *d_tab, int nbits, float *d_z, size_t n, hipStream_t s)
+{
+    if (n == 0) return HEAAC_OK;
+    const dim3 g(grid_for(n, LC_WAVES, 4)), b(LC_WAVES * WAVE);
+    const unsigned long long nn = n;
+    if (nbits == 9)      hipLaunchKernelGGL((k_fft_calc<9>), g, b, 0, s, d_tab, d_z, nn);
+    else if (nbits == 6) hipLaunchKernelGGL((k_fft_calc<6>), g, b, 0, s, d_tab, d_z, nn);
+    else if (nbits == 5) hipLaunchKernelGGL((k_fft_calc<5>), g, b, 0, s, d_tab, d_z, nn);
+    else return HEAAC_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
+}
+
+extern "C" int heaac_launch_imdct_mirror(float *d_out, int n, size_t count, hipStream_t s)
+{
+    if (count == 0) return HEAAC_OK;
+    const unsigned long long work = (unsigned long long)count * (n >> 2);
+    int grid = (int)((work + 255) / 256 > 2048 ? 2048 : (work + 255) / 256);
+    hipLaunchKernelGGL(k_imdct_mirror, dim3(grid), dim3(256), 0, s, d_out, n, (unsigned long long)count);
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
 }

@@ -37,3 +37,8 @@ int heaac_launch_qmf_synthesis(const float *d_tab, const float *d_X, const float
                                float *d_v_out, float *d_out, float scale, float bias,
                                size_t n, hipStream_t s);
 }
+
+extern "C" {
+int heaac_launch_fft_calc(const float *d_tab, int nbits, float *d_z, size_t n, hipStream_t s);
+int heaac_launch_imdct_mirror(float *d_out, int n, size_t count, hipStream_t s);
+}

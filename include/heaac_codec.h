@@ -1,0 +1,95 @@
+/* heaac_codec.h -- AVCodec-shaped decoder surface for the HE-AAC DSP path.
+ *
+ * Mirrors the shape of the reference's codec plugin API so a host decoder can
+ * call this library exactly where spectral_to_sample() sits:
+ *
+ *   struct AVCodec { name, type, id, priv_data_size, init, encode, close,
+ *                    decode, ... }            libavcodec/avcodec.h:2675-2711
+ *   AVCodec aac_decoder = { "aac", ... aac_decode_init, NULL,
+ *                    aac_decode_close, aac_decode_frame }
+ *                                             libavcodec/aacdec.c:2128-2142
+ *   avcodec_open / avcodec_decode_audio3 / avcodec_close
+ *                                             libavcodec/utils.c:462-531, :638-663
+ *
+ * Scope: the reference's packet is an AAC bitstream; bitstream parsing is host
+ * work outside this library.  A packet HERE is the parser's
+ * output for one access unit -- dequantised spectrum plus side info -- in the
+ * HeaacFramePacket layout below.  decode() then does what aac_decode_frame()
+ * does from spectral_to_sample() on (aacdec.c:2078-2107): float DSP on the GPU,
+ * int16 interleaved PCM into the caller's buffer, *data_size = bytes written,
+ * return value = bytes consumed (negative on error).
+ *
+ * One context = one stream = one thread, as in the reference.  Inter-frame
+ * state lives in device memory owned by the context.  For throughput use the
+ * batched entry points of heaac_dsp.h; this surface exists for drop-in use.
+ */
+#ifndef HEAAC_CODEC_H
+#define HEAAC_CODEC_H
+
+#include <stdint.h>
+#include "heaac_dsp.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HEAAC_MAX_AUDIO_FRAME_SIZE 192000   /* AVCODEC_MAX_AUDIO_FRAME_SIZE, avcodec.h:431 */
+#define HEAAC_CODEC_ID_AAC 0x15002          /* CODEC_ID_AAC, avcodec.h */
+#define HEAAC_PACKET_MAGIC 0x48454141u      /* "HEAA" */
+
+/* One access unit as the host parsers leave it.  Variable length:
+ *   HeaacFramePacket hdr;
+ *   float coeffs[ncore][1024];
+ *   HeaacSbrFrame sbr;            if cfg is an HE configuration
+ *   HeaacPsFrame  ps;             if cfg == HEAAC_CFG_HEV2
+ *   HeaacSbrHeader new_header;    if (flags & HEAAC_PKT_NEW_SBR_HEADER); stored
+ *                                 at table index sbr.hdr before decoding      */
+typedef struct HeaacFramePacket {
+    uint32_t magic;
+    uint16_t cfg;                 /* HEAAC_CFG_*                             */
+    uint16_t flags;
+    HeaacIcs ics[2];
+} HeaacFramePacket;
+#define HEAAC_PKT_NEW_SBR_HEADER 1
+
+/* AVPacket subset (avcodec.h:1033-1080) */
+typedef struct HeaacPacket {
+    const uint8_t *data;
+    int size;
+} HeaacPacket;
+
+/* AVCodecContext subset (avcodec.h:1113-2650): what the AAC decoder reads/sets */
+typedef struct HeaacCodecContext {
+    int sample_rate;              /* output rate (set by init from cfg)      */
+    int channels;                 /* output channels                         */
+    int frame_size;               /* samples per channel per frame           */
+    int cfg;                      /* HEAAC_CFG_*, chosen by the caller       */
+    const struct HeaacCodec *codec;
+    void *priv_data;
+} HeaacCodecContext;
+
+typedef struct HeaacCodec {
+    const char *name;
+    int type;                     /* 1 = AVMEDIA_TYPE_AUDIO                  */
+    int id;
+    int priv_data_size;
+    int (*init)(HeaacCodecContext *);
+    int (*encode)(HeaacCodecContext *, uint8_t *buf, int buf_size, void *data);
+    int (*close)(HeaacCodecContext *);
+    int (*decode)(HeaacCodecContext *, void *outdata, int *outdata_size, HeaacPacket *avpkt);
+} HeaacCodec;
+
+extern HeaacCodec heaac_aac_decoder;
+
+/* avcodec_open (utils.c:462-531): allocates priv_data, calls codec->init. */
+int heaac_codec_open(HeaacCodecContext *avctx, HeaacCodec *codec);
+/* avcodec_decode_audio3 (utils.c:638-663): checks *frame_size_ptr >=
+ * HEAAC_MAX_AUDIO_FRAME_SIZE, calls codec->decode. */
+int heaac_codec_decode(HeaacCodecContext *avctx, int16_t *samples, int *frame_size_ptr, HeaacPacket *avpkt);
+/* avcodec_close (utils.c:533-560) */
+int heaac_codec_close(HeaacCodecContext *avctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEAAC_CODEC_H */

@@ -1,0 +1,148 @@
+"""Domain properties of the oracle (CPU).  The reference holds no test or vector for the
+windowing, SBR and PS stages, so besides following the reference's
+arithmetic line by line the oracle is checked against the mathematics of the codec."""
+import importlib
+
+import numpy as np
+import pytest
+
+
+def _synth():
+    return importlib.import_module("ffmpeg_heaac_amd.synth")
+
+
+def mdct_ref(x, n):
+    """fft-test.c:116-131 mdct_ref (no 1/N normalisation)."""
+    i = np.arange(n)[None, :]
+    k = np.arange(n // 2)[:, None]
+    return np.cos(2 * np.pi * (2 * i + 1 + n // 2) * (2 * k + 1) / (4 * n)) @ x
+
+
+@pytest.mark.parametrize("kb", [0, 1])
+def test_lc_tdac_reconstruction(pkg, oracle, kb):
+    """MDCT (windowed, 50 % overlap) -> imdct_and_windowing reconstructs the signal:
+    the time-domain aliasing of consecutive frames cancels (Princen-Bradley)."""
+    rng = np.random.default_rng(5 + kb)
+    n, frames = 2048, 6
+    w = pkg.get_table("kbd_long" if kb else "sine_long").astype(np.float64)
+    win = np.concatenate([w, w[::-1]])
+    sig = rng.standard_normal(1024 * (frames + 1)) * 1000.0
+    state = np.zeros((1, 512), np.float32)
+    ics = np.zeros((1, 1), oracle.ICS_DT)
+    ics["use_kb_window"][:] = kb
+    outs = []
+    for f in range(frames):
+        seg = sig[1024 * f: 1024 * f + 2048] * win
+        # AAC's forward MDCT is 2 * sum x cos(.) (ISO/IEC 14496-3 4.6.11.3.1); the decoder folds
+        # the inverse transform's 2/N and its own -1 ("wrong IMDCT method") into
+        # sf_scale = 1 / (-1024 * 32768) (aacdec.c:567-575)
+        X = (2.0 * mdct_ref(seg, n) * (-1.0 / (1024.0 * 32768.0))).astype(np.float32)
+        pcm, state = oracle.lc_decode_batch(1, X[None, None, :], ics, state, oracle.PCM_F32)
+        outs.append((pcm[0, 0].astype(np.float64) - 385.0) * 32768.0)
+    rec = np.concatenate(outs[1:])                  # first frame has no overlap partner
+    ref = sig[1024: 1024 * frames]
+    err = np.abs(rec - ref).max()
+    assert err < 0.51, err        # +385 bias puts the floats on the int16 grid: half an LSB of rounding
+
+
+
+
+def test_qmf_analysis_matches_direct_formula(pkg, oracle):
+    """32-band complex analysis QMF, ISO/IEC 14496-3 4.6.18.4.1:
+    u[n] = sum_j z[n + 64 j], z[n] = c[2n] * x[319 - n];
+    W[k] = sum_n u[n] * 2 * exp(i pi/64 (k + 0.5)(2n - 0.5)),  k = 0..31."""
+    rng = np.random.default_rng(8)
+    c = pkg.get_table("qmf_ds").astype(np.float64)
+    x = (rng.standard_normal(1024) * 1e-3).astype(np.float32)
+    xh = (rng.standard_normal(288) * 30).astype(np.float32)
+    W, _ = oracle.qmf_analysis(x, xh)
+    buf = np.concatenate([xh.astype(np.float64), x.astype(np.float64) * 32768.0])
+    n = np.arange(64)
+    k = np.arange(32)[:, None]
+    M = 2 * np.exp(1j * np.pi / 64 * (k + 0.5) * (2 * n[None, :] - 0.5))
+    for i in (0, 1, 15, 31):
+        seg = buf[32 * i: 32 * i + 320][::-1]          # x[319 - n]
+        z = c * seg
+        u = z.reshape(5, 64).sum(axis=0)
+        ref = M @ u
+        got = W[i, :, 0] + 1j * W[i, :, 1]
+        scale = np.abs(ref).max()
+        assert np.abs(got - ref).max() < 2e-5 * scale, i
+
+
+def test_qmf_analysis_synthesis_reconstruction(pkg, oracle):
+    """Analysis (32 bands) -> zero-padded to 64 bands -> synthesis returns the input
+    upsampled by 2 with the filterbank delay; SBR's QMF pair is near-perfect-reconstruction
+    (ISO/IEC 14496-3 4.6.18.4).  Here: correlation with the delayed, linearly interpolated
+    input must be > 0.999 for a band-limited signal."""
+    rng = np.random.default_rng(9)
+    frames = 5
+    t = np.arange(1024 * frames)
+    sig = (np.sin(2 * np.pi * 0.013 * t) + 0.5 * np.sin(2 * np.pi * 0.071 * t + 1.0)) * 3000.0 / 32768.0
+    xh = np.zeros(288, np.float32)
+    v = np.zeros(1152, np.float32)
+    out = []
+    for f in range(frames):
+        W, xh = oracle.qmf_analysis(sig[1024 * f: 1024 * (f + 1)].astype(np.float32), xh)
+        X = np.zeros((2, 32, 64), np.float32)
+        X[0, :, :32] = W[:, :, 0]
+        X[1, :, :32] = W[:, :, 1]
+        o, v = oracle.qmf_synthesis(X, v, scale=1.0 / 32768.0, bias=0.0)   # undo the analysis x32768
+        out.append(o.astype(np.float64))
+    y = np.concatenate(out)
+    th = np.arange(2048 * frames) / 2.0               # the same signal sampled at twice the rate
+    up = (np.sin(2 * np.pi * 0.013 * th) + 0.5 * np.sin(2 * np.pi * 0.071 * th + 1.0)) * 3000.0 / 32768.0
+    best, gain = 0.0, 0.0
+    for d in range(500, 700):                        # filterbank pair delay: 578 output samples
+        a, b = y[d + 2048: d + 2048 * 3], up[2048: 2048 * 3]
+        c = abs(np.corrcoef(a, b)[0, 1])
+        if c > best:
+            best, gain = c, np.sqrt((a ** 2).mean() / (b ** 2).mean())
+    assert best > 0.999999, best                    # reconstruction error below -60 dB
+    assert abs(gain - 1.0) < 2e-3, gain
+
+
+def test_exp2f_on_half_integers_is_exact_form(oracle):
+    """sbr_dequant calls exp2f on multiples of 0.5 (aacsbr.c:1099-1125); the HIP path builds
+    those values as 2^k or 0x3FB504F3 * 2^k.  Check libm agrees on the whole argument range."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.exp2f.restype = ctypes.c_float
+    libm.exp2f.argtypes = [ctypes.c_float]
+    for twice in range(-252, 256):                   # results in the normal float range
+        ref = np.float32(libm.exp2f(ctypes.c_float(twice / 2.0)))
+        e = twice >> 1
+        mant = 0x3FB504F3 if twice & 1 else 0x3F800000
+        mine = np.array([(mant + (e << 23)) & 0xFFFFFFFF], np.uint32).view(np.float32)[0]
+        assert ref == mine, twice
+
+
+def test_ps_unity_parameters_preserve_energy(pkg, oracle):
+    """iid = 0, icc = 0 (fully correlated): mode-A mixing gives L = R = s (h11 = h12 = 1,
+    h21 = h22 = 0), so PS must output two identical channels equal to the mono decode."""
+    synth = _synth()
+    rng = np.random.default_rng(12)
+    hdr = synth.default_headers(pkg)
+    n = 3
+    st2 = np.zeros((n, pkg.STATE_WORDS[pkg.CFG_HEV2]), np.float32)
+    st1 = np.zeros((n, pkg.STATE_WORDS[pkg.CFG_HEV1_MONO]), np.float32)
+    for t, fr in enumerate(synth.he_stream(rng, pkg.CFG_HEV2, n, 5, hdr)):
+        fr["ps"]["iid_par"][:] = 0
+        fr["ps"]["icc_par"][:] = 0
+        pcm2, st2 = oracle.he_decode_batch(pkg.CFG_HEV2, fr["coeffs"], fr["ics"], fr["sbr"], hdr, fr["ps"], st2)
+        pcm1, st1 = oracle.he_decode_batch(pkg.CFG_HEV1_MONO, fr["coeffs"], fr["ics"], fr["sbr"], hdr, None, st1)
+        assert np.array_equal(pcm2[:, 0], pcm2[:, 1])
+        # the H matrices ramp up from the zero state during the first frame and the synthesis
+        # ring needs one more to flush; after that hybrid analysis -> unity mix -> hybrid synthesis
+        # is transparent on the int16 grid
+        if t >= 2:
+            assert np.array_equal(pcm2[:, 0], pcm1[:, 0]), t
+
+
+def test_float_to_int16_bias_trick(oracle):
+    """float_to_int16_one (dsputil.c:3972-3981) == clip(round-to-grid((f - 385) * 32768))."""
+    vals = np.array([385.0, 385.0 + 1 / 32768, 385.0 - 1 / 32768, 385.99997, 384.00003, 386.5, 383.2, 1e6, -5.0,
+                     384.0, 386.0 - 2.0 ** -15], np.float32)
+    got = oracle.float_to_int16(vals)
+    want = np.clip(np.round((vals.astype(np.float64) - 385.0) * 32768.0), -32768, 32767).astype(np.int16)
+    assert np.array_equal(got, want), (got, want)

@@ -1,0 +1,141 @@
+"""GPU: the reference-shaped per-call surfaces (FFTContext / ff_imdct_half, AVCodec-shaped
+decoder) run the HIP path and agree with the oracle bit for bit."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class FFTComplex(C.Structure):
+    _fields_ = [("re", C.c_float), ("im", C.c_float)]
+
+
+class FFTContext(C.Structure):
+    pass
+
+
+FN2 = C.CFUNCTYPE(None, C.POINTER(FFTContext), C.c_void_p)
+FN3 = C.CFUNCTYPE(None, C.POINTER(FFTContext), C.c_void_p, C.c_void_p)
+FFTContext._fields_ = [
+    ("nbits", C.c_int), ("inverse", C.c_int), ("revtab", C.POINTER(C.c_uint16)),
+    ("exptab", C.c_void_p), ("exptab1", C.c_void_p), ("tmp_buf", C.c_void_p),
+    ("mdct_size", C.c_int), ("mdct_bits", C.c_int), ("tcos", C.POINTER(C.c_float)),
+    ("tsin", C.POINTER(C.c_float)), ("fft_permute", FN2), ("fft_calc", FN2),
+    ("imdct_calc", FN3), ("imdct_half", FN3), ("mdct_calc", FN3),
+    ("split_radix", C.c_int), ("permutation", C.c_int),
+]
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("which,nbits,scale", [(0, 11, 1.0), (1, 8, 1.0), (2, 7, 1.0 / 64), (3, 7, -2.0)])
+def test_ff_mdct_init_and_imdct(pkg, oracle, dev, which, nbits, scale):
+    lib = pkg.lib()
+    s = FFTContext()
+    assert lib.ff_mdct_init(C.byref(s), nbits, 1, C.c_double(scale)) == 0
+    n = 1 << nbits
+    assert (s.mdct_bits, s.mdct_size, s.nbits, s.inverse, s.split_radix, s.permutation) == (nbits, n, nbits - 2, 1, 1, 0)
+    name = {0: "tcos2048", 1: "tcos256", 2: "tcos128s", 3: "tcos128a"}[which]
+    tc = np.ctypeslib.as_array(s.tcos, (n // 2,))
+    assert np.array_equal(_bits(tc), _bits(oracle.get_table(name)))
+    assert C.addressof(s.tsin.contents) - C.addressof(s.tcos.contents) == n  # tsin = tcos + n/4 floats
+    rev = np.ctypeslib.as_array(s.revtab, (n // 4,))
+    assert np.array_equal(rev, oracle.get_table("revtab%d" % min(which, 2)).astype(np.uint16))
+    rng = np.random.default_rng(which)
+    x = rng.standard_normal(n // 2).astype(np.float32)
+    out = np.zeros(n // 2, np.float32)
+    lib.ff_imdct_half(C.byref(s), out.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(_bits(out), _bits(oracle.imdct_half(which, x)))
+    full = np.zeros(n, np.float32)
+    s.imdct_calc(C.byref(s), full.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p))   # via the fn pointer
+    assert np.array_equal(_bits(full), _bits(oracle.imdct_calc(which, x)))
+    lib.ff_mdct_end(C.byref(s))
+    assert not s.tcos and not s.revtab
+
+
+def test_ff_mdct_init_rejects_foreign_transforms(pkg, dev):
+    s = FFTContext()
+    assert pkg.lib().ff_mdct_init(C.byref(s), 9, 1, C.c_double(1.0)) == -1
+    assert pkg.lib().ff_mdct_init(C.byref(s), 11, 0, C.c_double(1.0)) == -1
+
+
+@pytest.mark.parametrize("nbits", [5, 6, 9])
+def test_ff_fft_permute_calc(pkg, oracle, dev, nbits):
+    lib = pkg.lib()
+    s = FFTContext()
+    assert lib.ff_fft_init(C.byref(s), nbits, 1) == 0
+    n = 1 << nbits
+    rng = np.random.default_rng(nbits)
+    z = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    buf = z.copy()
+    lib.ff_fft_permute(C.byref(s), buf.ctypes.data_as(C.c_void_p))
+    rev = oracle.get_table({9: "revtab0", 6: "revtab1", 5: "revtab2"}[nbits]).astype(int)
+    zp = np.zeros_like(z); zp[rev] = z
+    assert np.array_equal(buf, zp)
+    lib.ff_fft_calc(C.byref(s), buf.ctypes.data_as(C.c_void_p))
+    ref = oracle.fft_calc(nbits, zp)
+    assert np.array_equal(buf.view(np.uint32), ref.view(np.uint32))
+    lib.ff_fft_end(C.byref(s))
+
+
+class HeaacPacket(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("size", C.c_int)]
+
+
+class HeaacCodecContext(C.Structure):
+    _fields_ = [("sample_rate", C.c_int), ("channels", C.c_int), ("frame_size", C.c_int), ("cfg", C.c_int),
+                ("codec", C.c_void_p), ("priv_data", C.c_void_p)]
+
+
+@pytest.mark.parametrize("cfgname", ["CFG_LC_STEREO", "CFG_HEV1", "CFG_HEV2"])
+def test_codec_surface_decodes_a_stream(pkg, oracle, dev, cfgname):
+    """open / decode x4 / close through the AVCodec-shaped vtable; int16 PCM equals the oracle's."""
+    lib = pkg.lib()
+    synth = importlib.import_module("ffmpeg_heaac_amd.synth")
+    cfg = getattr(pkg, cfgname)
+    rng = np.random.default_rng(77)
+    ctx = HeaacCodecContext(cfg=cfg)
+    codec = C.c_void_p.in_dll(lib, "heaac_aac_decoder")
+    assert lib.heaac_codec_open(C.byref(ctx), C.addressof(codec)) == 0
+    assert (ctx.channels, ctx.frame_size) == (pkg.OUT_CH[cfg], pkg.OUT_LEN[cfg])
+    hdr = synth.default_headers(pkg)
+    state = np.zeros((1, pkg.STATE_WORDS[cfg]), np.float32)
+    if cfg == pkg.CFG_LC_STEREO:
+        frames = [dict(coeffs=c, ics=i, sbr=None, ps=None) for c, i in synth.lc_stream(rng, 1, 4, 2)]
+    else:
+        frames = list(synth.he_stream(rng, cfg, 1, 4, hdr))
+    out = (C.c_int16 * (192000 // 2))()
+    for t, fr in enumerate(frames):
+        ics2 = np.zeros(2, pkg.ICS_DT); ics2[: pkg.CORE_CH[cfg]] = fr["ics"][0]
+        head = np.zeros(1, np.dtype([("magic", "<u4"), ("cfg", "<u2"), ("flags", "<u2"), ("ics", pkg.ICS_DT, (2,))]))
+        head["magic"] = 0x48454141; head["cfg"] = cfg; head["ics"][0] = ics2
+        blob = head.tobytes() + fr["coeffs"][0].astype(np.float32).tobytes()
+        if fr["sbr"] is not None:
+            head["flags"] = 1 if t == 0 else 0
+            blob = head.tobytes() + fr["coeffs"][0].astype(np.float32).tobytes() + fr["sbr"][0].tobytes()
+            if fr["ps"] is not None:
+                blob += fr["ps"][0].tobytes()
+            if t == 0:
+                blob += hdr[0].tobytes()
+        buf = C.create_string_buffer(blob, len(blob))
+        pkt = HeaacPacket(C.cast(buf, C.c_void_p), len(blob))
+        size = C.c_int(192000)
+        used = lib.heaac_codec_decode(C.byref(ctx), out, C.byref(size), C.byref(pkt))
+        assert used == len(blob)
+        assert size.value == pkg.OUT_LEN[cfg] * pkg.OUT_CH[cfg] * 2
+        got = np.frombuffer(out, np.int16, size.value // 2).reshape(pkg.OUT_LEN[cfg], pkg.OUT_CH[cfg])
+        if cfg == pkg.CFG_LC_STEREO:
+            ref, state = oracle.lc_decode_batch(2, fr["coeffs"], fr["ics"], state, oracle.PCM_S16)
+        else:
+            ref, state = oracle.he_decode_batch(cfg, fr["coeffs"], fr["ics"], fr["sbr"], hdr, fr["ps"], state,
+                                                oracle.PCM_S16)
+        assert np.array_equal(got, ref[0]), "frame %d" % t
+    # too-small output buffer is refused like avcodec_decode_audio3 does (utils.c:645-651)
+    small = C.c_int(1000)
+    assert lib.heaac_codec_decode(C.byref(ctx), out, C.byref(small), C.byref(pkt)) == -1
+    assert lib.heaac_codec_close(C.byref(ctx)) == 0
