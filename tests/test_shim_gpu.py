@@ -101,7 +101,7 @@ def test_codec_surface_decodes_a_stream(pkg, oracle, dev, cfgname):
     rng = np.random.default_rng(77)
     ctx = HeaacCodecContext(cfg=cfg)
     codec = C.c_void_p.in_dll(lib, "heaac_aac_decoder")
-    assert lib.heaac_codec_open(C.byref(ctx), C.addressof(codec)) == 0
+    assert lib.heaac_codec_open(C.byref(ctx), C.c_void_p(C.addressof(codec))) == 0
     assert (ctx.channels, ctx.frame_size) == (pkg.OUT_CH[cfg], pkg.OUT_LEN[cfg])
     hdr = synth.default_headers(pkg)
     state = np.zeros((1, pkg.STATE_WORDS[cfg]), np.float32)
