@@ -151,7 +151,8 @@ def main():
     steps_in, coeffs, hdr = make_inputs(pkg, synth, torch, cfg, n, seed=1234 + rank)
     fmt = pkg.PCM_F32 if args.pcm == "f32" else pkg.PCM_S16
     words = pkg.STATE_WORDS[cfg]
-    st = [torch.zeros((n, words), device="cuda"), torch.zeros((n, words), device="cuda")]
+    # state is updated in place (st_in == st_out), as a decoder does frame after frame
+    st = [torch.zeros((n, words), device="cuda")] * 2
     if fmt == pkg.PCM_F32:
         pcm = torch.empty((n, pkg.OUT_CH[cfg], pkg.OUT_LEN[cfg]), device="cuda")
     else:

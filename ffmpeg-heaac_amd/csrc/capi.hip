@@ -40,7 +40,7 @@ extern "C" const char *heaac_strerror(int err)
 // HE pipeline stages exchange W[ncore][32][32][2] and X[2][2][38][64] per frame
 // through this workspace.  Frames are processed in chunks so that it stays
 // resident in the 256 MiB Infinity Cache instead of travelling to HBM.
-#define HE_CHUNK_FRAMES 2048
+#define HE_CHUNK_FRAMES 32768
 #define WS_W_FLOATS (2 * 2048)
 #define WS_X_FLOATS (2 * 2 * 38 * 64)
 

@@ -11,33 +11,78 @@
 #include "k_common.h"
 #include "kernels.h"
 
-#define PS_WAVES 4
+#ifdef PS_STAMPS
+__device__ unsigned long long g_ps_stamps[16];
+#define STAMP(i) do { wave_sync(); if (lane == 0 && blockIdx.x == 7 && wave == 0) g_ps_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 #define SUB_STRIDE 66          // one sub-subband row: 32 slots * (re,im) + 2 pad
-#define PN_STRIDE 92
 
-__device__ const signed char k_to_i_20_d[71] = {
+// Table 8.48 / 8.49 of ISO/IEC 14496-3 (aacpsdata.c:145-158): hybrid band -> parameter band
+struct KtoI { signed char v[91]; };
+constexpr KtoI k_to_i_20_c = {{
      1,  0,  0,  1,  2,  3,  4,  5,  6,  7,  8,  9, 10, 11, 12, 13, 14, 14, 15,
     15, 15, 16, 16, 16, 16, 17, 17, 17, 17, 17, 18, 18, 18, 18, 18, 18, 18, 18,
     18, 18, 18, 18, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19,
-    19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19
-};
-__device__ const signed char k_to_i_34_d[91] = {
+    19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19 }};
+constexpr KtoI k_to_i_34_c = {{
      0,  1,  2,  3,  4,  5,  6,  6,  7,  2,  1,  0, 10, 10,  4,  5,  6,  7,  8,
      9, 10, 11, 12,  9, 14, 11, 12, 13, 14, 15, 16, 13, 16, 17, 18, 19, 20, 21,
     22, 22, 23, 23, 24, 24, 25, 25, 26, 26, 27, 27, 27, 28, 28, 28, 29, 29, 29,
     30, 30, 30, 31, 31, 31, 31, 32, 32, 32, 32, 33, 33, 33, 33, 33, 33, 33, 33,
-    33, 33, 33, 33, 33, 33, 33, 33, 33, 33, 33, 33, 33, 33, 33
-};
+    33, 33, 33, 33, 33, 33, 33, 33, 33, 33, 33, 33, 33, 33, 33 }};
 
-struct PsWave {
-    HeaacPsFrame p;
-    float inb[5][44][2];               // hybrid analysis input: 6 history + 38 current slots
-    float sub[32][SUB_STRIDE];         // sub-subband signals s[ks][n]; L output in place
-    float pn[32 * PN_STRIDE];          // |s|^2 [n][k]; later R output of the sub-subbands
-    float pw[34][33];                  // band power, then transient gain
-    float Hs[6][8][34];                // H11r,H11i,H12r,H12i,H21r,H21i,H22r,H22i rows per envelope border
-    signed char kti[92];               // k_to_i for this frame's band layout
-    signed char iid_m[5][34], icc_m[5][34], ipd_m[5][34], opd_m[5][34];
+// Members of every parameter band in ascending hybrid-band order: the order in
+// which decorrelation() accumulates power[i][n] (aacps.c:673-678).
+struct BandMembers {
+    signed char kti[92];
+    unsigned char order[92];      // hybrid bands sorted by (parameter band, k)
+    unsigned char first[36];      // first[i] .. first[i+1]: members of band i
+    int split;                    // bands [0,split) and [split,nr_par) hold about half the members each
+};
+constexpr BandMembers make_members(const KtoI &t, int nr_bands, int nr_par)
+{
+    BandMembers m{};
+    int pos = 0;
+    for (int k = 0; k < nr_bands; k++) m.kti[k] = t.v[k];
+    for (int i = 0; i < nr_par; i++) {
+        m.first[i] = (unsigned char)pos;
+        for (int k = 0; k < nr_bands; k++)
+            if (t.v[k] == i) m.order[pos++] = (unsigned char)k;
+    }
+    m.first[nr_par] = (unsigned char)pos;
+    m.split = nr_par;
+    for (int i = 0; i <= nr_par; i++)
+        if (2 * m.first[i] >= pos) { m.split = i; break; }
+    return m;
+}
+__device__ constexpr BandMembers kMem20 = make_members(k_to_i_20_c, 71, 20);
+__device__ constexpr BandMembers kMem34 = make_members(k_to_i_34_c, 91, 34);
+
+// Per-wave LDS.  GENERAL = false: baseline PS -- frames that are and were 20-band with
+// IPD/OPD off (what HE-AACv2 encoders emit) -- small enough for 8 waves per CU.  GENERAL = true: any
+// layout, including 20 <-> 34 switches.
+template <bool GENERAL>
+struct PsWaveT {
+    static constexpr int NSUB = GENERAL ? 32 : 10;
+    static constexpr int NLOW = GENERAL ? 5 : 3;
+    static constexpr int NB = GENERAL ? 91 : 71;
+    static constexpr int NPAR = GENERAL ? 34 : 20;
+    static constexpr bool IS_GENERAL = GENERAL;
+    static constexpr int NH = GENERAL ? 8 : 4;      // H rows kept: re+im, or re only (IPD/OPD off)
+    static constexpr int TS = NB + 2;               // tile row stride in complex elements: 73 / 93
+                                                    // (stride*2 floats = 18 / 58 mod 64: conflict-free b64 columns)
+    // Views of separate __shared__ arrays (distinct objects, so the compiler can
+    // reorder tile loads around the sub-subband stores).
+    HeaacPsFrame &p;
+    float (*inb)[44][2];               // [NLOW] hybrid analysis input: 6 history + 38 current slots
+    float (*tile)[TS][2];              // [32]   s[kh][n] of this frame, [slot][hybrid band][re,im]
+    float (*subL)[SUB_STRIDE];         // [NSUB] mixed sub-subband outputs, left / right
+    float (*subR)[SUB_STRIDE];
+    float (*pw)[33];                   // [NPAR] band power, then transient gain
+    float (*Hs)[NH][NPAR];             // [6]    H11,H12,H21,H22 (re[,im]) rows per envelope border
+    signed char (*iid_m)[NPAR], (*icc_m)[NPAR], (*ipd_m)[NPAR], (*opd_m)[NPAR];   // [5]
 };
 
 // map_idx_* (aacps.c:461-643) as a gather: mapped value of band b.
@@ -148,33 +193,46 @@ __device__ __forceinline__ void hybrid_fir(const float *in, const float *filt, f
 
 // One band, all 32 slots: decorrelation (aacps.c:696-753) fused with the mixing
 // loop of stereo_processing (:900-969).
-//   src(n, re, im)        : s[k][n]
-//   sink(n, lre, lim, rre, rim)
-//   dl / ap               : state pointers already offset to this band's column
-template <class Src, class Sink>
-__device__ __forceinline__ void ps_band(PsWave &w, const float *__restrict__ g_tab, int is34, int kh,
-                                        bool clear_delay, bool clear_ap,
-                                        const float *dl_in, float *dl_out, int dl_stride,
-                                        const float *ap_in, float *ap_out, int ap_stride,
-                                        Src src, Sink sink)
+//   HEAVY = true : any band (all-pass chain, 14-slot or 1-slot delay)
+//   HEAVY = false: bands >= 64 only, all of which use the 1-slot delay
+//   input  : w.tile[n][kh]
+//   output : sub-subbands (is_sub) -> w.subL / w.subR rows; QMF column q -> X planes
+// Envelope borders are walked once in ascending order (border[0] = -1,
+// border[num_env] = 31, monotonic: what ff_ps_read_data produces).
+template <bool HEAVY, bool ALIGNED8, class W>
+__device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, const signed char *kti,
+                                        int is34, int kh, bool clear_state,
+                                        const float *dl_in, float *dl_out,
+                                        const float *ap_in, float *ap_out,
+                                        bool is_sub, int q,
+                                        float *XL0, float *XL1, float *XR0, float *XR1)
 {
+    // ALIGNED8: every envelope border is 8k - 1 (frame_class 0, aacps.c:203-205), so the
+    // H interpolation can only restart at slots 0, 8, 16, 24 and the unrolled slot code
+    // in between is one straight-line block the scheduler can software-pipeline.
+    constexpr int dl_stride = 91 * 2, ap_stride = 50 * 2;
     const int nr_allpass = is34 ? 50 : 30, short_delay = is34 ? 62 : 42;
-    const int b = w.kti[kh];
-    const int enable_ipdopd = w.p.enable_ipdopd;
+    const int b = kti[kh];
+    const int enable_ipdopd = W::IS_GENERAL ? w.p.enable_ipdopd : 0;
+    const bool allpass = HEAVY && kh < nr_allpass;
+    const bool d14 = HEAVY && !allpass && kh < short_delay;
 
-    // delay line tail d[j] = s[k][j - 14], j = 0..13
-    float dre[14], dim[14];
+    // Delay line: s[k][n - D] with D = 2 (all-pass input), 14 or 1.  For n >= D it is
+    // a row of the LDS tile, before that the state tail hst[j] = s[k][j - 14].
+    const int D = allpass ? 2 : d14 ? 14 : 1;
+    float hre[14], him[14];
 #pragma unroll
-    for (int j = 0; j < 14; j++) {
-        dre[j] = clear_delay ? 0.0f : dl_in[j * dl_stride];
-        dim[j] = clear_delay ? 0.0f : dl_in[j * dl_stride + 1];
+    for (int j = HEAVY ? 0 : 13; j < 14; j++) {
+        hre[j] = clear_state ? 0.0f : dl_in[j * dl_stride];
+        him[j] = clear_state ? 0.0f : dl_in[j * dl_stride + 1];
     }
-    const bool allpass = kh < nr_allpass;
-    const bool d14 = !allpass && kh < short_delay;
-
-    // all-pass state: last 5 values of every link
+    // all-pass history: ring of 5 per link, position = time mod 5 (state j = time j - 5)
     float are[3][5], aim[3][5];
-    float ag[3], qre[3], qim[3], phre = 0.0f, phim = 0.0f;
+    float ag[3] = {0, 0, 0}, qre[3] = {0, 0, 0}, qim[3] = {0, 0, 0}, phre = 0.0f, phim = 0.0f;
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int j = 0; j < 5; j++) { are[m][j] = 0.0f; aim[m][j] = 0.0f; }
     if (allpass) {
         float g_decay_slope = 1.f - 0.05f * (kh - (is34 ? 32 : 10));
         g_decay_slope = g_decay_slope < 0.f ? 0.f : (g_decay_slope > 1.f ? 1.f : g_decay_slope);   // av_clipf
@@ -186,119 +244,194 @@ __device__ __forceinline__ void ps_band(PsWave &w, const float *__restrict__ g_t
             qim[m] = g_tab[TB_QFRACT + ((is34 * 50 + kh) * 3 + m) * 2 + 1];
 #pragma unroll
             for (int j = 0; j < 5; j++) {
-                are[m][j] = clear_ap ? 0.0f : ap_in[(m * 5 + j) * ap_stride];
-                aim[m][j] = clear_ap ? 0.0f : ap_in[(m * 5 + j) * ap_stride + 1];
+                are[m][j] = clear_state ? 0.0f : ap_in[(m * 5 + j) * ap_stride];
+                aim[m][j] = clear_state ? 0.0f : ap_in[(m * 5 + j) * ap_stride + 1];
             }
         }
         phre = g_tab[TB_PHIFRACT + (is34 * 50 + kh) * 2];
         phim = g_tab[TB_PHIFRACT + (is34 * 50 + kh) * 2 + 1];
     }
-
     const bool neg_im = (is34 && kh <= 13 && kh >= 9) || (!is34 && kh <= 1);
+    const float *tgrow = w.pw[b];
+    const float2 *src = reinterpret_cast<const float2 *>(&w.tile[0][kh][0]);
+    const float2 *src_d = src - D * W::TS;
+    float *lrow = w.subL[is_sub ? kh : W::NSUB], *rrow = w.subR[is_sub ? kh : W::NSUB];   // row NSUB = scratch
+    // column 0 of every row is rewritten by the hybrid synthesis at the end of the frame
+    const int qs = is_sub ? 0 : q;
+    float *gl0 = XL0 + qs, *gl1 = XL1 + qs, *gr0 = XR0 + qs, *gr1 = XR1 + qs;
 
-    for (int e = 0; e < w.p.num_env; e++) {
-        const int start = w.p.border_position[e], stop = w.p.border_position[e + 1];
-        const float width = 1.f / (stop - start);
-        float h11r = w.Hs[e][0][b], h12r = w.Hs[e][2][b], h21r = w.Hs[e][4][b], h22r = w.Hs[e][6][b];
-        float h11i = 0, h12i = 0, h21i = 0, h22i = 0;
-        float h11i_step = 0, h12i_step = 0, h21i_step = 0, h22i_step = 0;
-        if (enable_ipdopd) {
-            h11i = w.Hs[e][1][b]; h12i = w.Hs[e][3][b]; h21i = w.Hs[e][5][b]; h22i = w.Hs[e][7][b];
-            if (neg_im) { h11i = -h11i; h12i = -h12i; h21i = -h21i; h22i = -h22i; }
-        }
-        const float h11r_step = (w.Hs[e + 1][0][b] - h11r) * width;
-        const float h12r_step = (w.Hs[e + 1][2][b] - h12r) * width;
-        const float h21r_step = (w.Hs[e + 1][4][b] - h21r) * width;
-        const float h22r_step = (w.Hs[e + 1][6][b] - h22r) * width;
-        if (enable_ipdopd) {
-            h11i_step = (w.Hs[e + 1][1][b] - h11i) * width;
-            h12i_step = (w.Hs[e + 1][3][b] - h12i) * width;
-            h21i_step = (w.Hs[e + 1][5][b] - h21i) * width;
-            h22i_step = (w.Hs[e + 1][7][b] - h22i) * width;
-        }
-        for (int n = start + 1; n <= stop; n++) {
-            float sre, sim;
-            src(n, sre, sim);
-            const float tg = w.pw[b][n];
-            float r_re, r_im;
-            if (allpass) {
-                // z^-2 tap (delay[k][n + PS_MAX_DELAY - 2]) times phi_fract
-                float in_re = dre[12] * phre - dim[12] * phim;
-                float in_im = dre[12] * phim + dim[12] * phre;
-#pragma unroll
-                for (int m = 0; m < 3; m++) {
-                    const float a_re = ag[m] * in_re, a_im = ag[m] * in_im;
-                    // link_delay = 3, 4, 5 -> history position 5 - delay
-                    const float ld_re = are[m][2 - m], ld_im = aim[m][2 - m];
-                    float nre = in_re, nim = in_im;
-                    in_re = ld_re * qre[m] - ld_im * qim[m] - a_re;
-                    in_im = ld_re * qim[m] + ld_im * qre[m] - a_im;
-                    nre += ag[m] * in_re;
-                    nim += ag[m] * in_im;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { are[m][j] = are[m][j + 1]; aim[m][j] = aim[m][j + 1]; }
-                    are[m][4] = nre; aim[m][4] = nim;
-                }
-                r_re = tg * in_re;
-                r_im = tg * in_im;
-            } else if (d14) {
-                r_re = tg * dre[0];          // delay[k][n + PS_MAX_DELAY - 14]
-                r_im = tg * dim[0];
-            } else {
-                r_re = tg * dre[13];         // delay[k][n + PS_MAX_DELAY - 1]
-                r_im = tg * dim[13];
-            }
-            // advance the 14-slot delay line (the reference keeps 46 slots and
-            // reads at an offset; a register shift is the same data flow)
-#pragma unroll
-            for (int j = 0; j < 13; j++) { dre[j] = dre[j + 1]; dim[j] = dim[j + 1]; }
-            dre[13] = sre; dim[13] = sim;
+    float h11r = 0, h12r = 0, h21r = 0, h22r = 0, h11i = 0, h12i = 0, h21i = 0, h22i = 0;
+    float h11r_step = 0, h12r_step = 0, h21r_step = 0, h22r_step = 0;
+    float h11i_step = 0, h12i_step = 0, h21i_step = 0, h22i_step = 0;
+    int e = -1, stop = -1;
 
-            h11r += h11r_step; h12r += h12r_step; h21r += h21r_step; h22r += h22r_step;
-            float lre, lim, rre, rim;
-            if (enable_ipdopd) {
-                h11i += h11i_step; h12i += h12i_step; h21i += h21i_step; h22i += h22i_step;
-                lre = h11r * sre + h21r * r_re - h11i * sim - h21i * r_im;
-                lim = h11r * sim + h21r * r_im + h11i * sre + h21i * r_re;
-                rre = h12r * sre + h22r * r_re - h12i * sim - h22i * r_im;
-                rim = h12r * sim + h22r * r_im + h12i * sre + h22i * r_re;
-            } else {
-                lre = h11r * sre + h21r * r_re;
-                lim = h11r * sim + h21r * r_im;
-                rre = h12r * sre + h22r * r_re;
-                rim = h12r * sim + h22r * r_im;
+    // Fully unrolled over the 32 slots: ring positions and state selects are static.
+#pragma unroll
+    for (int n = 0; n < 32; n++) {
+        if ((!ALIGNED8 || (n & 7) == 0) && n > stop) {
+            // next envelope (aacps.c:900-938)
+            e++;
+            const int start = __builtin_amdgcn_readfirstlane(w.p.border_position[e]);
+            stop = __builtin_amdgcn_readfirstlane(w.p.border_position[e + 1]);
+            const float width = 1.f / (stop - start);
+            constexpr int R = W::IS_GENERAL ? 2 : 1;     // row step between H11, H12, H21, H22
+            h11r = w.Hs[e][0][b]; h12r = w.Hs[e][R][b]; h21r = w.Hs[e][2 * R][b]; h22r = w.Hs[e][3 * R][b];
+            h11r_step = (w.Hs[e + 1][0][b] - h11r) * width;
+            h12r_step = (w.Hs[e + 1][R][b] - h12r) * width;
+            h21r_step = (w.Hs[e + 1][2 * R][b] - h21r) * width;
+            h22r_step = (w.Hs[e + 1][3 * R][b] - h22r) * width;
+            if constexpr (W::IS_GENERAL) if (enable_ipdopd) {
+                h11i = w.Hs[e][1][b]; h12i = w.Hs[e][3][b]; h21i = w.Hs[e][5][b]; h22i = w.Hs[e][7][b];
+                if (neg_im) { h11i = -h11i; h12i = -h12i; h21i = -h21i; h22i = -h22i; }
+                h11i_step = (w.Hs[e + 1][1][b] - h11i) * width;
+                h12i_step = (w.Hs[e + 1][3][b] - h12i) * width;
+                h21i_step = (w.Hs[e + 1][5][b] - h21i) * width;
+                h22i_step = (w.Hs[e + 1][7][b] - h22i) * width;
             }
-            sink(n, lre, lim, rre, rim);
         }
+        const float2 sv = src[n * W::TS];
+        const float sre = sv.x, sim = sv.y;
+        const float tg = tgrow[n];
+        // delayed sample s[k][n - D]: one LDS read at a per-lane base (src_d = src - D rows;
+        // for n < D it points below the tile, still inside LDS, and the value is
+        // replaced by the state tail, whose register index is static per category)
+        float dre, dim;
+        {
+            const float2 dv = src_d[n * W::TS];
+            float s_re, s_im;
+            if (HEAVY) {
+                const float a_re = n < 2 ? hre[12 + (n < 2 ? n : 0)] : 0.0f, a_im = n < 2 ? him[12 + (n < 2 ? n : 0)] : 0.0f;
+                const float b_re = n < 14 ? hre[n < 14 ? n : 0] : 0.0f,      b_im = n < 14 ? him[n < 14 ? n : 0] : 0.0f;
+                const float c_re = n < 1 ? hre[13] : 0.0f,                   c_im = n < 1 ? him[13] : 0.0f;
+                s_re = allpass ? a_re : d14 ? b_re : c_re;
+                s_im = allpass ? a_im : d14 ? b_im : c_im;
+            } else {
+                s_re = hre[13]; s_im = him[13];
+            }
+            dre = n >= D ? dv.x : s_re;
+            dim = n >= D ? dv.y : s_im;
+        }
+        float r_re, r_im;
+        if (HEAVY) {
+            // all-pass chain, computed by every lane (no branch inside the slot);
+            // lanes that are plain delays keep the delayed sample instead
+            float in_re = dre * phre - dim * phim;
+            float in_im = dre * phim + dim * phre;
+#pragma unroll
+            for (int m = 0; m < 3; m++) {
+                const float a_re = ag[m] * in_re, a_im = ag[m] * in_im;
+                // link_delay = 3, 4, 5: value written at time n - delay
+                const int rp = (n + 5 - (3 + m)) % 5, wp = n % 5;
+                const float ld_re = are[m][rp], ld_im = aim[m][rp];
+                float nre = in_re, nim = in_im;
+                in_re = ld_re * qre[m] - ld_im * qim[m] - a_re;
+                in_im = ld_re * qim[m] + ld_im * qre[m] - a_im;
+                nre += ag[m] * in_re;
+                nim += ag[m] * in_im;
+                are[m][wp] = nre; aim[m][wp] = nim;
+            }
+            r_re = tg * (allpass ? in_re : dre);
+            r_im = tg * (allpass ? in_im : dim);
+        } else {
+            r_re = tg * dre;
+            r_im = tg * dim;
+        }
+
+        h11r += h11r_step; h12r += h12r_step; h21r += h21r_step; h22r += h22r_step;
+        float lre, lim, rre, rim;
+        if (enable_ipdopd) {
+            h11i += h11i_step; h12i += h12i_step; h21i += h21i_step; h22i += h22i_step;
+            lre = h11r * sre + h21r * r_re - h11i * sim - h21i * r_im;
+            lim = h11r * sim + h21r * r_im + h11i * sre + h21i * r_re;
+            rre = h12r * sre + h22r * r_re - h12i * sim - h22i * r_im;
+            rim = h12r * sim + h22r * r_im + h12i * sre + h22i * r_re;
+        } else {
+            lre = h11r * sre + h21r * r_re;
+            lim = h11r * sim + h21r * r_im;
+            rre = h12r * sre + h22r * r_re;
+            rim = h12r * sim + h22r * r_im;
+        }
+        // Branch-free stores: sub-subband lanes keep L/R in LDS rows (hybrid synthesis sums
+        // them later) and send their global store to column 0, which the hybrid synthesis
+        // rewrites afterwards; QMF lanes store to X and send their LDS store to a scratch row.
+        *reinterpret_cast<float2 *>(lrow + 2 * n) = make_float2(lre, lim);
+        *reinterpret_cast<float2 *>(rrow + 2 * n) = make_float2(rre, rim);
+        gl0[n * 64] = lre; gl1[n * 64] = lim;
+        gr0[n * 64] = rre; gr1[n * 64] = rim;
     }
+    // new delay-line tail = s[k][18..31], straight from the tile
 #pragma unroll
     for (int j = 0; j < 14; j++) {
-        dl_out[j * dl_stride]     = dre[j];
-        dl_out[j * dl_stride + 1] = dim[j];
+        const float2 v = src[(18 + j) * W::TS];
+        dl_out[j * dl_stride]     = v.x;
+        dl_out[j * dl_stride + 1] = v.y;
     }
     if (allpass) {
+        // times 27..31 sit at ring positions (27 + j) % 5
 #pragma unroll
         for (int m = 0; m < 3; m++)
 #pragma unroll
             for (int j = 0; j < 5; j++) {
-                ap_out[(m * 5 + j) * ap_stride]     = are[m][j];
-                ap_out[(m * 5 + j) * ap_stride + 1] = aim[m][j];
+                ap_out[(m * 5 + j) * ap_stride]     = are[m][(27 + j) % 5];
+                ap_out[(m * 5 + j) * ap_stride + 1] = aim[m][(27 + j) % 5];
             }
     }
 }
 
-__device__ __forceinline__ void ps_frame(PsWave &w, const float *__restrict__ g_tab,
+// power[i][n] = sum over the members of parameter band i (ascending hybrid band) of |s|^2.
+// The member lists are constexpr, so both loops unroll into straight-line LDS reads.
+template <bool IS34, int I>
+__device__ __forceinline__ void band_power_one(const float2 *row, float *pw_col)
+{
+    constexpr int J0 = IS34 ? kMem34.first[I] : kMem20.first[I];
+    constexpr int J1 = IS34 ? kMem34.first[I + 1] : kMem20.first[I + 1];
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = J0; j < J1; j++) {
+        const float2 v = row[IS34 ? kMem34.order[j] : kMem20.order[j]];
+        acc += v.x * v.x + v.y * v.y;
+    }
+    pw_col[I * 33] = acc;          // pw[I][n]
+}
+template <bool IS34, int I0, int I1>
+__device__ __forceinline__ void band_power_range(const float2 *row, float *pw_col)
+{
+    if constexpr (I0 < I1) {
+        band_power_one<IS34, I0>(row, pw_col);
+        band_power_range<IS34, I0 + 1, I1>(row, pw_col);
+    }
+}
+template <bool IS34>
+__device__ __forceinline__ void band_power(const float2 *row, float *pw_col, int half)
+{
+    constexpr int SPLIT = IS34 ? kMem34.split : kMem20.split;
+    constexpr int NPAR_ = IS34 ? 34 : 20;
+    if (half == 0) band_power_range<IS34, 0, SPLIT>(row, pw_col);
+    else           band_power_range<IS34, SPLIT, NPAR_>(row, pw_col);
+}
+
+// Which kernel variant owns a frame: the small-LDS one takes frames that are and
+// were 20-band (and frames with PS off), the general one everything else.
+__device__ __forceinline__ bool ps_frame_is_general(const HeaacPsFrame *g_p)
+{
+    return g_p->start && (g_p->is34bands || g_p->is34bands_old || g_p->enable_ipdopd);
+}
+
+template <bool GENERAL>
+__device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__restrict__ g_tab,
                                          const HeaacPsFrame *g_p, int top_qmf,
                                          const float *st_in, float *st_out,
                                          float *XL /* [2][38][64] in: mono, out: left */,
-                                         float *XR /* [2][38][64] out: right */, int lane)
+                                         float *XR /* [2][38][64] out: right */, int lane, int wave = 0)
 {
+    using WT = PsWaveT<GENERAL>;
     {
         const uint32_t *s = reinterpret_cast<const uint32_t *>(g_p);
-        uint32_t *d = reinterpret_cast<uint32_t *>(&w.p);
+        uint32_t *d = reinterpret_cast<uint32_t *>(&w.p);   // w.p is a reference into LDS
         for (int i = lane; i < (int)(sizeof(HeaacPsFrame) / 4); i += WAVE) d[i] = s[i];
     }
     wave_sync();
+    STAMP(0);
     const HeaacPsFrame &p = w.p;
     float *XL0 = XL, *XL1 = XL + 38 * 64, *XR0 = XR, *XR1 = XR + 38 * 64;
 
@@ -311,31 +444,47 @@ __device__ __forceinline__ void ps_frame(PsWave &w, const float *__restrict__ g_
         return;
     }
 
-    const int is34 = p.is34bands;
+    const int is34 = GENERAL ? p.is34bands : 0;
     const int nr_bands = is34 ? 91 : 71, nr_par = is34 ? 34 : 20, nr_allpass = is34 ? 50 : 30;
     const int nsub = is34 ? 32 : 10, nlow = is34 ? 5 : 3;     // sub-subbands / hybrid QMF bands
     const int top = top_qmf + nr_bands - 64;                  // aacps.c:980
-    const bool switched = is34 != p.is34bands_old;
+    const bool switched = GENERAL && is34 != p.is34bands_old;
+    const BandMembers &M = is34 ? kMem34 : kMem20;
 
-    for (int k = lane; k < nr_bands; k += WAVE) w.kti[k] = is34 ? k_to_i_34_d[k] : k_to_i_20_d[k];
-
-    // ---- hybrid analysis input (aacps.c:362-367): in[i][j+6] = L[.][j][i] ----
-    for (int t = lane; t < 5 * 6; t += WAVE) {
+    // ---- stage this frame's QMF rows in LDS: every load is in flight at once ----
+    // tile[n][kh]: kh < nsub sub-subbands (filled below), kh >= nsub <- QMF band kh - nsub + nlow
+    {
+        const int q = lane, kh = q - nlow + nsub;
+        float re[32], im[32];
+#pragma unroll
+        for (int n = 0; n < 32; n++) { re[n] = XL0[n * 64 + q]; im[n] = XL1[n * 64 + q]; }
+        if (q >= nlow) {
+#pragma unroll
+            for (int n = 0; n < 32; n++) { w.tile[n][kh][0] = re[n]; w.tile[n][kh][1] = im[n]; }
+        } else if (q < nlow) {
+            // hybrid analysis input (aacps.c:362-367): in[i][j+6] = L[.][j][i]
+#pragma unroll
+            for (int n = 0; n < 32; n++) { w.inb[q][n + 6][0] = re[n]; w.inb[q][n + 6][1] = im[n]; }
+        }
+    }
+    for (int t = lane; t < nlow * 6; t += WAVE) {
         const int i = t / 6, j = t % 6;
         w.inb[i][j][0] = st_in[HEAAC_PS_INBUF + t * 2];
         w.inb[i][j][1] = st_in[HEAAC_PS_INBUF + t * 2 + 1];
-    }
-    for (int t = lane; t < 5 * 38; t += WAVE) {
-        const int i = t % 5, j = t / 5;
-        w.inb[i][j + 6][0] = XL0[j * 64 + i];
-        w.inb[i][j + 6][1] = XL1[j * 64 + i];
+        // lookahead slots 32..37
+        w.inb[i][38 + j][0] = XL0[(32 + j) * 64 + i];
+        w.inb[i][38 + j][1] = XL1[(32 + j) * 64 + i];
     }
     wave_sync();
-    // in_buf update (:391-394): in[i][0..5] <- in[i][32..37]
+    STAMP(1);
+    // in_buf update (:391-394): in[i][0..5] <- in[i][32..37] = L[.][26..31][i], all 5 bands
     for (int t = lane; t < 5 * 6; t += WAVE) {
         const int i = t / 6, j = t % 6;
-        st_out[HEAAC_PS_INBUF + t * 2]     = w.inb[i][32 + j][0];
-        st_out[HEAAC_PS_INBUF + t * 2 + 1] = w.inb[i][32 + j][1];
+        float re, im;
+        if (i < nlow) { re = w.inb[i][32 + j][0]; im = w.inb[i][32 + j][1]; }
+        else          { re = XL0[(26 + j) * 64 + i]; im = XL1[(26 + j) * 64 + i]; }
+        st_out[HEAAC_PS_INBUF + t * 2]     = re;
+        st_out[HEAAC_PS_INBUF + t * 2 + 1] = im;
     }
     // ---- hybrid filters -> sub[ks][n] ----
     for (int t = lane; t < nsub * 32; t += WAVE) {
@@ -348,19 +497,16 @@ __device__ __forceinline__ void ps_frame(PsWave &w, const float *__restrict__ g_
             else              { qb = 2 + ((ks - 20) >> 2); f = (ks - 20) & 3; off = TB_F34_2_4; }
             hybrid_fir(&w.inb[qb][n][0], g_tab + off + f * 14, re, im);
         } else if (ks < 6) {
-            // hybrid6_cx output order (:322-334)
+            // hybrid6_cx (:303-336): out = temp[fa] (+ temp[fb]); order 6,7,0,1,2+5,3+4
             const float *in = &w.inb[0][n][0];
             const float *F = g_tab + TB_F20_0_8;
-            if (ks == 0)      hybrid_fir(in, F + 6 * 14, re, im);
-            else if (ks == 1) hybrid_fir(in, F + 7 * 14, re, im);
-            else if (ks == 2) hybrid_fir(in, F + 0 * 14, re, im);
-            else if (ks == 3) hybrid_fir(in, F + 1 * 14, re, im);
-            else {
-                float ar, ai, br, bi;
-                hybrid_fir(in, F + (ks == 4 ? 2 : 3) * 14, ar, ai);
+            const int fa = ks == 0 ? 6 : ks == 1 ? 7 : ks == 2 ? 0 : ks == 3 ? 1 : ks == 4 ? 2 : 3;
+            hybrid_fir(in, F + fa * 14, re, im);
+            if (ks >= 4) {
+                float br, bi;
                 hybrid_fir(in, F + (ks == 4 ? 5 : 4) * 14, br, bi);
-                re = ar + br;
-                im = ai + bi;
+                re = re + br;
+                im = im + bi;
             }
         } else {
             // hybrid2_re (:283-301): band 1 reversed, band 2 not
@@ -379,38 +525,38 @@ __device__ __forceinline__ void ps_frame(PsWave &w, const float *__restrict__ g_
             if (which == reverse) { re = re_in + re_op; im = im_in + im_op; }
             else                  { re = re_in - re_op; im = im_in - im_op; }
         }
-        w.sub[ks][2 * n] = re;
-        w.sub[ks][2 * n + 1] = im;
-        w.pn[n * PN_STRIDE + ks] = re * re + im * im;
-    }
-    // |s|^2 of the plain QMF bands
-    for (int n = 0; n < 32; n++) {
-        const int q = lane;
-        if (q >= nlow) {
-            const float re = XL0[n * 64 + q], im = XL1[n * 64 + q];
-            w.pn[n * PN_STRIDE + q - nlow + nsub] = re * re + im * im;
-        }
+        w.tile[n][ks][0] = re;
+        w.tile[n][ks][1] = im;
     }
     wave_sync();
 
-    // ---- band power (aacps.c:673-678): ascending k per parameter band ----
-    for (int t = lane; t < nr_par * 32; t += WAVE) {
-        const int i = t >> 5, n = t & 31;
-        float acc = 0.0f;
-        for (int k = 0; k < nr_bands; k++)
-            if (w.kti[k] == i)
-                acc += w.pn[n * PN_STRIDE + k];
-        w.pw[i][n] = acc;
+    STAMP(2);
+    // ---- band power (aacps.c:673-678): members of each parameter band in ascending
+    // hybrid-band order.  The member lists are compile-time constants, so the sums
+    // unroll into straight-line LDS reads; two half-waves split the parameter bands.
+    {
+        const int n = lane & 31, half = lane >> 5;
+        const float2 *row = reinterpret_cast<const float2 *>(&w.tile[n][0][0]);
+        if (is34) {
+            if constexpr (GENERAL) band_power<true>(row, &w.pw[0][n], half);
+        } else {
+            band_power<false>(row, &w.pw[0][n], half);
+        }
     }
     wave_sync();
+    STAMP(3);
     // ---- transient detection (:681-692), one lane per parameter band ----
     if (lane < nr_par) {
         const int i = lane;
         float peak = switched ? 0.0f : st_in[HEAAC_PS_PEAK + i];
         float smooth = switched ? 0.0f : st_in[HEAAC_PS_PSMOOTH + i];
         float diff = switched ? 0.0f : st_in[HEAAC_PS_PDIFF + i];
+        float prow[32];
+#pragma unroll
+        for (int n = 0; n < 32; n++) prow[n] = w.pw[i][n];
+#pragma unroll
         for (int n = 0; n < 32; n++) {
-            const float pwr = w.pw[i][n];
+            const float pwr = prow[n];
             const float decayed_peak = 0.76592833836465f * peak;
             peak = decayed_peak > pwr ? decayed_peak : pwr;
             smooth += 0.25f * (pwr - smooth);
@@ -429,9 +575,10 @@ __device__ __forceinline__ void ps_frame(PsWave &w, const float *__restrict__ g_
         st_out[HEAAC_PS_PDIFF + i]   = switched ? 0.0f : st_in[HEAAC_PS_PDIFF + i];
     }
 
+    STAMP(4);
     // ---- parameter remapping + H matrices (aacps.c:817-899) ----
-    for (int t = lane; t < 5 * 34; t += WAVE) {
-        const int e = t / 34, b = t % 34;
+    for (int t = lane; t < 5 * WT::NPAR; t += WAVE) {
+        const int e = t / WT::NPAR, b = t % WT::NPAR;
         int iid = 0, icc = 0, ipd = 0, opd = 0;
         if (e < p.num_env && b < nr_par) {
             iid = remap_idx(p.iid_par[e], p.nr_iid_par, is34, b);
@@ -445,9 +592,9 @@ __device__ __forceinline__ void ps_frame(PsWave &w, const float *__restrict__ g_
         w.ipd_m[e][b] = (signed char)ipd; w.opd_m[e][b] = (signed char)opd;
     }
     // row 0 = H of the last envelope of the previous frame, remapped on a 20<->34 switch
-    for (int t = lane; t < 8 * 34; t += WAVE) {
-        const int j = t / 34, b = t % 34;
-        const float *row = st_in + HEAAC_PS_H + j * 34;
+    for (int t = lane; t < WT::NH * WT::NPAR; t += WAVE) {
+        const int j = t / WT::NPAR, b = t % WT::NPAR;
+        const float *row = st_in + HEAAC_PS_H + (GENERAL ? j : 2 * j) * 34;   // baseline keeps the real rows
         w.Hs[0][j][b] = switched ? remap_val(row, is34, b) : row[b];
     }
     wave_sync();
@@ -457,11 +604,22 @@ __device__ __forceinline__ void ps_frame(PsWave &w, const float *__restrict__ g_
         const signed char *hist = reinterpret_cast<const signed char *>(st_in + HEAAC_PS_HIST);
         int opd_hist = hist[b], ipd_hist = hist[34 + b];
         if (switched && b < 17) { opd_hist = 0; ipd_hist = 0; }        // ipdopd_reset
-        for (int e = 0; e < p.num_env; e++) {
-            const float *h = LUT + ((w.iid_m[e][b] + 7 + 23 * p.iid_quant) * 8 + w.icc_m[e][b]) * 4;
-            float h11 = h[0], h12 = h[1], h21 = h[2], h22 = h[3];
+        // fetch every envelope's LUT row first (independent loads), then run the
+        // IPD/OPD history chain over them
+        float hl[5][4];
+#pragma unroll
+        for (int e = 0; e < 5; e++) {
+            const int ee = e < p.num_env ? e : 0;
+            const float4 h4 = *reinterpret_cast<const float4 *>(
+                LUT + ((w.iid_m[ee][b] + 7 + 23 * p.iid_quant) * 8 + w.icc_m[ee][b]) * 4);
+            hl[e][0] = h4.x; hl[e][1] = h4.y; hl[e][2] = h4.z; hl[e][3] = h4.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 5; e++) {
+            if (e >= p.num_env) break;
+            float h11 = hl[e][0], h12 = hl[e][1], h21 = hl[e][2], h22 = hl[e][3];
             float h11i = 0.0f, h12i = 0.0f, h21i = 0.0f, h22i = 0.0f;
-            if (p.enable_ipdopd && b < p.nr_ipdopd_par) {
+            if (GENERAL && p.enable_ipdopd && b < p.nr_ipdopd_par) {
                 const int opd_idx = opd_hist * 8 + w.opd_m[e][b];
                 const int ipd_idx = ipd_hist * 8 + w.ipd_m[e][b];
                 const float opd_re = g_tab[TB_PD_RE + opd_idx], opd_im = g_tab[TB_PD_IM + opd_idx];
@@ -475,10 +633,15 @@ __device__ __forceinline__ void ps_frame(PsWave &w, const float *__restrict__ g_
                 h21i = h21 * opd_im;     h21 = h21 * opd_re;
                 h22i = h22 * ipd_adj_im; h22 = h22 * ipd_adj_re;
             }
-            w.Hs[e + 1][0][b] = h11; w.Hs[e + 1][1][b] = h11i;
-            w.Hs[e + 1][2][b] = h12; w.Hs[e + 1][3][b] = h12i;
-            w.Hs[e + 1][4][b] = h21; w.Hs[e + 1][5][b] = h21i;
-            w.Hs[e + 1][6][b] = h22; w.Hs[e + 1][7][b] = h22i;
+            if constexpr (GENERAL) {
+                w.Hs[e + 1][0][b] = h11; w.Hs[e + 1][1][b] = h11i;
+                w.Hs[e + 1][2][b] = h12; w.Hs[e + 1][3][b] = h12i;
+                w.Hs[e + 1][4][b] = h21; w.Hs[e + 1][5][b] = h21i;
+                w.Hs[e + 1][6][b] = h22; w.Hs[e + 1][7][b] = h22i;
+            } else {
+                w.Hs[e + 1][0][b] = h11; w.Hs[e + 1][1][b] = h12;
+                w.Hs[e + 1][2][b] = h21; w.Hs[e + 1][3][b] = h22;
+            }
         }
         // new history (bytes of two packed rows)
         signed char *ho = reinterpret_cast<signed char *>(st_out + HEAAC_PS_HIST);
@@ -496,48 +659,65 @@ __device__ __forceinline__ void ps_frame(PsWave &w, const float *__restrict__ g_
     }
     wave_sync();
     // H state out: real rows always, imaginary rows only while IPD/OPD is on
-    for (int t = lane; t < 8 * 34; t += WAVE) {
-        const int j = t / 34, b = t % 34;
-        const bool imag = j & 1;
-        float v;
-        if (!imag) v = b < nr_par ? w.Hs[p.num_env][j][b] : 0.0f;
-        else if (p.enable_ipdopd) v = b < nr_par ? w.Hs[p.num_env][j][b] : 0.0f;
-        else v = st_in[HEAAC_PS_H + t];
-        st_out[HEAAC_PS_H + t] = v;
+    if constexpr (GENERAL) {
+        for (int t = lane; t < 8 * 34; t += WAVE) {
+            const int j = t / 34, b = t % 34;
+            const bool imag = j & 1;
+            float v;
+            if (!imag || p.enable_ipdopd) v = b < nr_par ? w.Hs[p.num_env][j][b] : 0.0f;
+            else v = st_in[HEAAC_PS_H + t];
+            st_out[HEAAC_PS_H + t] = v;
+        }
+    } else {
+        for (int t = lane; t < 4 * 34; t += WAVE) {
+            const int j = t / 34, b = t % 34;
+            st_out[HEAAC_PS_H + 2 * j * 34 + b] = b < 20 ? w.Hs[p.num_env][j][b] : 0.0f;
+        }
+        if (st_out != st_in)
+            for (int t = lane; t < 4 * 34; t += WAVE) {
+                const int j = t / 34, b = t % 34;
+                st_out[HEAAC_PS_H + (2 * j + 1) * 34 + b] = st_in[HEAAC_PS_H + (2 * j + 1) * 34 + b];
+            }
     }
 
     const float *dl_in = st_in + HEAAC_PS_DELAY;
     float *dl_out = st_out + HEAAC_PS_DELAY;
     const float *ap_in = st_in + HEAAC_PS_APDELAY;
     float *ap_out = st_out + HEAAC_PS_APDELAY;
-
-    // ---- pass A: plain QMF bands q >= nlow, hybrid index kh = q - nlow + nsub ----
-    if (lane >= nlow) {
-        const int q = lane, kh = q - nlow + nsub;
-        ps_band(w, g_tab, is34, kh, switched || kh >= top, switched || kh >= top,
-                dl_in + kh * 2, dl_out + kh * 2, 91 * 2, ap_in + kh * 2, ap_out + kh * 2, 50 * 2,
-                [&](int n, float &re, float &im) { re = XL0[n * 64 + q]; im = XL1[n * 64 + q]; },
-                [&](int n, float lre, float lim, float rre, float rim) {
-                    XL0[n * 64 + q] = lre; XL1[n * 64 + q] = lim;
-                    XR0[n * 64 + q] = rre; XR1[n * 64 + q] = rim;
-                });
-    }
-    // ---- pass B: hybrid sub-subbands ----
-    float *subR = w.pn;                  // |s|^2 is dead: reuse as R rows [ks][SUB_STRIDE]
-    wave_sync();
-    if (lane < nsub) {
+    STAMP(5);
+    // every border at 8k - 1 (what frame_class 0 produces): fast straight-line variant
+    bool aligned8 = true;
+    for (int e = 1; e <= p.num_env; e++) aligned8 = aligned8 && ((p.border_position[e] & 7) == 7);
+    aligned8 = __builtin_amdgcn_readfirstlane(aligned8);
+    // ---- pass 1: hybrid bands 0..63 = all sub-subbands + the first QMF bands ----
+    {
         const int kh = lane;
-        float *srow = w.sub[kh];
-        float *rrow = subR + kh * SUB_STRIDE;
-        ps_band(w, g_tab, is34, kh, switched || kh >= top, switched || kh >= top,
-                dl_in + kh * 2, dl_out + kh * 2, 91 * 2, ap_in + kh * 2, ap_out + kh * 2, 50 * 2,
-                [&](int n, float &re, float &im) { re = srow[2 * n]; im = srow[2 * n + 1]; },
-                [&](int n, float lre, float lim, float rre, float rim) {
-                    srow[2 * n] = lre; srow[2 * n + 1] = lim;
-                    rrow[2 * n] = rre; rrow[2 * n + 1] = rim;
-                });
+        const bool is_sub = kh < nsub;
+        if (aligned8)
+            ps_band<true, true>(w, g_tab, M.kti, is34, kh, switched || kh >= top,
+                                dl_in + kh * 2, dl_out + kh * 2, ap_in + kh * 2, ap_out + kh * 2,
+                                is_sub, kh - nsub + nlow, XL0, XL1, XR0, XR1);
+        else
+            ps_band<true, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top,
+                                 dl_in + kh * 2, dl_out + kh * 2, ap_in + kh * 2, ap_out + kh * 2,
+                                 is_sub, kh - nsub + nlow, XL0, XL1, XR0, XR1);
     }
+    STAMP(6);
+    // ---- pass 2: hybrid bands 64.. (all use the one-slot delay) ----
+    if (lane < nr_bands - 64) {
+        const int kh = 64 + lane;
+        if (aligned8)
+            ps_band<false, true>(w, g_tab, M.kti, is34, kh, switched || kh >= top,
+                                 dl_in + kh * 2, dl_out + kh * 2, ap_in, ap_out,
+                                 false, kh - nsub + nlow, XL0, XL1, XR0, XR1);
+        else
+            ps_band<false, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top,
+                                  dl_in + kh * 2, dl_out + kh * 2, ap_in, ap_out,
+                                  false, kh - nsub + nlow, XL0, XL1, XR0, XR1);
+    }
+    STAMP(7);
     // bands that exist in the state record but not in this layout / all-pass set
+    if (st_out != st_in || switched)
     for (int t = lane; t < 14 * 91; t += WAVE) {
         const int k = t % 91;
         if (k >= nr_bands) {
@@ -545,6 +725,7 @@ __device__ __forceinline__ void ps_frame(PsWave &w, const float *__restrict__ g_
             dl_out[t * 2 + 1] = switched ? 0.0f : dl_in[t * 2 + 1];
         }
     }
+    if (st_out != st_in || switched)
     for (int t = lane; t < 15 * 50; t += WAVE) {
         const int k = t % 50;
         if (k >= nr_allpass) {
@@ -554,20 +735,21 @@ __device__ __forceinline__ void ps_frame(PsWave &w, const float *__restrict__ g_
     }
     wave_sync();
 
+    STAMP(8);
     // ---- hybrid synthesis (aacps.c:397-445) for the lowest QMF bands ----
-    for (int t = lane; t < 2 * 32; t += WAVE) {
-        const int n = t & 31, side = t >> 5;
-        const float *rows = side ? subR : &w.sub[0][0];
+    {
+        const int n = lane & 31, side = lane >> 5;
+        const float *rows = side ? &w.subR[0][0] : &w.subL[0][0];
         float *O0 = side ? XR0 : XL0, *O1 = side ? XR1 : XL1;
 #define SUBV(i, c) rows[(i) * SUB_STRIDE + 2 * n + (c)]
         if (is34) {
             const int first[5] = { 0, 12, 20, 24, 28 }, cnt[5] = { 12, 8, 4, 4, 4 };
 #pragma unroll
-            for (int q = 0; q < 5; q++) {
+            for (int qq = 0; qq < 5; qq++) {
                 float re = 0.0f, im = 0.0f;
-                for (int i = 0; i < cnt[q]; i++) { re += SUBV(first[q] + i, 0); im += SUBV(first[q] + i, 1); }
-                O0[n * 64 + q] = re;
-                O1[n * 64 + q] = im;
+                for (int i = 0; i < cnt[qq]; i++) { re += SUBV(first[qq] + i, 0); im += SUBV(first[qq] + i, 1); }
+                O0[n * 64 + qq] = re;
+                O1[n * 64 + qq] = im;
             }
         } else {
             O0[n * 64 + 0] = SUBV(0, 0) + SUBV(1, 0) + SUBV(2, 0) + SUBV(3, 0) + SUBV(4, 0) + SUBV(5, 0);
@@ -580,34 +762,64 @@ __device__ __forceinline__ void ps_frame(PsWave &w, const float *__restrict__ g_
 #undef SUBV
     }
     wave_sync();
+    STAMP(9);
 }
 
-__global__ __launch_bounds__(PS_WAVES * WAVE)
+template <bool GENERAL, int WAVES>
+__global__ __launch_bounds__(WAVES * WAVE)
 void k_ps(const float *__restrict__ g_tab, const HeaacPsFrame *__restrict__ g_ps,
           const HeaacSbrFrame *__restrict__ g_sbr, const HeaacSbrHeader *__restrict__ g_hdr,
           const float *g_state_in, float *g_state_out, int state_words, int off_ps,
           float *g_X, unsigned long long n)
 {
-    __shared__ PsWave S[PS_WAVES];
-    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-    for (unsigned long long f = (unsigned long long)blockIdx.x * PS_WAVES + wave; f < n;
-         f += (unsigned long long)gridDim.x * PS_WAVES) {
+    using WT = PsWaveT<GENERAL>;
+    __shared__ HeaacPsFrame s_p[WAVES];
+    __shared__ float s_inb[WAVES][WT::NLOW][44][2];
+    __shared__ float s_subL[WAVES][WT::NSUB + 1][SUB_STRIDE];      // + 1 scratch row
+    __shared__ float s_subR[WAVES][WT::NSUB + 1][SUB_STRIDE];
+    __shared__ float s_pw[WAVES][WT::NPAR][33];
+    __shared__ float s_Hs[WAVES][6][WT::NH][WT::NPAR];
+    __shared__ signed char s_idx[WAVES][4][5][WT::NPAR];
+    __shared__ float s_tile[WAVES][32][WT::TS][2];   // last: rows below a wave's tile base are still LDS
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
+    WT W = { s_p[wave], s_inb[wave], s_tile[wave], s_subL[wave], s_subR[wave], s_pw[wave], s_Hs[wave],
+             s_idx[wave][0], s_idx[wave][1], s_idx[wave][2], s_idx[wave][3] };
+    for (unsigned long long f = (unsigned long long)blockIdx.x * WAVES + wave; f < n;
+         f += (unsigned long long)gridDim.x * WAVES) {
+        if (ps_frame_is_general(&g_ps[f]) != GENERAL)
+            continue;                               // the other variant owns this frame
         const HeaacSbrHeader &h = g_hdr[g_sbr[f].hdr];
         const int top = h.kx + h.m;                 // ff_ps_apply(..., sbr->kx[1] + sbr->m[1])
         float *XL = g_X + (f * 2) * (2 * 38 * 64);
-        ps_frame(S[wave], g_tab, &g_ps[f], top, g_state_in + f * state_words + off_ps,
-                 g_state_out + f * state_words + off_ps, XL, XL + 2 * 38 * 64, lane);
+        ps_frame<GENERAL>(W, g_tab, &g_ps[f], top, g_state_in + f * state_words + off_ps,
+                          g_state_out + f * state_words + off_ps, XL, XL + 2 * 38 * 64, lane, wave);
     }
 }
+
+#define PS_WAVES_20 5
+#define PS_WAVES_GEN 2
 
 extern "C" int heaac_launch_ps(const float *d_tab, const HeaacPsFrame *d_ps, const HeaacSbrFrame *d_sbr,
                                const HeaacSbrHeader *d_hdr, const float *d_state_in, float *d_state_out,
                                int state_words, int off_ps, float *d_ws_X, size_t n, hipStream_t s)
 {
     if (!n) return HEAAC_OK;
-    unsigned long long g = (n + PS_WAVES - 1) / PS_WAVES;
+    unsigned long long g = (n + PS_WAVES_20 - 1) / PS_WAVES_20;
     if (g > 256) g = 256;
-    hipLaunchKernelGGL(k_ps, dim3((unsigned)g), dim3(PS_WAVES * WAVE), 0, s, d_tab, d_ps, d_sbr, d_hdr,
-                       d_state_in, d_state_out, state_words, off_ps, d_ws_X, (unsigned long long)n);
+    hipLaunchKernelGGL((k_ps<false, PS_WAVES_20>), dim3((unsigned)g), dim3(PS_WAVES_20 * WAVE), 0, s, d_tab,
+                       d_ps, d_sbr, d_hdr, d_state_in, d_state_out, state_words, off_ps, d_ws_X,
+                       (unsigned long long)n);
+    g = (n + PS_WAVES_GEN - 1) / PS_WAVES_GEN;
+    if (g > 256) g = 256;
+    hipLaunchKernelGGL((k_ps<true, PS_WAVES_GEN>), dim3((unsigned)g), dim3(PS_WAVES_GEN * WAVE), 0, s, d_tab,
+                       d_ps, d_sbr, d_hdr, d_state_in, d_state_out, state_words, off_ps, d_ws_X,
+                       (unsigned long long)n);
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
 }
+
+#ifdef PS_STAMPS
+extern "C" int heaac_debug_ps_stamps(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ps_stamps), sizeof(g_ps_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
