@@ -51,6 +51,8 @@ SBR_HDR_DT = np.dtype([
     ("patch_num_subbands", "u1", (6,)), ("patch_start_subband", "u1", (6,)),
     ("f_tablenoise", "u1", (6,)), ("pad1", "u1", (2,)),
     ("f_tablelow", "u1", (28,)), ("f_tablehigh", "u1", (52,)), ("f_tablelim", "u1", (32,)),
+    ("map_hi", "u1", (64,)), ("map_lo", "u1", (64,)), ("map_nq", "u1", (64,)),
+    ("map_lim", "u1", (64,)), ("map_mid", "u1", (64,)), ("map_src", "u1", (64,)),
 ])
 SBR_CH_DT = np.dtype([
     ("bs_num_env", "u1"), ("bs_num_noise", "u1"), ("bs_amp_res", "u1"), ("bs_add_harmonic_flag", "u1"),
@@ -71,7 +73,7 @@ PS_FRAME_DT = np.dtype([
     ("iid_par", "i1", (5, 34)), ("icc_par", "i1", (5, 34)),
     ("ipd_par", "i1", (5, 17)), ("opd_par", "i1", (5, 17)), ("pad2", "u1", (2,)),
 ])
-assert SBR_HDR_DT.itemsize == 148 and SBR_CH_DT.itemsize == 336
+assert SBR_HDR_DT.itemsize == 532 and SBR_CH_DT.itemsize == 336
 assert SBR_FRAME_DT.itemsize == 680 and PS_FRAME_DT.itemsize == 532
 
 # Every symbol include/*.h declares (checked by tests/test_abi.py).

@@ -19,6 +19,13 @@
 
 #define ENV_ADJ 2          // ENVELOPE_ADJUSTMENT_OFFSET, aacsbr.c:39
 
+#ifdef HF_STAMPS
+__device__ unsigned long long g_hf_stamps[16];
+#define HSTAMP(i) do { wave_sync(); if (lane == 0 && blockIdx.x == 7 && threadIdx.x < 64) g_hf_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define HSTAMP(i) do {} while (0)
+#endif
+
 // exp2f(twice / 2.0f) for integer `twice`: exact powers of two, or sqrt(2)
 // (0x3FB504F3, what glibc's exp2f(0.5f) returns) times a power of two.
 // sbr_dequant's arguments are always multiples of 0.5 (aacsbr.c:1099-1125).
@@ -104,7 +111,7 @@ void k_core_ana(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_
     for (int i = threadIdx.x; i < 320; i += blockDim.x) S.qmf_ds[i] = g_tab[TB_QMF_DS + i];
     for (int i = threadIdx.x; i < 64; i += blockDim.x)  S.rot[i] = g_tab[TB_ROT128A + i];
     __syncthreads();
-    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
     float *pool = S.pool[wave];
     const float *c16 = S.core.tab + TB_COS16, *c32 = S.core.tab + TB_COS32;
 
@@ -142,7 +149,11 @@ void k_core_ana(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_
 // ===========================================================================
 // K_B  HF generation + envelope adjustment + x_gen, one wave per SBR channel
 // ===========================================================================
-#define HF_WAVES 6
+// Lane = QMF band k (m = k - kx for the SBR range).  Everything that is per band
+// and per envelope (mapped scalefactors, estimated envelope, gains) lives in that
+// lane's registers; the only cross-lane steps are the limiter-band sums of
+// sbr_gain_calc, which go through small LDS arrays in the reference's order.
+#define HF_WAVES 8
 #define XL_STRIDE 81              // X_low row: 40 slots * (re,im) + 1 pad (bank spread)
 #define MAXM 48                   // e_origmapped[7][48] etc. in the reference (sbr.h:165-177)
 #define MAXE 5
@@ -150,15 +161,9 @@ void k_core_ana(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_
 struct HfWave {
     float xlow[32 * XL_STRIDE];   // X_low[k][i][re,im]
     float alpha0[32][2], alpha1[32][2];
-    float kc[MAXM][4];            // hf_gen coefficients alpha[0..3] per HF band m
-    int   kp[MAXM];               // patch source band, -1: band above the last patch (zeros)
-    float e_orig[MAXE][MAXM], q_map[MAXE][MAXM], e_curr[MAXE][MAXM];
-    float gain[MAXE][MAXM], q_m[MAXE][MAXM], s_m[MAXE][MAXM];
-    float ghist[4][MAXM], qhist[4][MAXM];
     float bw[8];
-    int   env_of[40];
-    uint8_t s_idx[MAXE + 1][MAXM];
-    uint8_t s_map[MAXE][MAXM];
+    float sumA[MAXE][MAXM], sumB[MAXE][MAXM];     // per-band terms of the limiter-band sums
+    float bandv[MAXE][32];                        // gain_max / gain_boost per (envelope, limiter band)
     HeaacSbrHeader h;
     HeaacSbrChannel c[2];
 };
@@ -200,81 +205,133 @@ __device__ __forceinline__ float deq_noise(const HfWave &w, int coupling, int ch
     return exp2_half(2 * (6 - (int)w.c[ch].noise_facs_q[e][i]));   // exp2f(6 - q)
 }
 
-// X_high[kx + m][idx] of sbr_hf_gen (aacsbr.c:1388-1402), recomputed on demand.
-__device__ __forceinline__ void xhigh(const HfWave &w, int m, int idx, float &re, float &im)
-{
-    const int p = w.kp[m];
-    if (p < 0) { re = 0.0f; im = 0.0f; return; }
-    const float *xl = w.xlow + p * XL_STRIDE + 2 * idx;
-    const float a0 = w.kc[m][0], a1 = w.kc[m][1], a2 = w.kc[m][2], a3 = w.kc[m][3];
-    re = xl[-4] * a0 - xl[-3] * a1 + xl[-2] * a2 - xl[-1] * a3 + xl[0];
-    im = xl[-3] * a0 + xl[-4] * a1 + xl[-1] * a2 + xl[-2] * a3 + xl[1];
-}
-
 #define FFMIN_(a, b) ((a) > (b) ? (b) : (a))
 
-__device__ __forceinline__ void hf_channel(HfWave &w, const float *__restrict__ g_noise,
+// X_high[k][idx] from three consecutive X_low samples of the patch source band
+// (sbr_hf_gen, aacsbr.c:1388-1402); x2 = X_low[p][idx-2], x1 = [idx-1], x0 = [idx].
+__device__ __forceinline__ void xhigh3(float2 x2, float2 x1, float2 x0, const float *a, float &re, float &im)
+{
+    re = x2.x * a[0] - x2.y * a[1] + x1.x * a[2] - x1.y * a[3] + x0.x;
+    im = x2.y * a[0] + x2.x * a[1] + x1.y * a[2] + x1.x * a[3] + x0.y;
+}
+
+__device__ __forceinline__ void hf_channel(HfWave &w, const float *g_noise /* LDS */,
                                            const HeaacSbrFrame *g_fr, const HeaacSbrHeader *g_hdr,
                                            int ch, const float *g_W,
                                            const float *st_in, float *st_out,
                                            float *g_X /* [2][38][64] */, int lane)
 {
-    // ---- parameters into LDS (uniform reads afterwards) ----
+    HSTAMP(0);
+    // ---- issue every global load up front: parameters, W, state ----
     const int hdr_idx = g_fr->hdr;
-    lds_copy_bytes(&w.h, &g_hdr[hdr_idx], sizeof(HeaacSbrHeader), lane);
-    lds_copy_bytes(&w.c[0], &g_fr->ch[0], 2 * sizeof(HeaacSbrChannel), lane);
+    // channel records (2 x 336 B = 168 dwords) and the header (532 B = 133 dwords):
+    // all loads issued before any LDS store
+    uint32_t creg[3], hreg[3];
+    {
+        const uint32_t *cs = reinterpret_cast<const uint32_t *>(&g_fr->ch[0]);
+        const uint32_t *hs_ = reinterpret_cast<const uint32_t *>(&g_hdr[hdr_idx]);
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            creg[r] = lane + 64 * r < 168 ? cs[lane + 64 * r] : 0;
+            hreg[r] = lane + 64 * r < 133 ? hs_[lane + 64 * r] : 0;
+        }
+    }
     const int start = g_fr->start, reset = g_fr->reset;
     const int kx_old = g_fr->kx_old, m_old = g_fr->m_old;
     const int coupling = g_fr->bs_coupling;
+    float2 wreg[16], treg[4];
+    {
+        const float2 *W2 = reinterpret_cast<const float2 *>(g_W);
+        const float2 *T2 = reinterpret_cast<const float2 *>(st_in + HEAAC_SBR_WTAIL);
+#pragma unroll
+        for (int r = 0; r < 16; r++) wreg[r] = W2[lane + 64 * r];
+#pragma unroll
+        for (int r = 0; r < 4; r++) treg[r] = T2[lane + 64 * r];
+    }
+    const int k = lane;                                  // this lane's QMF band
+    float ghist[4], qhist[4];                            // g_temp / q_temp history rows of band m
+    unsigned idxnoise = __float_as_uint(st_in[HEAAC_SBR_IDXNOISE]);
+    unsigned idxsine  = __float_as_uint(st_in[HEAAC_SBR_IDXSINE]);
+    const float bw_in = lane < 5 ? st_in[HEAAC_SBR_BW + lane] : 0.0f;
+    {
+        uint32_t *cd = reinterpret_cast<uint32_t *>(&w.c[0]);
+        uint32_t *hd = reinterpret_cast<uint32_t *>(&w.h);
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            if (lane + 64 * r < 168) cd[lane + 64 * r] = creg[r];
+            if (lane + 64 * r < 133) hd[lane + 64 * r] = hreg[r];
+        }
+    }
     wave_sync();
     const HeaacSbrHeader &h = w.h;
     const HeaacSbrChannel &c = w.c[ch];
     const int kx = h.kx, m_max = h.m, n_q = h.n_q;
+    const int m = k - kx;
+    const bool in_sbr = m >= 0 && m < m_max && m < MAXM;
     const int num_env = c.bs_num_env;
     const int t0 = c.t_env[0], tL = c.t_env[num_env];
     const int h_SL = 4 * !h.bs_smoothing_mode;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        ghist[j] = in_sbr ? st_in[HEAAC_SBR_GTAIL + j * MAXM + m] : 0.0f;
+        qhist[j] = in_sbr ? st_in[HEAAC_SBR_QTAIL + j * MAXM + m] : 0.0f;
+    }
+    const int sidx0 = in_sbr ? reinterpret_cast<const uint8_t *>(st_in + HEAAC_SBR_SIDX)[m] : 0;
+    if (reset) idxnoise = 0;                     // sbr_make_f_derived, :587-588
 
+    HSTAMP(1);
     // ---- sbr_lf_gen (:1337-1357): W -> X_low, previous tail for slots 0..7 ----
     {
-        const float2 *W2 = reinterpret_cast<const float2 *>(g_W);
-        for (int t = lane; t < 1024; t += WAVE) {
-            const int i = t >> 5, k = t & 31;
-            float2 v = W2[t];
-            if (k >= kx) v = make_float2(0.0f, 0.0f);
-            float *d = w.xlow + k * XL_STRIDE + 2 * (i + 8);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int t = lane + 64 * r, i = t >> 5, kk = t & 31;
+            float2 v = wreg[r];
+            if (kk >= kx) v = make_float2(0.0f, 0.0f);
+            float *d = w.xlow + kk * XL_STRIDE + 2 * (i + 8);
             d[0] = v.x; d[1] = v.y;
         }
-        const float2 *T2 = reinterpret_cast<const float2 *>(st_in + HEAAC_SBR_WTAIL);
-        for (int t = lane; t < 256; t += WAVE) {
-            const int i = t >> 5, k = t & 31;
-            float2 v = T2[t];
-            if (k >= kx_old) v = make_float2(0.0f, 0.0f);
-            float *d = w.xlow + k * XL_STRIDE + 2 * i;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int t = lane + 64 * r, i = t >> 5, kk = t & 31;
+            float2 v = treg[r];
+            if (kk >= kx_old) v = make_float2(0.0f, 0.0f);
+            float *d = w.xlow + kk * XL_STRIDE + 2 * i;
             d[0] = v.x; d[1] = v.y;
         }
-        // new tail = W[1][24..31]
-        float *To = st_out + HEAAC_SBR_WTAIL;
-        for (int t = lane; t < 512; t += WAVE) To[t] = g_W[24 * 64 + t];
+        // new tail = W[1][24..31]: registers 12..15 hold slots 24..31
+        float2 *To = reinterpret_cast<float2 *>(st_out + HEAAC_SBR_WTAIL);
+#pragma unroll
+        for (int r = 0; r < 4; r++) To[lane + 64 * r] = wreg[12 + r];
     }
-    // small state words to LDS
-    if (lane < 8) w.bw[lane] = lane < 5 ? st_in[HEAAC_SBR_BW + lane] : 0.0f;
-    for (int t = lane; t < 4 * MAXM; t += WAVE) {
-        (&w.ghist[0][0])[t] = st_in[HEAAC_SBR_GTAIL + t];
-        (&w.qhist[0][0])[t] = st_in[HEAAC_SBR_QTAIL + t];
-    }
-    if (lane < 12)
-        reinterpret_cast<uint32_t *>(&w.s_idx[0][0])[lane] =
-            reinterpret_cast<const uint32_t *>(st_in + HEAAC_SBR_SIDX)[lane];
-    unsigned idxnoise = __float_as_uint(st_in[HEAAC_SBR_IDXNOISE]);
-    unsigned idxsine  = __float_as_uint(st_in[HEAAC_SBR_IDXSINE]);
-    if (reset) idxnoise = 0;                     // sbr_make_f_derived, :587-588
+    if (lane < 8) w.bw[lane] = bw_in;
     wave_sync();
 
+    // per-lane registers of the envelope adjuster
+    float e_orig[MAXE], q_map[MAXE], e_curr[MAXE], gain[MAXE], q_m[MAXE], s_m[MAXE];
+    int sidx[MAXE];                               // s_indexmapped[e + 1][m]
+    unsigned smap = 0;                            // bit e: s_mapped[e][m]
+    float kc[4] = { 0, 0, 0, 0 };                 // hf_gen alpha[0..3]
+#pragma unroll
+    for (int e = 0; e < MAXE; e++) { e_orig[e] = q_map[e] = e_curr[e] = gain[e] = q_m[e] = s_m[e] = 0.0f; sidx[e] = 0; }
+    // X_low row this lane reads: its own band below kx, the patch source above
+    const int p_src = in_sbr ? (int)h.map_src[k] : 0xff;
+    const bool has_src = p_src < 32;
+    const int row = k < kx ? (k < 32 ? k : 0) : (has_src ? p_src : 0);
+    const float2 *xr = reinterpret_cast<const float2 *>(0);   // (unaligned rows: read as two floats)
+    (void)xr;
+    const float *xrow = w.xlow + row * XL_STRIDE;
+
     if (start) {
+        HSTAMP(2);
         // ---- sbr_hf_inverse_filter (:1261-1313) + autocorrelate (:1232-1255) ----
         if (lane < h.k0 && lane < 32) {
-            const float *x = w.xlow + lane * XL_STRIDE;        // x[i][c] = x[2i + c]
+            // the whole row first (all LDS reads in flight), then the five running sums
+            float x[80];
+            const float *xs = w.xlow + lane * XL_STRIDE;
+#pragma unroll
+            for (int i = 0; i < 80; i++) x[i] = xs[i];
             float r0 = 0.0f, r1 = 0.0f, i1 = 0.0f, r2 = 0.0f, i2 = 0.0f;
+#pragma unroll
             for (int i = 1; i < 38; i++) {
                 const float a = x[2 * i], b = x[2 * i + 1];
                 r0 += a * a + b * b;
@@ -283,15 +340,12 @@ __device__ __forceinline__ void hf_channel(HfWave &w, const float *__restrict__ 
                 r2 += a * x[2 * i + 4] + b * x[2 * i + 5];
                 i2 += a * x[2 * i + 5] - b * x[2 * i + 4];
             }
-            // lag 0: phi[2][1][0], phi[1][0][0]
             const float p210 = r0 + x[0] * x[0] + x[1] * x[1];
             const float p100 = r0 + x[76] * x[76] + x[77] * x[77];
-            // lag 1: phi[1][1][*] (head), phi[0][0][*] (tail)
             const float p110 = r1 + x[0] * x[2] + x[1] * x[3];
             const float p111 = i1 + x[0] * x[3] - x[1] * x[2];
             const float p000 = r1 + x[76] * x[78] + x[77] * x[79];
             const float p001 = i1 + x[76] * x[79] - x[77] * x[78];
-            // lag 2: phi[0][1][*]
             const float p010 = r2 + x[0] * x[4] + x[1] * x[5];
             const float p011 = i2 + x[0] * x[5] - x[1] * x[4];
 
@@ -319,6 +373,7 @@ __device__ __forceinline__ void hf_channel(HfWave &w, const float *__restrict__ 
             w.alpha0[lane][0] = a0r; w.alpha0[lane][1] = a0i;
             w.alpha1[lane][0] = a1r; w.alpha1[lane][1] = a1i;
         }
+        HSTAMP(3);
         // ---- sbr_chirp (:1316-1334) ----
         if (lane < n_q) {
             const int m0 = c.bs_invf_mode[0][lane], m1 = c.bs_invf_mode[1][lane];
@@ -330,196 +385,208 @@ __device__ __forceinline__ void hf_channel(HfWave &w, const float *__restrict__ 
             else              new_bw = 0.90625f * new_bw + 0.09375f * old;
             w.bw[lane] = new_bw < 0.015625f ? 0.0f : new_bw;
         }
-        // envelope index of every time slot
-        if (lane < 40) {
-            int e = 0;
-            for (int q = 1; q < num_env; q++)
-                if (lane >= 2 * c.t_env[q]) e = q;
-            w.env_of[lane] = e;
-        }
         wave_sync();
 
+        HSTAMP(4);
         // ---- per-band constants of sbr_hf_gen (:1369-1386) ----
-        for (int m = lane; m < m_max; m += WAVE) {
-            const int k = kx + m;
-            int p = -1, base = 0;
-            for (int j = 0; j < h.num_patches; j++) {
-                const int len = h.patch_num_subbands[j];
-                if (m >= base && m < base + len) p = h.patch_start_subband[j] + (m - base);
-                base += len;
-            }
-            int g = -1;
-            for (int q = 0; q <= n_q; q++)
-                if (k >= h.f_tablenoise[q]) g = q;
-            w.kp[m] = p;
-            if (p >= 0 && p < 32 && g >= 0) {
-                const float b = w.bw[g];
-                w.kc[m][0] = w.alpha1[p][0] * b * b;
-                w.kc[m][1] = w.alpha1[p][1] * b * b;
-                w.kc[m][2] = w.alpha0[p][0] * b;
-                w.kc[m][3] = w.alpha0[p][1] * b;
-            } else {
-                w.kp[m] = -1;
-            }
+        if (has_src) {
+            const int g = h.map_nq[k];
+            const float b = w.bw[g < 5 ? g : 0];
+            kc[0] = w.alpha1[p_src][0] * b * b;
+            kc[1] = w.alpha1[p_src][1] * b * b;
+            kc[2] = w.alpha0[p_src][0] * b;
+            kc[3] = w.alpha0[p_src][1] * b;
         }
 
+        HSTAMP(5);
         // ---- sbr_mapping (:1451-1496) ----
-        for (int m = lane; m < MAXM; m += WAVE) {
-            const int k = kx + m;
-            for (int e = 0; e < num_env; e++) {
-                uint8_t sidx = 0;
-                if (m < m_max) {
+        if (in_sbr) {
+            const int hi = h.map_hi[k], lo = h.map_lo[k], nq = h.map_nq[k], mid = h.map_mid[k];
+#pragma unroll
+            for (int e = 0; e < MAXE; e++) {
+                if (e < num_env) {
+                    const int res = c.bs_freq_res[e + 1];
+                    e_orig[e] = deq_env(w, coupling, ch, e, res ? hi : lo);
+                    const int kq = (c.bs_num_noise > 1) && (c.t_env[e] >= c.t_q[1]);
+                    q_map[e] = deq_noise(w, coupling, ch, kq, nq);
+                    if (c.bs_add_harmonic_flag && mid != 0xff)
+                        sidx[e] = c.bs_add_harmonic[mid] * (e >= c.e_a[1] || (sidx0 == 1));
+                }
+            }
+        }
+        // s_mapped[e][m]: any sinusoid inside the band of the envelope's resolution (:1479-1491)
+#pragma unroll
+        for (int e = 0; e < MAXE; e++) {
+            if (e < num_env) {
+                const unsigned long long present = __ballot(sidx[e] != 0);      // bit = lane = band k
+                if (in_sbr) {
                     const int res = c.bs_freq_res[e + 1];
                     const uint8_t *table = res ? h.f_tablehigh : h.f_tablelow;
-                    const int ilim = h.n[res];
-                    int bi = 0;
-                    for (int i = 0; i < ilim; i++)
-                        if (k >= table[i]) bi = i;
-                    w.e_orig[e][m] = deq_env(w, coupling, ch, e, bi);
-                    const int kq = (c.bs_num_noise > 1) && (c.t_env[e] >= c.t_q[1]);
-                    int qi = 0;
-                    for (int i = 0; i < n_q; i++)
-                        if (k >= h.f_tablenoise[i]) qi = i;
-                    w.q_map[e][m] = deq_noise(w, coupling, ch, kq, qi);
-                    if (c.bs_add_harmonic_flag) {
-                        for (int i = 0; i < h.n[1]; i++) {
-                            const int mid = (h.f_tablehigh[i] + h.f_tablehigh[i + 1]) >> 1;
-                            if (mid == k)
-                                sidx = c.bs_add_harmonic[i] *
-                                       (e >= c.e_a[1] || (w.s_idx[0][m] == 1));
-                        }
-                    }
+                    const int bi = res ? h.map_hi[k] : h.map_lo[k];
+                    const int lo_k = table[bi], hi_k = table[bi + 1];               // [lo_k, hi_k)
+                    const unsigned long long mask = (hi_k >= 64 ? ~0ull : ((1ull << hi_k) - 1)) & ~((1ull << lo_k) - 1);
+                    if (present & mask) smap |= 1u << e;
                 }
-                w.s_idx[e + 1][m] = sidx;
-            }
-        }
-        wave_sync();
-        for (int m = lane; m < m_max; m += WAVE) {
-            const int k = kx + m;
-            for (int e = 0; e < num_env; e++) {
-                const int res = c.bs_freq_res[e + 1];
-                const uint8_t *table = res ? h.f_tablehigh : h.f_tablelow;
-                const int ilim = h.n[res];
-                int bi = 0;
-                for (int i = 0; i < ilim; i++)
-                    if (k >= table[i]) bi = i;
-                int present = 0;
-                for (int mm = table[bi]; mm < table[bi + 1]; mm++)
-                    if (w.s_idx[e + 1][mm - kx]) { present = 1; break; }
-                w.s_map[e][m] = (uint8_t)present;
             }
         }
 
+        HSTAMP(6);
         // ---- sbr_env_estimate (:1499-1546) ----
         if (h.bs_interpol_freq) {
-            for (int m = lane; m < m_max; m += WAVE) {
-                for (int e = 0; e < num_env; e++) {
-                    const float recip_env_size = 0.5f / (c.t_env[e + 1] - c.t_env[e]);
-                    const int ilb = c.t_env[e] * 2 + ENV_ADJ, iub = c.t_env[e + 1] * 2 + ENV_ADJ;
-                    float sum = 0.0f;
-                    for (int i = ilb; i < iub; i++) {
-                        float re, im;
-                        xhigh(w, m, i, re, im);
-                        sum += re * re + im * im;
+            if (in_sbr) {
+#pragma unroll
+                for (int e = 0; e < MAXE; e++) {
+                    if (e < num_env) {
+                        const float recip_env_size = 0.5f / (c.t_env[e + 1] - c.t_env[e]);
+                        const int ilb = c.t_env[e] * 2 + ENV_ADJ, iub = c.t_env[e + 1] * 2 + ENV_ADJ;
+                        float sum = 0.0f;
+                        if (has_src) {
+                            float2 x2 = make_float2(xrow[2 * (ilb - 2)], xrow[2 * (ilb - 2) + 1]);
+                            float2 x1 = make_float2(xrow[2 * (ilb - 1)], xrow[2 * (ilb - 1) + 1]);
+                            for (int i = ilb; i < iub; i++) {
+                                const float2 x0 = make_float2(xrow[2 * i], xrow[2 * i + 1]);
+                                float re, im;
+                                xhigh3(x2, x1, x0, kc, re, im);
+                                sum += re * re + im * im;
+                                x2 = x1; x1 = x0;
+                            }
+                        } else {
+                            for (int i = ilb; i < iub; i++) sum += 0.0f * 0.0f + 0.0f * 0.0f;
+                        }
+                        e_curr[e] = sum * recip_env_size;
                     }
-                    w.e_curr[e][m] = sum * recip_env_size;
                 }
             }
         } else {
-            for (int e = 0; e < num_env; e++) {
-                const int res = c.bs_freq_res[e + 1];
-                const uint8_t *table = res ? h.f_tablehigh : h.f_tablelow;
-                const int env_size = 2 * (c.t_env[e + 1] - c.t_env[e]);
-                const int ilb = c.t_env[e] * 2 + ENV_ADJ, iub = c.t_env[e + 1] * 2 + ENV_ADJ;
-                for (int p = lane; p < h.n[res]; p += WAVE) {
-                    float sum = 0.0f;
-                    const int den = env_size * (table[p + 1] - table[p]);
-                    for (int k = table[p]; k < table[p + 1]; k++)
-                        for (int i = ilb; i < iub; i++) {
-                            float re, im;
-                            xhigh(w, k - kx, i, re, im);
-                            sum += re * re + im * im;
+            // one lane per band of the envelope's frequency table; result broadcast through LDS
+#pragma unroll
+            for (int e = 0; e < MAXE; e++) {
+                if (e < num_env) {
+                    const int res = c.bs_freq_res[e + 1];
+                    const uint8_t *table = res ? h.f_tablehigh : h.f_tablelow;
+                    const int env_size = 2 * (c.t_env[e + 1] - c.t_env[e]);
+                    const int ilb = c.t_env[e] * 2 + ENV_ADJ, iub = c.t_env[e + 1] * 2 + ENV_ADJ;
+                    if (lane < h.n[res]) {
+                        float sum = 0.0f;
+                        const int den = env_size * (table[lane + 1] - table[lane]);
+                        for (int kk = table[lane]; kk < table[lane + 1]; kk++) {
+                            const int ps = h.map_src[kk];
+                            float a[4] = { 0, 0, 0, 0 };
+                            if (ps < 32) {
+                                const int g = h.map_nq[kk];
+                                const float b = w.bw[g < 5 ? g : 0];
+                                a[0] = w.alpha1[ps][0] * b * b; a[1] = w.alpha1[ps][1] * b * b;
+                                a[2] = w.alpha0[ps][0] * b;     a[3] = w.alpha0[ps][1] * b;
+                            }
+                            const float *xs = w.xlow + (ps < 32 ? ps : 0) * XL_STRIDE;
+                            for (int i = ilb; i < iub; i++) {
+                                float re = 0.0f, im = 0.0f;
+                                if (ps < 32)
+                                    xhigh3(make_float2(xs[2 * i - 4], xs[2 * i - 3]), make_float2(xs[2 * i - 2], xs[2 * i - 1]),
+                                           make_float2(xs[2 * i], xs[2 * i + 1]), a, re, im);
+                                sum += re * re + im * im;
+                            }
                         }
-                    sum /= den;
-                    for (int k = table[p]; k < table[p + 1]; k++)
-                        w.e_curr[e][k - kx] = sum;
-                }
-            }
-        }
-        wave_sync();
-
-        // ---- sbr_gain_calc (:1552-1605): one lane per (envelope, limiter band) ----
-        // Bands no limiter band covers (last patch dropped, :538-539) keep the
-        // zeros of the reference's av_mallocz'ed context.
-        for (int t = lane; t < MAXE * MAXM; t += WAVE) {
-            (&w.gain[0][0])[t] = 0.0f;
-            (&w.q_m[0][0])[t] = 0.0f;
-            (&w.s_m[0][0])[t] = 0.0f;
-        }
-        wave_sync();
-        {
-            const int n_lim = h.n_lim;
-            const float limgain = h.bs_limiter_gains == 0 ? 0.70795f :
-                                  h.bs_limiter_gains == 1 ? 1.0f :
-                                  h.bs_limiter_gains == 2 ? 1.41254f : 10000000000.0f;
-            for (int t = lane; t < num_env * n_lim; t += WAVE) {
-                const int e = t / n_lim, kk = t - e * n_lim;
-                const int delta = !((e == c.e_a[1]) || (e == c.e_a[0]));
-                const int ma = h.f_tablelim[kk] - kx, mb = h.f_tablelim[kk + 1] - kx;
-                float sum0 = 0.0f, sum1 = 0.0f;
-                for (int m = ma; m < mb; m++) {
-                    const float eo = w.e_orig[e][m], qm = w.q_map[e][m], ec = w.e_curr[e][m];
-                    const float temp = eo / (1.0f + qm);
-                    w.q_m[e][m] = sqrtf(temp * qm);
-                    w.s_m[e][m] = sqrtf(temp * (float)w.s_idx[e + 1][m]);
-                    if (!w.s_map[e][m])
-                        w.gain[e][m] = sqrtf(eo / ((1.0f + ec) * (1.0f + qm * (float)delta)));
-                    else
-                        w.gain[e][m] = sqrtf(eo * qm / ((1.0f + ec) * (1.0f + qm)));
-                }
-                for (int m = ma; m < mb; m++) {
-                    sum0 += w.e_orig[e][m];
-                    sum1 += w.e_curr[e][m];
-                }
-                float gain_max = limgain * sqrtf((1.1920928955078125e-7f + sum0) / (1.1920928955078125e-7f + sum1));
-                gain_max = FFMIN_(100000.0f, gain_max);
-                for (int m = ma; m < mb; m++) {
-                    const float q_m_max = w.q_m[e][m] * gain_max / w.gain[e][m];
-                    w.q_m[e][m]  = FFMIN_(w.q_m[e][m], q_m_max);
-                    w.gain[e][m] = FFMIN_(w.gain[e][m], gain_max);
-                }
-                sum0 = sum1 = 0.0f;
-                for (int m = ma; m < mb; m++) {
-                    sum0 += w.e_orig[e][m];
-                    sum1 += w.e_curr[e][m] * w.gain[e][m] * w.gain[e][m]
-                            + w.s_m[e][m] * w.s_m[e][m]
-                            + (float)(delta && !w.s_m[e][m]) * w.q_m[e][m] * w.q_m[e][m];
-                }
-                float gain_boost = sqrtf((1.1920928955078125e-7f + sum0) / (1.1920928955078125e-7f + sum1));
-                // FFMIN(1.584893192, gain_boost) is evaluated in double (:1597)
-                gain_boost = (float)(1.584893192 > (double)gain_boost ? (double)gain_boost : 1.584893192);
-                for (int m = ma; m < mb; m++) {
-                    w.gain[e][m] *= gain_boost;
-                    w.q_m[e][m]  *= gain_boost;
-                    w.s_m[e][m]  *= gain_boost;
-                }
-            }
-        }
-        wave_sync();
-
-        // history rows for the smoothing filter (:1630-1639)
-        if (reset) {
-            for (int t = lane; t < 4 * MAXM; t += WAVE) {
-                const int m = t % MAXM;
-                if (m < m_max) {
-                    (&w.ghist[0][0])[t] = w.gain[0][m];
-                    (&w.qhist[0][0])[t] = w.q_m[0][m];
+                        sum /= den;
+                        for (int kk = table[lane]; kk < table[lane + 1]; kk++)
+                            if (kk - kx < MAXM) w.sumA[e][kk - kx] = sum;
+                    }
                 }
             }
             wave_sync();
+            if (in_sbr) {
+#pragma unroll
+                for (int e = 0; e < MAXE; e++)
+                    if (e < num_env) e_curr[e] = w.sumA[e][m];
+            }
+            wave_sync();
+        }
+
+        HSTAMP(7);
+        // ---- sbr_gain_calc (:1552-1605) ----
+        // elementwise parts per lane, limiter-band sums by one lane per (envelope, band)
+        const int lim = in_sbr ? (int)h.map_lim[k] : 0xff;
+        const bool limited = lim != 0xff;
+        const float limgain = h.bs_limiter_gains == 0 ? 0.70795f :
+                              h.bs_limiter_gains == 1 ? 1.0f :
+                              h.bs_limiter_gains == 2 ? 1.41254f : 10000000000.0f;
+        const int n_lim = h.n_lim;
+#pragma unroll
+        for (int e = 0; e < MAXE; e++) {
+            if (e < num_env && limited) {
+                const int delta = !((e == c.e_a[1]) || (e == c.e_a[0]));
+                const float eo = e_orig[e], qm = q_map[e], ec = e_curr[e];
+                const float temp = eo / (1.0f + qm);
+                q_m[e] = sqrtf(temp * qm);
+                s_m[e] = sqrtf(temp * (float)sidx[e]);
+                if (!((smap >> e) & 1))
+                    gain[e] = sqrtf(eo / ((1.0f + ec) * (1.0f + qm * (float)delta)));
+                else
+                    gain[e] = sqrtf(eo * qm / ((1.0f + ec) * (1.0f + qm)));
+                w.sumA[e][m] = eo;
+                w.sumB[e][m] = ec;
+            }
+        }
+        wave_sync();
+        for (int t = lane; t < num_env * n_lim; t += WAVE) {
+            const int e = t / n_lim, kk = t - e * n_lim;
+            const int ma = h.f_tablelim[kk] - kx, mb = h.f_tablelim[kk + 1] - kx;
+            float sum0 = 0.0f, sum1 = 0.0f;
+            for (int mm = ma; mm < mb; mm++) {
+                sum0 += w.sumA[e][mm];
+                sum1 += w.sumB[e][mm];
+            }
+            float gain_max = limgain * sqrtf((1.1920928955078125e-7f + sum0) / (1.1920928955078125e-7f + sum1));
+            gain_max = FFMIN_(100000.0f, gain_max);
+            w.bandv[e][kk] = gain_max;
+        }
+        wave_sync();
+#pragma unroll
+        for (int e = 0; e < MAXE; e++) {
+            if (e < num_env && limited) {
+                const int delta = !((e == c.e_a[1]) || (e == c.e_a[0]));
+                const float gain_max = w.bandv[e][lim];
+                const float q_m_max = q_m[e] * gain_max / gain[e];
+                q_m[e]  = FFMIN_(q_m[e], q_m_max);
+                gain[e] = FFMIN_(gain[e], gain_max);
+                // term of the second sum[1] (:1590-1594); sumA still holds e_origmapped
+                w.sumB[e][m] = e_curr[e] * gain[e] * gain[e]
+                               + s_m[e] * s_m[e]
+                               + (float)(delta && !s_m[e]) * q_m[e] * q_m[e];
+            }
+        }
+        wave_sync();
+        for (int t = lane; t < num_env * n_lim; t += WAVE) {
+            const int e = t / n_lim, kk = t - e * n_lim;
+            const int ma = h.f_tablelim[kk] - kx, mb = h.f_tablelim[kk + 1] - kx;
+            float sum0 = 0.0f, sum1 = 0.0f;
+            for (int mm = ma; mm < mb; mm++) {
+                sum0 += w.sumA[e][mm];
+                sum1 += w.sumB[e][mm];
+            }
+            float gain_boost = sqrtf((1.1920928955078125e-7f + sum0) / (1.1920928955078125e-7f + sum1));
+            // FFMIN(1.584893192, gain_boost) is evaluated in double (:1597)
+            gain_boost = (float)(1.584893192 > (double)gain_boost ? (double)gain_boost : 1.584893192);
+            w.bandv[e][kk] = gain_boost;
+        }
+        wave_sync();
+#pragma unroll
+        for (int e = 0; e < MAXE; e++) {
+            if (e < num_env && limited) {
+                const float gain_boost = w.bandv[e][lim];
+                gain[e] *= gain_boost;
+                q_m[e]  *= gain_boost;
+                s_m[e]  *= gain_boost;
+            }
+        }
+        // history rows for the smoothing filter (:1630-1639)
+        if (reset) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { ghist[j] = gain[0]; qhist[j] = q_m[0]; }
         }
     }
 
+    HSTAMP(8);
     // ---- sbr_hf_assemble (:1608-1714) fused with sbr_x_gen (:1412-1446) ----
     const int t_old = c.t_env_num_env_old;
     const int i_Temp = 2 * t_old - 32 > 0 ? 2 * t_old - 32 : 0;
@@ -527,69 +594,79 @@ __device__ __forceinline__ void hf_channel(HfWave &w, const float *__restrict__ 
     float *ytail_out = st_out + HEAAC_SBR_YTAIL;
     float *X0 = g_X, *X1 = g_X + 38 * 64;
     {
-        const int k = lane;                       // one QMF band per lane
-        const int m = k - kx;
-        const bool hf = start && m >= 0 && m < m_max;
-        const float h0 = 0.33333333333333f, h1 = 0.30150283239582f, h2 = 0.21816949906249f,
-                    h3 = 0.11516383427084f, h4 = 0.03183050093751f;
+        const bool hf = start && in_sbr;
+        const float hs[5] = { 0.33333333333333f, 0.30150283239582f, 0.21816949906249f,
+                              0.11516383427084f, 0.03183050093751f };
         const int phi_sign0 = (1 - 2 * (kx & 1)) * ((m & 1) ? -1 : 1);
+        // g_temp / q_temp rows r = slot + h_SL kept as a ring of 5 (position r % 5);
+        // rows 2 t0 .. 2 t0 + 3 hold the history, row slot + 4 the slot's own gain
+        float gr[5] = { 0, 0, 0, 0, 0 }, qr[5] = { 0, 0, 0, 0, 0 };
+        // current envelope (uniform): advanced at even slots = 2 * t_env[e + 1]
+        int e = 0, next_border = 2 * c.t_env[1];
+        float g_e = gain[0], q_e = q_m[0], s_e = s_m[0];
+        bool plain = (0 == c.e_a[0]) || (0 == c.e_a[1]);
+        // sliding window of X_low of the source row
+        float2 x2 = make_float2(xrow[0], xrow[1]), x1 = make_float2(xrow[2], xrow[3]);
+
+#pragma unroll
         for (int i = 0; i < 38; i++) {
+            const float2 x0 = make_float2(xrow[2 * (i + ENV_ADJ)], xrow[2 * (i + ENV_ADJ) + 1]);
+            if ((i & 1) == 0 && i <= 6 && i == 2 * t0 && h_SL) {
+                // seed the ring with the four history rows (:1630-1639)
+#pragma unroll
+                for (int j = 0; j < 4; j++) { gr[(i + j) % 5] = ghist[j]; qr[(i + j) % 5] = qhist[j]; }
+            }
+            if ((i & 1) == 0 && i > 0 && i == next_border && e + 1 < num_env) {
+                e++;
+                next_border = 2 * c.t_env[e + 1];
+                // per-envelope values of this lane (static select: e is uniform)
+                g_e = e == 1 ? gain[1] : e == 2 ? gain[2] : e == 3 ? gain[3] : gain[4];
+                q_e = e == 1 ? q_m[1] : e == 2 ? q_m[2] : e == 3 ? q_m[3] : q_m[4];
+                s_e = e == 1 ? s_m[1] : e == 2 ? s_m[2] : e == 3 ? s_m[3] : s_m[4];
+                plain = (e == c.e_a[0]) || (e == c.e_a[1]);
+            }
             float yr = 0.0f, yi = 0.0f;
-            bool have_y = false;
-            if (hf && i >= 2 * t0 && i < 2 * tL) {
-                have_y = true;
-                const int e = w.env_of[i];
-                const bool plain = (e == c.e_a[0]) || (e == c.e_a[1]);
-                float xr, xi;
-                xhigh(w, m, i + ENV_ADJ, xr, xi);
+            const bool have_y = hf && i >= 2 * t0 && i < 2 * tL;
+            if (have_y) {
+                float xr_, xi_;
+                if (has_src) xhigh3(x2, x1, x0, kc, xr_, xi_); else { xr_ = 0.0f; xi_ = 0.0f; }
+                gr[(i + 4) % 5] = g_e;
+                qr[(i + 4) % 5] = q_e;
                 float g_filt;
-                // g_temp row r holds gain[env_of[r - h_SL]] for r >= h_SL + 2 t0,
-                // the 4 history rows below that
-#define GROW(arr, hist, r) ((r) >= h_SL + 2 * t0 ? w.arr[w.env_of[(r) - h_SL]][m] : w.hist[(r) - 2 * t0][m])
                 if (h_SL && !plain) {
-                    const int idx1 = i + h_SL;
                     g_filt = 0.0f;
-                    g_filt += GROW(gain, ghist, idx1 - 0) * h0;
-                    g_filt += GROW(gain, ghist, idx1 - 1) * h1;
-                    g_filt += GROW(gain, ghist, idx1 - 2) * h2;
-                    g_filt += GROW(gain, ghist, idx1 - 3) * h3;
-                    g_filt += GROW(gain, ghist, idx1 - 4) * h4;
+#pragma unroll
+                    for (int j = 0; j < 5; j++) g_filt += gr[(i + 4 - j) % 5] * hs[j];
                 } else {
-                    g_filt = GROW(gain, ghist, i + h_SL);
+                    g_filt = h_SL ? g_e : g_e;       // g_temp[i + h_SL][m] = this slot's gain
                 }
-                yr = xr * g_filt;
-                yi = xi * g_filt;
+                yr = xr_ * g_filt;
+                yi = xi_ * g_filt;
                 const int slot = i - 2 * t0;
                 const int isine = (idxsine + slot) & 3;
                 const int phi_re = isine == 0 ? 1 : isine == 2 ? -1 : 0;
                 const int phi_im = isine == 1 ? 1 : isine == 3 ? -1 : 0;
-                const float sm = w.s_m[e][m];
                 if (!plain) {
-                    if (sm) {
-                        yr += sm * (float)phi_re;
-                        yi += sm * (float)(phi_im * phi_sign0);
+                    if (s_e) {
+                        yr += s_e * (float)phi_re;
+                        yi += s_e * (float)(phi_im * phi_sign0);
                     } else {
                         float q_filt;
                         if (h_SL) {
-                            const int idx1 = i + h_SL;
                             q_filt = 0.0f;
-                            q_filt += GROW(q_m, qhist, idx1 - 0) * h0;
-                            q_filt += GROW(q_m, qhist, idx1 - 1) * h1;
-                            q_filt += GROW(q_m, qhist, idx1 - 2) * h2;
-                            q_filt += GROW(q_m, qhist, idx1 - 3) * h3;
-                            q_filt += GROW(q_m, qhist, idx1 - 4) * h4;
+#pragma unroll
+                            for (int j = 0; j < 5; j++) q_filt += qr[(i + 4 - j) % 5] * hs[j];
                         } else {
-                            q_filt = w.q_m[e][m];          // q_temp[i][m], h_SL == 0
+                            q_filt = q_e;              // q_temp[i][m], h_SL == 0
                         }
                         const unsigned in = (idxnoise + (unsigned)slot * m_max + m + 1) & 0x1ff;
                         yr += q_filt * g_noise[2 * in];
                         yi += q_filt * g_noise[2 * in + 1];
                     }
                 } else {
-                    yr += sm * (float)phi_re;
-                    yi += sm * (float)(phi_im * phi_sign0);
+                    yr += s_e * (float)phi_re;
+                    yi += s_e * (float)(phi_im * phi_sign0);
                 }
-#undef GROW
             }
             // ytail: Y[1][32..37]
             if (i >= 32) {
@@ -598,25 +675,27 @@ __device__ __forceinline__ void hf_channel(HfWave &w, const float *__restrict__ 
                 else if (ytail_out != ytail_in) { ytail_out[o] = ytail_in[o]; ytail_out[o + 1] = ytail_in[o + 1]; }
             }
             // x_gen
-            float xr = 0.0f, xi = 0.0f;
-            if (i < i_Temp) {
+            float xo_r = 0.0f, xo_i = 0.0f;
+            if (i < 6 && i < i_Temp) {
                 if (k < kx_old) {
-                    if (k < 32) { xr = w.xlow[k * XL_STRIDE + 2 * (i + ENV_ADJ)]; xi = w.xlow[k * XL_STRIDE + 2 * (i + ENV_ADJ) + 1]; }
+                    if (k < 32) { xo_r = w.xlow[k * XL_STRIDE + 2 * (i + ENV_ADJ)]; xo_i = w.xlow[k * XL_STRIDE + 2 * (i + ENV_ADJ) + 1]; }
                 } else if (k < kx_old + m_old) {
-                    xr = ytail_in[(i * 64 + k) * 2]; xi = ytail_in[(i * 64 + k) * 2 + 1];
+                    xo_r = ytail_in[(i * 64 + k) * 2]; xo_i = ytail_in[(i * 64 + k) * 2 + 1];
                 }
             } else {
                 if (k < kx) {
-                    if (k < 32) { xr = w.xlow[k * XL_STRIDE + 2 * (i + ENV_ADJ)]; xi = w.xlow[k * XL_STRIDE + 2 * (i + ENV_ADJ) + 1]; }
+                    if (k < 32) { xo_r = x0.x; xo_i = x0.y; }
                 } else if (k < kx + m_max && i < 32) {
-                    xr = yr; xi = yi;
+                    xo_r = yr; xo_i = yi;
                 }
             }
-            X0[i * 64 + k] = xr;
-            X1[i * 64 + k] = xi;
+            X0[i * 64 + k] = xo_r;
+            X1[i * 64 + k] = xo_i;
+            x2 = x1; x1 = x0;
         }
     }
 
+    HSTAMP(9);
     // ---- remaining state ----
     if (start) {
         if (lane < 5) st_out[HEAAC_SBR_BW + lane] = w.bw[lane];
@@ -625,23 +704,48 @@ __device__ __forceinline__ void hf_channel(HfWave &w, const float *__restrict__ 
             st_out[HEAAC_SBR_IDXNOISE] = __uint_as_float((idxnoise + slots * m_max) & 0x1ff);
             st_out[HEAAC_SBR_IDXSINE]  = __uint_as_float((idxsine + slots) & 3);
         }
-        if (lane < 12) {
-            // s_indexmapped[0] <- s_indexmapped[bs_num_env]
-            reinterpret_cast<uint32_t *>(st_out + HEAAC_SBR_SIDX)[lane] =
-                reinterpret_cast<const uint32_t *>(&w.s_idx[num_env][0])[lane];
+        // s_indexmapped[0] <- s_indexmapped[bs_num_env]  (bytes, one per band m < 48)
+        {
+            int v = 0;
+#pragma unroll
+            for (int e = 0; e < MAXE; e++) if (e == num_env - 1) v = sidx[e];
+            // gather the byte of band m = lane (not k): shuffle from lane kx + m
+            const int src_lane = kx + lane;
+            const int byte = __shfl(v, src_lane < 64 ? src_lane : 0);
+            const int valid = lane < MAXM && src_lane < 64 && lane < m_max;
+            const int b0 = valid ? (byte & 0xff) : 0;
+            // pack 4 bytes per dword via shuffles
+            const int p0 = __shfl(b0, (lane & 15) * 4 + 0 < 64 ? (lane & 15) * 4 + 0 : 0);
+            const int p1 = __shfl(b0, (lane & 15) * 4 + 1 < 64 ? (lane & 15) * 4 + 1 : 0);
+            const int p2 = __shfl(b0, (lane & 15) * 4 + 2 < 64 ? (lane & 15) * 4 + 2 : 0);
+            const int p3 = __shfl(b0, (lane & 15) * 4 + 3 < 64 ? (lane & 15) * 4 + 3 : 0);
+            if (lane < 12)
+                reinterpret_cast<uint32_t *>(st_out + HEAAC_SBR_SIDX)[lane] =
+                    (uint32_t)p0 | ((uint32_t)p1 << 8) | ((uint32_t)p2 << 16) | ((uint32_t)p3 << 24);
         }
         if (h_SL) {
-            for (int t = lane; t < 4 * MAXM; t += WAVE) {
-                const int j = t / MAXM, m = t % MAXM;
+            // rows 2 tL + j: the gains of slots 2 tL - 4 + j
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int slot = 2 * tL - 4 + j;
+                int ee = 0;
+                for (int q = 1; q < num_env; q++)
+                    if (slot >= 2 * c.t_env[q]) ee = q;
                 float g = 0.0f, q = 0.0f;
-                if (m < m_max) {
-                    const int r = 2 * tL + j;           // g_temp row, >= h_SL + 2 t0
-                    const int e = w.env_of[r - h_SL];
-                    g = w.gain[e][m];
-                    q = w.q_m[e][m];
+#pragma unroll
+                for (int e2 = 0; e2 < MAXE; e2++) if (e2 == ee) { g = gain[e2]; q = q_m[e2]; }
+                if (m >= 0 && m < MAXM) {
+                    st_out[HEAAC_SBR_GTAIL + j * MAXM + m] = in_sbr ? g : 0.0f;
+                    st_out[HEAAC_SBR_QTAIL + j * MAXM + m] = in_sbr ? q : 0.0f;
                 }
-                st_out[HEAAC_SBR_GTAIL + t] = g;
-                st_out[HEAAC_SBR_QTAIL + t] = q;
+            }
+            // bands m that no lane covers (kx + m >= 64) are beyond m_max: zero
+            if (lane < MAXM && kx + lane >= 64) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    st_out[HEAAC_SBR_GTAIL + j * MAXM + lane] = 0.0f;
+                    st_out[HEAAC_SBR_QTAIL + j * MAXM + lane] = 0.0f;
+                }
             }
         } else if (st_out != st_in) {
             for (int t = lane; t < 4 * MAXM; t += WAVE) {
@@ -655,6 +759,7 @@ __device__ __forceinline__ void hf_channel(HfWave &w, const float *__restrict__ 
     }
     if (lane == 0 && st_out != st_in) st_out[HEAAC_SBR_PAD] = st_in[HEAAC_SBR_PAD];
     wave_sync();
+    HSTAMP(10);
 }
 
 __global__ __launch_bounds__(HF_WAVES * WAVE)
@@ -664,13 +769,16 @@ void k_hfadj(const float *__restrict__ g_tab,
              int ncore, int off_sbr0, float *g_X, unsigned long long n_units)
 {
     __shared__ HfWave S[HF_WAVES];
-    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    __shared__ float s_noise[1024];              // sbr_noise_table, staged once per workgroup
+    wg_copy_f4(s_noise, g_tab + TB_NOISE, 1024);
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
     for (unsigned long long u = (unsigned long long)blockIdx.x * HF_WAVES + wave; u < n_units;
          u += (unsigned long long)gridDim.x * HF_WAVES) {
         const unsigned long long f = u / ncore;
         const int ch = (int)(u - f * ncore);
         const int off = off_sbr0 + ch * HEAAC_ST_SBR;
-        hf_channel(S[wave], g_tab + TB_NOISE, &g_sbr[f], g_hdr, ch, g_W + u * 2048,
+        hf_channel(S[wave], s_noise, &g_sbr[f], g_hdr, ch, g_W + u * 2048,
                    g_state_in + f * state_words + off, g_state_out + f * state_words + off,
                    g_X + (f * 2 + ch) * (2 * 38 * 64), lane);
     }
@@ -779,7 +887,7 @@ void k_synth(const float *__restrict__ g_tab, const float *g_X,
     if (threadIdx.x < 5) S.c16[threadIdx.x] = g_tab[TB_COS16 + threadIdx.x];
     if (threadIdx.x < 9) S.c32[threadIdx.x] = g_tab[TB_COS32 + threadIdx.x];
     __syncthreads();
-    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
     SynWave &w = S.w[wave];
     for (unsigned long long f = (unsigned long long)blockIdx.x * SYN_WAVES + wave; f < n_frames;
          f += (unsigned long long)gridDim.x * SYN_WAVES) {
@@ -830,7 +938,7 @@ void k_qmf_analysis(const float *__restrict__ g_tab, const float *__restrict__ g
     if (threadIdx.x < 5) c16[threadIdx.x] = g_tab[TB_COS16 + threadIdx.x];
     if (threadIdx.x < 9) c32[threadIdx.x] = g_tab[TB_COS32 + threadIdx.x];
     __syncthreads();
-    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
     float *p = pool[wave];
     for (unsigned long long u = (unsigned long long)blockIdx.x * ANA_WAVES + wave; u < n;
          u += (unsigned long long)gridDim.x * ANA_WAVES) {
@@ -858,7 +966,7 @@ void k_qmf_synthesis(const float *__restrict__ g_tab, const float *__restrict__ 
     if (threadIdx.x < 5) S.c16[threadIdx.x] = g_tab[TB_COS16 + threadIdx.x];
     if (threadIdx.x < 9) S.c32[threadIdx.x] = g_tab[TB_COS32 + threadIdx.x];
     __syncthreads();
-    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
     for (unsigned long long u = (unsigned long long)blockIdx.x * SYN_WAVES + wave; u < n;
          u += (unsigned long long)gridDim.x * SYN_WAVES) {
         const float *X0 = g_X + u * 4096, *X1 = X0 + 2048;
@@ -947,3 +1055,10 @@ extern "C" int heaac_launch_qmf_synthesis(const float *d_tab, const float *d_X, 
                        d_tab, d_X, d_v_in, d_v_out, d_out, scale, bias, (unsigned long long)n);
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
 }
+
+#ifdef HF_STAMPS
+extern "C" int heaac_debug_hf_stamps(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hf_stamps), sizeof(g_hf_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif

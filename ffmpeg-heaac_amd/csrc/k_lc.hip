@@ -32,7 +32,7 @@ void k_lc_decode(const float *__restrict__ g_tab, const uint16_t *__restrict__ g
     core_lds_init(L, g_tab, g_rev);
     __syncthreads();
 
-    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
     LcWaveLds &w = W[wave];
 
     for (unsigned long long f = (unsigned long long)blockIdx.x * LC_WAVES + wave; f < n;
@@ -95,7 +95,7 @@ void k_imdct_half_core(const float *__restrict__ g_tab, const uint16_t *__restri
     __shared__ LcWaveLds W[LC_WAVES];
     core_lds_init(L, g_tab, g_rev);
     __syncthreads();
-    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
     LcWaveLds &w = W[wave];
     // WHICH 0: one 1024-sample transform per unit; WHICH 1: eight 128-sample
     // transforms per unit (tail handled by clamping the copy).
@@ -162,7 +162,7 @@ void k_fft_calc(const float *__restrict__ g_tab, float *g_z, unsigned long long 
     }
     __syncthreads();
     constexpr SrSchedule S = BITS == 9 ? kSched512 : BITS == 6 ? kSched64 : kSched32;
-    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
     cpx *z = reinterpret_cast<cpx *>(zb[wave]);
     for (unsigned long long u = (unsigned long long)blockIdx.x * LC_WAVES + wave; u < n;
          u += (unsigned long long)gridDim.x * LC_WAVES) {

@@ -363,5 +363,21 @@ int heaac_sbr_make_header(HeaacSbrHeader *h, int sample_rate,
     for (int i = 0; i <= t.n_lo; i++) h->f_tablelow[i]   = (uint8_t)t.lo[i];
     for (int i = 0; i <= t.n_hi; i++) h->f_tablehigh[i]  = (uint8_t)t.hi[i];
     for (int i = 0; i <= t.n_lim; i++) h->f_tablelim[i]  = (uint8_t)t.lim[i];
+
+    /* per-band lookups for the kernels */
+    memset(h->map_hi, 0xff, 6 * 64);
+    for (int i = 0; i < t.n_hi; i++) {
+        for (int k = t.hi[i]; k < t.hi[i + 1]; k++) h->map_hi[k] = (uint8_t)i;
+        h->map_mid[(t.hi[i] + t.hi[i + 1]) >> 1] = (uint8_t)i;
+    }
+    for (int i = 0; i < t.n_lo; i++)
+        for (int k = t.lo[i]; k < t.lo[i + 1]; k++) h->map_lo[k] = (uint8_t)i;
+    for (int i = 0; i < t.n_q; i++)
+        for (int k = t.noise[i]; k < t.noise[i + 1]; k++) h->map_nq[k] = (uint8_t)i;
+    for (int i = 0; i < t.n_lim; i++)
+        for (int k = t.lim[i]; k < t.lim[i + 1] && k < 64; k++) h->map_lim[k] = (uint8_t)i;
+    for (int j = 0, k = t.kx; j < t.n_patch; j++)
+        for (int x = 0; x < t.patch_len[j] && k < 64; x++, k++)
+            h->map_src[k] = (uint8_t)(t.patch_src[j] + x);
     return HEAAC_OK;
 }

@@ -98,7 +98,16 @@ typedef struct HeaacSbrHeader {
     uint8_t f_tablelow[28];       /* 25 used */
     uint8_t f_tablehigh[52];      /* 49 used */
     uint8_t f_tablelim[32];       /* 29 used */
-} HeaacSbrHeader;                 /* 148 bytes */
+    /* Per-QMF-band lookups derived from the tables above by heaac_sbr_make_header()
+     * (0xff = none).  They replace the reference's per-frame table searches in
+     * sbr_hf_gen / sbr_mapping / sbr_gain_calc (aacsbr.c:1366-1376, 1457-1492, 1563). */
+    uint8_t map_hi[64];           /* i: f_tablehigh[i] <= k < f_tablehigh[i+1]            */
+    uint8_t map_lo[64];           /* i: f_tablelow[i]  <= k < f_tablelow[i+1]             */
+    uint8_t map_nq[64];           /* i: f_tablenoise[i] <= k < f_tablenoise[i+1]          */
+    uint8_t map_lim[64];          /* i: f_tablelim[i]  <= k < f_tablelim[i+1]             */
+    uint8_t map_mid[64];          /* i: k == (f_tablehigh[i] + f_tablehigh[i+1]) >> 1     */
+    uint8_t map_src[64];          /* patch source band p of HF band k (sbr_hf_gen)        */
+} HeaacSbrHeader;                 /* 532 bytes */
 
 /* Per-channel SBR frame data (SBRData bitstream fields, sbr.h:64-73,84,99-105)
  * exactly as read_sbr_grid()/read_sbr_envelope()/read_sbr_noise() leave them

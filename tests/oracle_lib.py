@@ -24,8 +24,10 @@ SBR_HDR_DT = np.dtype([
     ("patch_num_subbands", "u1", (6,)), ("patch_start_subband", "u1", (6,)),
     ("f_tablenoise", "u1", (6,)), ("pad1", "u1", (2,)),
     ("f_tablelow", "u1", (28,)), ("f_tablehigh", "u1", (52,)), ("f_tablelim", "u1", (32,)),
+    ("map_hi", "u1", (64,)), ("map_lo", "u1", (64,)), ("map_nq", "u1", (64,)),
+    ("map_lim", "u1", (64,)), ("map_mid", "u1", (64,)), ("map_src", "u1", (64,)),
 ])
-assert SBR_HDR_DT.itemsize == 148
+assert SBR_HDR_DT.itemsize == 532
 
 SBR_CH_DT = np.dtype([
     ("bs_num_env", "u1"), ("bs_num_noise", "u1"), ("bs_amp_res", "u1"), ("bs_add_harmonic_flag", "u1"),
@@ -78,9 +80,11 @@ _lib = None
 
 def build(force=False):
     """Compile the oracle (gcc, seconds)."""
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+    inc = os.path.join(ROOT, "include")
+    srcs += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
     if force or not os.path.exists(LIB_PATH) or any(
-            os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(LIB_PATH)
-            for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))):
+            os.path.getmtime(f) > os.path.getmtime(LIB_PATH) for f in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
     return LIB_PATH
 
