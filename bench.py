@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU (default: BASELINE config)")
     ap.add_argument("--pcm", default="f32", choices=["f32", "s16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse)")
+    ap.add_argument("--gather", action="store_true",
+                    help="also time the PCM gather onto rank 0 (BASELINE config 5), reported separately")
     args = ap.parse_args()
 
     import torch
@@ -143,7 +146,12 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if os.environ.get("HEAAC_BENCH_SINGLE_DEVICE"):      # rehearsal: several ranks on one card
+            local = 0
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local)
 
@@ -188,8 +196,16 @@ def main():
     elapsed = time.perf_counter() - t0
 
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    gather_ms = None
+    if args.gather and dist is not None:
+        shard = importlib.import_module(g.PKG_NAME + ".shard")
+        src = pcm if args.backend == "nccl" else pcm.cpu()
+        torch.cuda.synchronize(); dist.barrier(); tg = time.perf_counter()
+        shard.gather_pcm(src, n * world, dst=0)
+        torch.cuda.synchronize(); dist.barrier()
+        gather_ms = (time.perf_counter() - tg) * 1e3
     if dist is not None:
-        t = torch.tensor([elapsed, kern_ms], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed, kern_ms], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_ms = float(t[0]), float(t[1])
 
@@ -215,6 +231,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kern_ms},
         }
+        if gather_ms is not None:
+            out["pcm_gather_ms"] = gather_ms
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, synth, cfg)
         print(json.dumps(out))

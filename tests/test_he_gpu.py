@@ -120,3 +120,60 @@ def test_hev2_chain_mixed_layouts(pkg, oracle, dev):
 def test_hev2_s16(pkg, oracle, dev):
     hdr = _synth().default_headers(pkg)
     _run_chain(pkg, oracle, dev, pkg.CFG_HEV2, 19, 3, 34, hdr, fmt=pkg.PCM_S16)
+
+
+def test_he_in_place_state(pkg, oracle, dev):
+    """state_out aliasing state_in (how a decoder runs frame after frame) gives the same bits."""
+    import torch
+    synth = _synth()
+    for cfg, ps_mode in ((pkg.CFG_HEV1, "20"), (pkg.CFG_HEV2, "mix")):
+        hdr = synth.default_headers(pkg, extra=True)
+        n = 28
+        rng = np.random.default_rng(41)
+        state = np.zeros((n, pkg.STATE_WORDS[cfg]), np.float32)
+        d_state = torch.from_numpy(state).cuda()
+        d_hdr = pkg.to_device(hdr)
+        for fr in synth.he_stream(rng, cfg, n, 4, hdr, ps_mode=ps_mode, hdr_choice=np.arange(n) % len(hdr)):
+            ref_pcm, state = oracle.he_decode_batch(cfg, fr["coeffs"], fr["ics"], fr["sbr"], hdr, fr["ps"], state)
+            pcm, out = dev.he_decode(cfg, torch.from_numpy(fr["coeffs"]).cuda(), pkg.to_device(fr["ics"]),
+                                     pkg.to_device(fr["sbr"]), d_hdr,
+                                     pkg.to_device(fr["ps"]) if fr["ps"] is not None else None,
+                                     d_state, state_out=d_state)
+            assert out.data_ptr() == d_state.data_ptr()
+            assert _mismatch(pcm.cpu().numpy(), ref_pcm)[0] == 0
+            assert _mismatch(d_state.cpu().numpy(), state)[0] == 0
+
+
+@pytest.mark.parametrize("cfgname,reps", [("CFG_HEV1", 1024), ("CFG_HEV2", 4096)])
+def test_he_full_size_batch_position_independent(pkg, oracle, dev, cfgname, reps):
+    """BASELINE configs 3 and 4 at full size (64 k HE-AACv1, 256 k HE-AACv2 frames): a 64-stream set,
+    checked against the oracle, is tiled across the batch (several chunks of the stage workspace);
+    every tile must reproduce the oracle's PCM and state bit for bit wherever it lands."""
+    import torch
+    synth = _synth()
+    cfg = getattr(pkg, cfgname)
+    base = 64
+    hdr = synth.default_headers(pkg, extra=True)
+    hc = np.arange(base) % len(hdr)
+    rng = np.random.default_rng(77)
+    frames = list(synth.he_stream(rng, cfg, base, 2, hdr, ps_mode="mix", hdr_choice=hc))
+    st0 = np.zeros((base, pkg.STATE_WORDS[cfg]), np.float32)
+    _, st1 = oracle.he_decode_batch(cfg, frames[0]["coeffs"], frames[0]["ics"], frames[0]["sbr"], hdr,
+                                    frames[0]["ps"], st0)
+    fr = frames[1]
+    ref_pcm, ref_state = oracle.he_decode_batch(cfg, fr["coeffs"], fr["ics"], fr["sbr"], hdr, fr["ps"], st1,
+                                                oracle.PCM_S16)
+    big = pkg.Device(base * reps)
+    try:
+        d_state = torch.from_numpy(st1).cuda().repeat(reps, 1)
+        pcm, st = big.he_decode(cfg, torch.from_numpy(fr["coeffs"]).cuda().repeat(reps, 1, 1),
+                                pkg.to_device(fr["ics"]).repeat(reps), pkg.to_device(fr["sbr"]).repeat(reps),
+                                pkg.to_device(hdr),
+                                pkg.to_device(fr["ps"]).repeat(reps) if fr["ps"] is not None else None,
+                                d_state, state_out=d_state, pcm_format=pkg.PCM_S16)
+        want_pcm = torch.from_numpy(ref_pcm).cuda()
+        want_st = torch.from_numpy(ref_state).cuda().view(torch.int32)
+        assert bool((pcm.view(reps, base, 2048, 2) == want_pcm[None]).all())
+        assert bool((st.view(torch.int32).view(reps, base, -1) == want_st[None]).all())
+    finally:
+        big.close()

@@ -1,0 +1,25 @@
+import ctypes as C, importlib, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g
+pkg = g.load_package(); synth = importlib.import_module("ffmpeg_heaac_amd.synth")
+cfg = pkg.CFG_HEV2; n = 4096
+hdr = synth.default_headers(pkg); rng = np.random.default_rng(1)
+dev = pkg.Device(n)
+frames = list(synth.he_stream(rng, cfg, 256, 3, hdr))
+rep = n // 256
+st = torch.zeros((n, pkg.STATE_WORDS[cfg]), device="cuda")
+d_hdr = pkg.to_device(hdr)
+for fr in frames:
+    args = (torch.from_numpy(fr["coeffs"]).cuda().repeat(rep, 1, 1), pkg.to_device(fr["ics"]).repeat(rep),
+            pkg.to_device(fr["sbr"]).repeat(rep), d_hdr, pkg.to_device(fr["ps"]).repeat(rep))
+    for _ in range(3):
+        dev.he_decode(cfg, *args, st, state_out=st)
+    torch.cuda.synchronize()
+out = (C.c_ulonglong * 16)()
+pkg.lib().heaac_debug_hf_stamps(out)
+v = list(out)
+print("synth channel total", v[15] - v[11])
+for i, nm in enumerate(["hist load", "imdct+v", "polyphase", "state out"]):
+    print("%-10s %8d" % (nm, v[12 + i] - v[11 + i]))
