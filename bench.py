@@ -219,7 +219,11 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("%s_%s" % (workload, args.pcm))
+            # HBM bytes per frame measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate
+            # passes, gfx950 correction applied) on this workload; scaled to one step here
+            rec = json.load(open(tpath)).get("%s_%s" % (workload, args.pcm))
+            if rec:
+                traffic = rec["bytes_per_frame"] * n
         out = {
             "metric": "HE-AAC frames/s (batched)", "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -38,15 +38,21 @@ extern "C" const char *heaac_strerror(int err)
 }
 
 // HE pipeline stages exchange W[ncore][32][32][2] and X[2][2][38][64] per frame
-// through this workspace.  Frames are processed in chunks so that it stays
-// resident in the 256 MiB Infinity Cache instead of travelling to HBM.
-#define HE_CHUNK_FRAMES 32768
+// through this workspace, one chunk of frames at a time.  Measured on MI355X
+// (profiles/r01_chunk_sweep.txt): throughput rises monotonically with the chunk
+// size (persistent-kernel tails amortise); keeping the workspace inside the
+// 256 MiB Infinity Cache (chunk <= 4096) costs more in tails than it saves in
+// HBM traffic while the kernels are latency-bound.
+#define HE_CHUNK_FRAMES 65536
 #define WS_W_FLOATS (2 * 2048)
 #define WS_X_FLOATS (2 * 2 * 38 * 64)
 
 extern "C" size_t heaac_device_workspace_bytes(size_t max_frames)
 {
-    size_t chunk = max_frames < HE_CHUNK_FRAMES ? max_frames : HE_CHUNK_FRAMES;
+    size_t cap = HE_CHUNK_FRAMES;
+    const char *env = getenv("HEAAC_CHUNK_FRAMES");          /* tuning knob */
+    if (env && atol(env) >= 64) cap = (size_t)atol(env);
+    size_t chunk = max_frames < cap ? max_frames : cap;
     if (chunk < 64) chunk = 64;
     return chunk * (WS_W_FLOATS + WS_X_FLOATS) * sizeof(float);
 }
