@@ -17,6 +17,9 @@ __device__ unsigned long long g_ps_stamps[16];
 #else
 #define STAMP(i) do {} while (0)
 #endif
+#ifndef PS_SCHED_GROUP
+#define PS_SCHED_GROUP 2
+#endif
 #define SUB_STRIDE 66          // one sub-subband row: 32 slots * (re,im) + 2 pad
 
 // Table 8.48 / 8.49 of ISO/IEC 14496-3 (aacpsdata.c:145-158): hybrid band -> parameter band
@@ -71,14 +74,16 @@ struct PsWaveT {
     static constexpr int NPAR = GENERAL ? 34 : 20;
     static constexpr bool IS_GENERAL = GENERAL;
     static constexpr int NH = GENERAL ? 8 : 4;      // H rows kept: re+im, or re only (IPD/OPD off)
-    static constexpr int TS = NB + 2;               // tile row stride in complex elements: 73 / 93
-                                                    // (stride*2 floats = 18 / 58 mod 64: conflict-free b64 columns)
-    // Views of separate __shared__ arrays (distinct objects, so the compiler can
-    // reorder tile loads around the sub-subband stores).
+    static constexpr int PNS = NB + 1;              // |s|^2 row stride (72 / 92 floats)
+    // scratch shared by |s|^2 (until the band powers are formed) and the mixed
+    // sub-subband outputs (written afterwards): max of the two, in floats
+    static constexpr int SCR = (32 * PNS > 2 * (NSUB + 1) * SUB_STRIDE) ? 32 * PNS : 2 * (NSUB + 1) * SUB_STRIDE;
+    // Views of separate __shared__ arrays (distinct objects for the alias analysis).
     HeaacPsFrame &p;
     float (*inb)[44][2];               // [NLOW] hybrid analysis input: 6 history + 38 current slots
-    float (*tile)[TS][2];              // [32]   s[kh][n] of this frame, [slot][hybrid band][re,im]
-    float (*subL)[SUB_STRIDE];         // [NSUB] mixed sub-subband outputs, left / right
+    float *pn;                         // [32][PNS] |s|^2 per slot and hybrid band
+    float (*sub)[SUB_STRIDE];          // [NSUB] sub-subband signals s[ks][n] (re,im interleaved)
+    float (*subL)[SUB_STRIDE];         // [NSUB + 1] mixed sub-subband outputs (alias pn's memory)
     float (*subR)[SUB_STRIDE];
     float (*pw)[33];                   // [NPAR] band power, then transient gain
     float (*Hs)[NH][NPAR];             // [6]    H11,H12,H21,H22 (re[,im]) rows per envelope border
@@ -195,21 +200,22 @@ __device__ __forceinline__ void hybrid_fir(const float *in, const float *filt, f
 // loop of stereo_processing (:900-969).
 //   HEAVY = true : any band (all-pass chain, 14-slot or 1-slot delay)
 //   HEAVY = false: bands >= 64 only, all of which use the 1-slot delay
-//   input  : w.tile[n][kh]
-//   output : sub-subbands (is_sub) -> w.subL / w.subR rows; QMF column q -> X planes
+//   input  : QMF bands -- this lane's column cre/cim[32] (registers);
+//            sub-subbands (is_sub) -- LDS row w.sub[kh]
+//   output : sub-subbands -> w.subL / w.subR rows; QMF column q -> X planes
 // Envelope borders are walked once in ascending order (border[0] = -1,
 // border[num_env] = 31, monotonic: what ff_ps_read_data produces).
+// ALIGNED8: every border is 8k - 1 (frame_class 0, aacps.c:203-205), so the H
+// interpolation can only restart at slots 0, 8, 16, 24 and the unrolled slot code in
+// between is one straight-line block.
 template <bool HEAVY, bool ALIGNED8, class W>
 __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, const signed char *kti,
                                         int is34, int kh, bool clear_state,
                                         const float *dl_in, float *dl_out,
                                         const float *ap_in, float *ap_out,
-                                        bool is_sub, int q,
+                                        bool is_sub, int q, const float (&cre)[32], const float (&cim)[32],
                                         float *XL0, float *XL1, float *XR0, float *XR1)
 {
-    // ALIGNED8: every envelope border is 8k - 1 (frame_class 0, aacps.c:203-205), so the
-    // H interpolation can only restart at slots 0, 8, 16, 24 and the unrolled slot code
-    // in between is one straight-line block the scheduler can software-pipeline.
     constexpr int dl_stride = 91 * 2, ap_stride = 50 * 2;
     const int nr_allpass = is34 ? 50 : 30, short_delay = is34 ? 62 : 42;
     const int b = kti[kh];
@@ -217,9 +223,8 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
     const bool allpass = HEAVY && kh < nr_allpass;
     const bool d14 = HEAVY && !allpass && kh < short_delay;
 
-    // Delay line: s[k][n - D] with D = 2 (all-pass input), 14 or 1.  For n >= D it is
-    // a row of the LDS tile, before that the state tail hst[j] = s[k][j - 14].
-    const int D = allpass ? 2 : d14 ? 14 : 1;
+    // Delay line: s[k][n - D] with D = 2 (all-pass input), 14 or 1: the lane's own column
+    // for n >= D, before that the state tail hst[j] = s[k][j - 14].
     float hre[14], him[14];
 #pragma unroll
     for (int j = HEAVY ? 0 : 13; j < 14; j++) {
@@ -253,8 +258,7 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
     }
     const bool neg_im = (is34 && kh <= 13 && kh >= 9) || (!is34 && kh <= 1);
     const float *tgrow = w.pw[b];
-    const float2 *src = reinterpret_cast<const float2 *>(&w.tile[0][kh][0]);
-    const float2 *src_d = src - D * W::TS;
+    const float2 *srow = reinterpret_cast<const float2 *>(w.sub[is_sub ? kh : 0]);
     float *lrow = w.subL[is_sub ? kh : W::NSUB], *rrow = w.subR[is_sub ? kh : W::NSUB];   // row NSUB = scratch
     // column 0 of every row is rewritten by the hybrid synthesis at the end of the frame
     const int qs = is_sub ? 0 : q;
@@ -265,7 +269,7 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
     float h11i_step = 0, h12i_step = 0, h21i_step = 0, h22i_step = 0;
     int e = -1, stop = -1;
 
-    // Fully unrolled over the 32 slots: ring positions and state selects are static.
+    // Fully unrolled over the 32 slots: ring positions and column indices are static.
 #pragma unroll
     for (int n = 0; n < 32; n++) {
         if ((!ALIGNED8 || (n & 7) == 0) && n > stop) {
@@ -289,27 +293,35 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
                 h22i_step = (w.Hs[e + 1][7][b] - h22i) * width;
             }
         }
-        const float2 sv = src[n * W::TS];
-        const float sre = sv.x, sim = sv.y;
+        // current sample
+        float sre, sim;
+        if (HEAVY) {
+            const float2 sv = srow[n];                 // sub-subband lanes (others read row 0, unused)
+            sre = is_sub ? sv.x : cre[n];
+            sim = is_sub ? sv.y : cim[n];
+        } else {
+            sre = cre[n]; sim = cim[n];
+        }
         const float tg = tgrow[n];
-        // delayed sample s[k][n - D]: one LDS read at a per-lane base (src_d = src - D rows;
-        // for n < D it points below the tile, still inside LDS, and the value is
-        // replaced by the state tail, whose register index is static per category)
+        // delayed sample s[k][n - D]
         float dre, dim;
-        {
-            const float2 dv = src_d[n * W::TS];
-            float s_re, s_im;
-            if (HEAVY) {
-                const float a_re = n < 2 ? hre[12 + (n < 2 ? n : 0)] : 0.0f, a_im = n < 2 ? him[12 + (n < 2 ? n : 0)] : 0.0f;
-                const float b_re = n < 14 ? hre[n < 14 ? n : 0] : 0.0f,      b_im = n < 14 ? him[n < 14 ? n : 0] : 0.0f;
-                const float c_re = n < 1 ? hre[13] : 0.0f,                   c_im = n < 1 ? him[13] : 0.0f;
-                s_re = allpass ? a_re : d14 ? b_re : c_re;
-                s_im = allpass ? a_im : d14 ? b_im : c_im;
-            } else {
-                s_re = hre[13]; s_im = him[13];
-            }
-            dre = n >= D ? dv.x : s_re;
-            dim = n >= D ? dv.y : s_im;
+        if (HEAVY) {
+            const float2 dv = srow[n >= 2 ? n - 2 : 0];            // sub-subbands are all-pass bands: D = 2
+            const float r2 = cre[n >= 2 ? n - 2 : 0],   i2 = cim[n >= 2 ? n - 2 : 0];
+            const float r14 = cre[n >= 14 ? n - 14 : 0], i14 = cim[n >= 14 ? n - 14 : 0];
+            const float r1 = cre[n >= 1 ? n - 1 : 0],   i1 = cim[n >= 1 ? n - 1 : 0];
+            // state tail for the first slots (static register index per category)
+            const float t2r = n < 2 ? hre[12 + (n < 2 ? n : 0)] : 0.0f, t2i = n < 2 ? him[12 + (n < 2 ? n : 0)] : 0.0f;
+            const float t14r = n < 14 ? hre[n < 14 ? n : 0] : 0.0f,     t14i = n < 14 ? him[n < 14 ? n : 0] : 0.0f;
+            const float t1r = n < 1 ? hre[13] : 0.0f,                   t1i = n < 1 ? him[13] : 0.0f;
+            const float ap_r = n >= 2 ? (is_sub ? dv.x : r2) : t2r, ap_i = n >= 2 ? (is_sub ? dv.y : i2) : t2i;
+            const float d14r = n >= 14 ? r14 : t14r,                d14i = n >= 14 ? i14 : t14i;
+            const float d1r = n >= 1 ? r1 : t1r,                    d1i = n >= 1 ? i1 : t1i;
+            dre = allpass ? ap_r : d14 ? d14r : d1r;
+            dim = allpass ? ap_i : d14 ? d14i : d1i;
+        } else {
+            dre = n >= 1 ? cre[n >= 1 ? n - 1 : 0] : hre[13];
+            dim = n >= 1 ? cim[n >= 1 ? n - 1 : 0] : him[13];
         }
         float r_re, r_im;
         if (HEAVY) {
@@ -354,17 +366,26 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
         // Branch-free stores: sub-subband lanes keep L/R in LDS rows (hybrid synthesis sums
         // them later) and send their global store to column 0, which the hybrid synthesis
         // rewrites afterwards; QMF lanes store to X and send their LDS store to a scratch row.
-        *reinterpret_cast<float2 *>(lrow + 2 * n) = make_float2(lre, lim);
-        *reinterpret_cast<float2 *>(rrow + 2 * n) = make_float2(rre, rim);
+        if (HEAVY) {
+            *reinterpret_cast<float2 *>(lrow + 2 * n) = make_float2(lre, lim);
+            *reinterpret_cast<float2 *>(rrow + 2 * n) = make_float2(rre, rim);
+        }
         gl0[n * 64] = lre; gl1[n * 64] = lim;
         gr0[n * 64] = rre; gr1[n * 64] = rim;
+        // bound the scheduler's look-ahead: without it the 32 unrolled slots are
+        // interleaved until the register file overflows
+        if ((n & (PS_SCHED_GROUP - 1)) == PS_SCHED_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
     }
-    // new delay-line tail = s[k][18..31], straight from the tile
+    // new delay-line tail = s[k][18..31]
 #pragma unroll
     for (int j = 0; j < 14; j++) {
-        const float2 v = src[(18 + j) * W::TS];
-        dl_out[j * dl_stride]     = v.x;
-        dl_out[j * dl_stride + 1] = v.y;
+        float vr = cre[18 + j], vi = cim[18 + j];
+        if (HEAVY) {
+            const float2 v = srow[18 + j];
+            vr = is_sub ? v.x : vr; vi = is_sub ? v.y : vi;
+        }
+        dl_out[j * dl_stride]     = vr;
+        dl_out[j * dl_stride + 1] = vi;
     }
     if (allpass) {
         // times 27..31 sit at ring positions (27 + j) % 5
@@ -381,20 +402,19 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
 // power[i][n] = sum over the members of parameter band i (ascending hybrid band) of |s|^2.
 // The member lists are constexpr, so both loops unroll into straight-line LDS reads.
 template <bool IS34, int I>
-__device__ __forceinline__ void band_power_one(const float2 *row, float *pw_col)
+__device__ __forceinline__ void band_power_one(const float *row, float *pw_col)
 {
     constexpr int J0 = IS34 ? kMem34.first[I] : kMem20.first[I];
     constexpr int J1 = IS34 ? kMem34.first[I + 1] : kMem20.first[I + 1];
     float acc = 0.0f;
 #pragma unroll
     for (int j = J0; j < J1; j++) {
-        const float2 v = row[IS34 ? kMem34.order[j] : kMem20.order[j]];
-        acc += v.x * v.x + v.y * v.y;
+        acc += row[IS34 ? kMem34.order[j] : kMem20.order[j]];      // |s|^2 = re*re + im*im
     }
     pw_col[I * 33] = acc;          // pw[I][n]
 }
 template <bool IS34, int I0, int I1>
-__device__ __forceinline__ void band_power_range(const float2 *row, float *pw_col)
+__device__ __forceinline__ void band_power_range(const float *row, float *pw_col)
 {
     if constexpr (I0 < I1) {
         band_power_one<IS34, I0>(row, pw_col);
@@ -402,7 +422,7 @@ __device__ __forceinline__ void band_power_range(const float2 *row, float *pw_co
     }
 }
 template <bool IS34>
-__device__ __forceinline__ void band_power(const float2 *row, float *pw_col, int half)
+__device__ __forceinline__ void band_power(const float *row, float *pw_col, int half)
 {
     constexpr int SPLIT = IS34 ? kMem34.split : kMem20.split;
     constexpr int NPAR_ = IS34 ? 34 : 20;
@@ -451,20 +471,24 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     const bool switched = GENERAL && is34 != p.is34bands_old;
     const BandMembers &M = is34 ? kMem34 : kMem20;
 
-    // ---- stage this frame's QMF rows in LDS: every load is in flight at once ----
-    // tile[n][kh]: kh < nsub sub-subbands (filled below), kh >= nsub <- QMF band kh - nsub + nlow
+    // ---- every lane loads ONE QMF column (32 slots, all loads in flight at once) ----
+    // lanes [0, P2)          : q = 64 - P2 + lane   the bands of pass 2 (hybrid index 64 + lane)
+    // lanes [P2, nsub)       : q = lane - P2        the nlow bands that feed the hybrid filters
+    // lanes [nsub, 64)       : q = lane - nsub + nlow   hybrid index kh = lane (pass 1)
+    const int P2 = nr_bands - 64;
+    const int q_own = lane < P2 ? 64 - P2 + lane : lane < nsub ? lane - P2 : lane - nsub + nlow;
+    float cre[32], cim[32];
+#pragma unroll
+    for (int n = 0; n < 32; n++) { cre[n] = XL0[n * 64 + q_own]; cim[n] = XL1[n * 64 + q_own]; }
     {
-        const int q = lane, kh = q - nlow + nsub;
-        float re[32], im[32];
+        const int kh_own = lane >= nsub ? lane : 64 + lane;      // valid unless P2 <= lane < nsub
+        if (lane >= nsub || lane < P2) {
 #pragma unroll
-        for (int n = 0; n < 32; n++) { re[n] = XL0[n * 64 + q]; im[n] = XL1[n * 64 + q]; }
-        if (q >= nlow) {
-#pragma unroll
-            for (int n = 0; n < 32; n++) { w.tile[n][kh][0] = re[n]; w.tile[n][kh][1] = im[n]; }
-        } else if (q < nlow) {
+            for (int n = 0; n < 32; n++) w.pn[n * WT::PNS + kh_own] = cre[n] * cre[n] + cim[n] * cim[n];
+        } else {
             // hybrid analysis input (aacps.c:362-367): in[i][j+6] = L[.][j][i]
 #pragma unroll
-            for (int n = 0; n < 32; n++) { w.inb[q][n + 6][0] = re[n]; w.inb[q][n + 6][1] = im[n]; }
+            for (int n = 0; n < 32; n++) { w.inb[q_own][n + 6][0] = cre[n]; w.inb[q_own][n + 6][1] = cim[n]; }
         }
     }
     for (int t = lane; t < nlow * 6; t += WAVE) {
@@ -525,8 +549,9 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
             if (which == reverse) { re = re_in + re_op; im = im_in + im_op; }
             else                  { re = re_in - re_op; im = im_in - im_op; }
         }
-        w.tile[n][ks][0] = re;
-        w.tile[n][ks][1] = im;
+        w.sub[ks][2 * n] = re;
+        w.sub[ks][2 * n + 1] = im;
+        w.pn[n * WT::PNS + ks] = re * re + im * im;
     }
     wave_sync();
 
@@ -536,7 +561,7 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     // unroll into straight-line LDS reads; two half-waves split the parameter bands.
     {
         const int n = lane & 31, half = lane >> 5;
-        const float2 *row = reinterpret_cast<const float2 *>(&w.tile[n][0][0]);
+        const float *row = w.pn + n * WT::PNS;
         if (is34) {
             if constexpr (GENERAL) band_power<true>(row, &w.pw[0][n], half);
         } else {
@@ -696,11 +721,11 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
         if (aligned8)
             ps_band<true, true>(w, g_tab, M.kti, is34, kh, switched || kh >= top,
                                 dl_in + kh * 2, dl_out + kh * 2, ap_in + kh * 2, ap_out + kh * 2,
-                                is_sub, kh - nsub + nlow, XL0, XL1, XR0, XR1);
+                                is_sub, kh - nsub + nlow, cre, cim, XL0, XL1, XR0, XR1);
         else
             ps_band<true, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top,
                                  dl_in + kh * 2, dl_out + kh * 2, ap_in + kh * 2, ap_out + kh * 2,
-                                 is_sub, kh - nsub + nlow, XL0, XL1, XR0, XR1);
+                                 is_sub, kh - nsub + nlow, cre, cim, XL0, XL1, XR0, XR1);
     }
     STAMP(6);
     // ---- pass 2: hybrid bands 64.. (all use the one-slot delay) ----
@@ -709,11 +734,11 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
         if (aligned8)
             ps_band<false, true>(w, g_tab, M.kti, is34, kh, switched || kh >= top,
                                  dl_in + kh * 2, dl_out + kh * 2, ap_in, ap_out,
-                                 false, kh - nsub + nlow, XL0, XL1, XR0, XR1);
+                                 false, kh - nsub + nlow, cre, cim, XL0, XL1, XR0, XR1);
         else
             ps_band<false, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top,
                                   dl_in + kh * 2, dl_out + kh * 2, ap_in, ap_out,
-                                  false, kh - nsub + nlow, XL0, XL1, XR0, XR1);
+                                  false, kh - nsub + nlow, cre, cim, XL0, XL1, XR0, XR1);
     }
     STAMP(7);
     // bands that exist in the state record but not in this layout / all-pass set
@@ -775,15 +800,16 @@ void k_ps(const float *__restrict__ g_tab, const HeaacPsFrame *__restrict__ g_ps
     using WT = PsWaveT<GENERAL>;
     __shared__ HeaacPsFrame s_p[WAVES];
     __shared__ float s_inb[WAVES][WT::NLOW][44][2];
-    __shared__ float s_subL[WAVES][WT::NSUB + 1][SUB_STRIDE];      // + 1 scratch row
-    __shared__ float s_subR[WAVES][WT::NSUB + 1][SUB_STRIDE];
+    __shared__ float s_scr[WAVES][WT::SCR];          // |s|^2, later subL / subR
+    __shared__ float s_sub[WAVES][WT::NSUB][SUB_STRIDE];
     __shared__ float s_pw[WAVES][WT::NPAR][33];
     __shared__ float s_Hs[WAVES][6][WT::NH][WT::NPAR];
     __shared__ signed char s_idx[WAVES][4][5][WT::NPAR];
-    __shared__ float s_tile[WAVES][32][WT::TS][2];   // last: rows below a wave's tile base are still LDS
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
-    WT W = { s_p[wave], s_inb[wave], s_tile[wave], s_subL[wave], s_subR[wave], s_pw[wave], s_Hs[wave],
-             s_idx[wave][0], s_idx[wave][1], s_idx[wave][2], s_idx[wave][3] };
+    WT W = { s_p[wave], s_inb[wave], s_scr[wave], s_sub[wave],
+             reinterpret_cast<float (*)[SUB_STRIDE]>(s_scr[wave]),
+             reinterpret_cast<float (*)[SUB_STRIDE]>(s_scr[wave] + (WT::NSUB + 1) * SUB_STRIDE),
+             s_pw[wave], s_Hs[wave], s_idx[wave][0], s_idx[wave][1], s_idx[wave][2], s_idx[wave][3] };
     for (unsigned long long f = (unsigned long long)blockIdx.x * WAVES + wave; f < n;
          f += (unsigned long long)gridDim.x * WAVES) {
         if (ps_frame_is_general(&g_ps[f]) != GENERAL)
@@ -796,8 +822,8 @@ void k_ps(const float *__restrict__ g_tab, const HeaacPsFrame *__restrict__ g_ps
     }
 }
 
-#define PS_WAVES_20 5
-#define PS_WAVES_GEN 2
+#define PS_WAVES_20 8
+#define PS_WAVES_GEN 4
 
 extern "C" int heaac_launch_ps(const float *d_tab, const HeaacPsFrame *d_ps, const HeaacSbrFrame *d_sbr,
                                const HeaacSbrHeader *d_hdr, const float *d_state_in, float *d_state_out,

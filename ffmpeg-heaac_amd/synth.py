@@ -232,15 +232,17 @@ class _PsChain:
         self.num_env, self.is34 = num_env, is34
 
 
-def he_stream(rng, cfg, n, steps, hdr, ps_mode="20", hdr_choice=None, core_bins=400):
+def he_stream(rng, cfg, n, steps, hdr, ps_mode="20", hdr_choice=None, core_bins=400, coupling=0.0):
     """Yield dicts {coeffs, ics, sbr, ps} per step for n streams.
-    hdr: header table; hdr_choice: per-stream header index (default all 0)."""
+    hdr: header table; hdr_choice: per-stream header index (default all 0);
+    coupling: fraction of CPE streams coded with bs_coupling = 1 (HE-AACv1 only)."""
     ncore = 2 if cfg == CFG_HEV1 else 1
     if hdr_choice is None:
         hdr_choice = np.zeros(n, int)
     ics_chains = [_IcsChain(rng, n) for _ in range(ncore)]
     sbr_chains = [[_SbrChain(rng, hdr[hdr_choice[s]], hdr_choice[s]) for _ in range(ncore)] for s in range(n)]
     ps_chains = [_PsChain(rng, ps_mode) for _ in range(n)] if cfg == CFG_HEV2 else None
+    coupled = (rng.random(n) < coupling) if cfg == CFG_HEV1 else np.zeros(n, bool)
     first = True
     for _ in range(steps):
         ics = np.stack([ch.step() for ch in ics_chains], axis=1)
@@ -258,6 +260,24 @@ def he_stream(rng, cfg, n, steps, hdr, ps_mode="20", hdr_choice=None, core_bins=
             fr["m_old"] = 0 if first else h["m"]
             for c in range(ncore):
                 sbr_chains[s][c].step(fr["ch"][c])
+            if coupled[s]:
+                # read_sbr_channel_pair_element with bs_coupling (aacsbr.c:842-858): channel 1 takes
+                # channel 0's grid (copy_sbr_grid, :747-766) and inverse-filtering modes; envelope and
+                # noise data are read per channel (balance values for channel 1)
+                fr["bs_coupling"] = 1
+                c0, c1 = fr["ch"][0], fr["ch"][1]
+                keep_prev = (int(c1["bs_freq_res"][0]), int(c1["t_env_num_env_old"]), int(c1["e_a"][0]))
+                for f in ("bs_num_env", "bs_num_noise", "bs_amp_res", "bs_freq_res", "t_env", "t_q", "e_a"):
+                    c1[f] = c0[f]
+                c1["bs_freq_res"][0], c1["t_env_num_env_old"], c1["e_a"][0] = keep_prev
+                c1["bs_invf_mode"][0] = c0["bs_invf_mode"][0]
+                lo, hi = (0, 25) if c0["bs_amp_res"] else (0, 49)          # balance: pan_offset +- 12 / 24
+                c1["env_facs_q"][: int(c0["bs_num_env"]), :] = rng.integers(lo, hi, (int(c0["bs_num_env"]), 48))
+                c1["noise_facs_q"][: int(c0["bs_num_noise"]), :] = rng.integers(0, 25, (int(c0["bs_num_noise"]), 5))
+                ch1 = sbr_chains[s][1]
+                ch0 = sbr_chains[s][0]
+                ch1.num_env, ch1.t_env_last, ch1.e_a1 = ch0.num_env, ch0.t_env_last, ch0.e_a1
+                ch1.freq_res_last, ch1.invf = ch0.freq_res_last, c1["bs_invf_mode"][0].copy()
             if ps is not None:
                 ps_chains[s].step(ps[s])
         first = False

@@ -50,7 +50,7 @@ def test_qmf_synthesis_batch(pkg, oracle, dev, n):
 
 
 def _run_chain(pkg, oracle, dev, cfg, n, steps, seed, hdr, ps_mode="20", hdr_choice=None, fmt=None,
-               check_state=True):
+               check_state=True, coupling=0.0):
     import torch
     synth = _synth()
     rng = np.random.default_rng(seed)
@@ -58,7 +58,8 @@ def _run_chain(pkg, oracle, dev, cfg, n, steps, seed, hdr, ps_mode="20", hdr_cho
     state = np.zeros((n, pkg.STATE_WORDS[cfg]), np.float32)
     d_state = torch.from_numpy(state).cuda()
     d_hdr = pkg.to_device(hdr)
-    for step, fr in enumerate(synth.he_stream(rng, cfg, n, steps, hdr, ps_mode=ps_mode, hdr_choice=hdr_choice)):
+    for step, fr in enumerate(synth.he_stream(rng, cfg, n, steps, hdr, ps_mode=ps_mode, hdr_choice=hdr_choice,
+                                              coupling=coupling)):
         ref_pcm, state = oracle.he_decode_batch(cfg, fr["coeffs"], fr["ics"], fr["sbr"], hdr, fr["ps"], state, fmt)
         pcm, d_state = dev.he_decode(cfg, torch.from_numpy(fr["coeffs"]).cuda(), pkg.to_device(fr["ics"]),
                                      pkg.to_device(fr["sbr"]), d_hdr,
@@ -177,3 +178,10 @@ def test_he_full_size_batch_position_independent(pkg, oracle, dev, cfgname, reps
         assert bool((st.view(torch.int32).view(reps, base, -1) == want_st[None]).all())
     finally:
         big.close()
+
+
+def test_hev1_coupled_channel_pairs(pkg, oracle, dev):
+    """bs_coupling = 1: sbr_dequant's pan-law branch (aacsbr.c:1094-1114), shared grid."""
+    hdr = _synth().default_headers(pkg, extra=True)
+    n = 42
+    _run_chain(pkg, oracle, dev, pkg.CFG_HEV1, n, 5, 25, hdr, hdr_choice=np.arange(n) % len(hdr), coupling=0.7)
