@@ -26,6 +26,50 @@ __device__ __forceinline__ void wave_sync()
 }
 
 // ---------------------------------------------------------------------------
+// Buffer addressing for per-unit HBM records.  A unit's record starts at a
+// wave-uniform address, so every access is  base(SGPR x4) + lane part (one
+// 32-bit VGPR) + uniform part (SGPR page + 12-bit immediate): no 64-bit
+// per-access VGPR addresses, which the compiler otherwise hoists out of the
+// unrolled slot loops and spills.  Indices are in 32-bit words.
+// ---------------------------------------------------------------------------
+struct GBuf {
+    __amdgpu_buffer_rsrc_t r;
+    __device__ __forceinline__ explicit GBuf(const void *base)
+        : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000)) {}
+    // v: lane-dependent word index, s: wave-uniform word index
+    __device__ __forceinline__ float ld(int v, int s = 0) const
+    {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+            r, v * 4 + ((s * 4) & 4095), (s * 4) & ~4095, 0));
+    }
+    __device__ __forceinline__ void st(float x, int v, int s = 0) const
+    {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), r,
+                                              v * 4 + ((s * 4) & 4095), (s * 4) & ~4095, 0);
+    }
+    // same with the lane part given as a BYTE offset (hot loops keep it in one VGPR)
+    __device__ __forceinline__ float ldb(int vb, int s = 0) const
+    {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+            r, vb + ((s * 4) & 4095), (s * 4) & ~4095, 0));
+    }
+    __device__ __forceinline__ void stb(float x, int vb, int s = 0) const
+    {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), r,
+                                              vb + ((s * 4) & 4095), (s * 4) & ~4095, 0);
+    }
+};
+
+// Redefine a lane offset opaquely: address arithmetic on it cannot be hoisted out of
+// an unrolled loop (where it would occupy a VGPR per access) and folds into the
+// instruction's immediate offset instead.
+__device__ __forceinline__ int opaque(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// ---------------------------------------------------------------------------
 // Split-radix schedule.  The reference FFT (libavcodec/fft.c:283-351) is the
 // recursion  fft(n, o) = fft(n/2, o); fft(n/4, o+n/2); fft(n/4, o+3n/4);
 // pass(n, o)  bottoming out in fft4/fft8.  A block of size M exists at offset

@@ -211,12 +211,11 @@ __device__ __forceinline__ void hybrid_fir(const float *in, const float *filt, f
 template <bool HEAVY, bool ALIGNED8, class W>
 __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, const signed char *kti,
                                         int is34, int kh, bool clear_state,
-                                        const float *dl_in, float *dl_out,
-                                        const float *ap_in, float *ap_out,
-                                        bool is_sub, int q, const float (&cre)[32], const float (&cim)[32],
-                                        float *XL0, float *XL1, float *XR0, float *XR1)
+                                        const GBuf &SI, const GBuf &SO, const GBuf &X,
+                                        bool is_sub, int q, const float (&cre)[32], const float (&cim)[32])
 {
     constexpr int dl_stride = 91 * 2, ap_stride = 50 * 2;
+    constexpr int XP = 38 * 64;                       // X record: [L, R][re, im][38][64]
     const int nr_allpass = is34 ? 50 : 30, short_delay = is34 ? 62 : 42;
     const int b = kti[kh];
     const int enable_ipdopd = W::IS_GENERAL ? w.p.enable_ipdopd : 0;
@@ -228,8 +227,10 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
     float hre[14], him[14];
 #pragma unroll
     for (int j = HEAVY ? 0 : 13; j < 14; j++) {
-        hre[j] = clear_state ? 0.0f : dl_in[j * dl_stride];
-        him[j] = clear_state ? 0.0f : dl_in[j * dl_stride + 1];
+        const float a = SI.ld(kh * 2, HEAAC_PS_DELAY + j * dl_stride);
+        const float b = SI.ld(kh * 2, HEAAC_PS_DELAY + j * dl_stride + 1);
+        hre[j] = clear_state ? 0.0f : a;
+        him[j] = clear_state ? 0.0f : b;
     }
     // all-pass history: ring of 5 per link, position = time mod 5 (state j = time j - 5)
     float are[3][5], aim[3][5];
@@ -249,8 +250,10 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
             qim[m] = g_tab[TB_QFRACT + ((is34 * 50 + kh) * 3 + m) * 2 + 1];
 #pragma unroll
             for (int j = 0; j < 5; j++) {
-                are[m][j] = clear_state ? 0.0f : ap_in[(m * 5 + j) * ap_stride];
-                aim[m][j] = clear_state ? 0.0f : ap_in[(m * 5 + j) * ap_stride + 1];
+                const float a = SI.ld(kh * 2, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride);
+                const float b = SI.ld(kh * 2, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride + 1);
+                are[m][j] = clear_state ? 0.0f : a;
+                aim[m][j] = clear_state ? 0.0f : b;
             }
         }
         phre = g_tab[TB_PHIFRACT + (is34 * 50 + kh) * 2];
@@ -261,8 +264,7 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
     const float2 *srow = reinterpret_cast<const float2 *>(w.sub[is_sub ? kh : 0]);
     float *lrow = w.subL[is_sub ? kh : W::NSUB], *rrow = w.subR[is_sub ? kh : W::NSUB];   // row NSUB = scratch
     // column 0 of every row is rewritten by the hybrid synthesis at the end of the frame
-    const int qs = is_sub ? 0 : q;
-    float *gl0 = XL0 + qs, *gl1 = XL1 + qs, *gr0 = XR0 + qs, *gr1 = XR1 + qs;
+    const int qs4 = is_sub ? 0 : q * 4;
 
     float h11r = 0, h12r = 0, h21r = 0, h22r = 0, h11i = 0, h12i = 0, h21i = 0, h22i = 0;
     float h11r_step = 0, h12r_step = 0, h21r_step = 0, h22r_step = 0;
@@ -370,8 +372,11 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
             *reinterpret_cast<float2 *>(lrow + 2 * n) = make_float2(lre, lim);
             *reinterpret_cast<float2 *>(rrow + 2 * n) = make_float2(rre, rim);
         }
-        gl0[n * 64] = lre; gl1[n * 64] = lim;
-        gr0[n * 64] = rre; gr1[n * 64] = rim;
+        {
+            const int qb = opaque(qs4);
+            X.stb(lre, qb, n * 64);          X.stb(lim, qb, XP + n * 64);
+            X.stb(rre, qb, 2 * XP + n * 64); X.stb(rim, qb, 3 * XP + n * 64);
+        }
         // bound the scheduler's look-ahead: without it the 32 unrolled slots are
         // interleaved until the register file overflows
         if ((n & (PS_SCHED_GROUP - 1)) == PS_SCHED_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
@@ -384,8 +389,8 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
             const float2 v = srow[18 + j];
             vr = is_sub ? v.x : vr; vi = is_sub ? v.y : vi;
         }
-        dl_out[j * dl_stride]     = vr;
-        dl_out[j * dl_stride + 1] = vi;
+        SO.st(vr, kh * 2, HEAAC_PS_DELAY + j * dl_stride);
+        SO.st(vi, kh * 2, HEAAC_PS_DELAY + j * dl_stride + 1);
     }
     if (allpass) {
         // times 27..31 sit at ring positions (27 + j) % 5
@@ -393,8 +398,8 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
         for (int m = 0; m < 3; m++)
 #pragma unroll
             for (int j = 0; j < 5; j++) {
-                ap_out[(m * 5 + j) * ap_stride]     = are[m][(27 + j) % 5];
-                ap_out[(m * 5 + j) * ap_stride + 1] = aim[m][(27 + j) % 5];
+                SO.st(are[m][(27 + j) % 5], kh * 2, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride);
+                SO.st(aim[m][(27 + j) % 5], kh * 2, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride + 1);
             }
     }
 }
@@ -441,10 +446,12 @@ template <bool GENERAL>
 __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__restrict__ g_tab,
                                          const HeaacPsFrame *g_p, int top_qmf,
                                          const float *st_in, float *st_out,
-                                         float *XL /* [2][38][64] in: mono, out: left */,
-                                         float *XR /* [2][38][64] out: right */, int lane, int wave = 0)
+                                         float *Xrec /* [2][2][38][64]: in: mono in [0], out: left, right */,
+                                         int lane, int wave = 0)
 {
     using WT = PsWaveT<GENERAL>;
+    constexpr int XP = 38 * 64;
+    const GBuf SI(st_in), SO(st_out), X(Xrec);
     {
         const uint32_t *s = reinterpret_cast<const uint32_t *>(g_p);
         uint32_t *d = reinterpret_cast<uint32_t *>(&w.p);   // w.p is a reference into LDS
@@ -453,13 +460,12 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     wave_sync();
     STAMP(0);
     const HeaacPsFrame &p = w.p;
-    float *XL0 = XL, *XL1 = XL + 38 * 64, *XR0 = XR, *XR1 = XR + 38 * 64;
 
     if (!p.start) {
         // memcpy(sbr->X[1], sbr->X[0]) (aacsbr.c:1755); PS state untouched
-        for (int t = lane; t < 2 * 38 * 64; t += WAVE) XR[t] = XL[t];
+        for (int t = lane; t < 2 * XP; t += WAVE) X.st(X.ld(t), t, 2 * XP);
         if (st_out != st_in)
-            for (int t = lane; t < HEAAC_ST_PS; t += WAVE) st_out[t] = st_in[t];
+            for (int t = lane; t < HEAAC_ST_PS; t += WAVE) SO.st(SI.ld(t), t);
         wave_sync();
         return;
     }
@@ -479,7 +485,10 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     const int q_own = lane < P2 ? 64 - P2 + lane : lane < nsub ? lane - P2 : lane - nsub + nlow;
     float cre[32], cim[32];
 #pragma unroll
-    for (int n = 0; n < 32; n++) { cre[n] = XL0[n * 64 + q_own]; cim[n] = XL1[n * 64 + q_own]; }
+    for (int n = 0; n < 32; n++) {
+        const int qb = opaque(q_own * 4);
+        cre[n] = X.ldb(qb, n * 64); cim[n] = X.ldb(qb, XP + n * 64);
+    }
     {
         const int kh_own = lane >= nsub ? lane : 64 + lane;      // valid unless P2 <= lane < nsub
         if (lane >= nsub || lane < P2) {
@@ -493,11 +502,11 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     }
     for (int t = lane; t < nlow * 6; t += WAVE) {
         const int i = t / 6, j = t % 6;
-        w.inb[i][j][0] = st_in[HEAAC_PS_INBUF + t * 2];
-        w.inb[i][j][1] = st_in[HEAAC_PS_INBUF + t * 2 + 1];
+        w.inb[i][j][0] = SI.ld(t * 2, HEAAC_PS_INBUF);
+        w.inb[i][j][1] = SI.ld(t * 2, HEAAC_PS_INBUF + 1);
         // lookahead slots 32..37
-        w.inb[i][38 + j][0] = XL0[(32 + j) * 64 + i];
-        w.inb[i][38 + j][1] = XL1[(32 + j) * 64 + i];
+        w.inb[i][38 + j][0] = X.ld((32 + j) * 64 + i);
+        w.inb[i][38 + j][1] = X.ld((32 + j) * 64 + i, XP);
     }
     wave_sync();
     STAMP(1);
@@ -506,9 +515,9 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
         const int i = t / 6, j = t % 6;
         float re, im;
         if (i < nlow) { re = w.inb[i][32 + j][0]; im = w.inb[i][32 + j][1]; }
-        else          { re = XL0[(26 + j) * 64 + i]; im = XL1[(26 + j) * 64 + i]; }
-        st_out[HEAAC_PS_INBUF + t * 2]     = re;
-        st_out[HEAAC_PS_INBUF + t * 2 + 1] = im;
+        else          { re = X.ld((26 + j) * 64 + i); im = X.ld((26 + j) * 64 + i, XP); }
+        SO.st(re, t * 2, HEAAC_PS_INBUF);
+        SO.st(im, t * 2, HEAAC_PS_INBUF + 1);
     }
     // ---- hybrid filters -> sub[ks][n] ----
     for (int t = lane; t < nsub * 32; t += WAVE) {
@@ -573,9 +582,8 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     // ---- transient detection (:681-692), one lane per parameter band ----
     if (lane < nr_par) {
         const int i = lane;
-        float peak = switched ? 0.0f : st_in[HEAAC_PS_PEAK + i];
-        float smooth = switched ? 0.0f : st_in[HEAAC_PS_PSMOOTH + i];
-        float diff = switched ? 0.0f : st_in[HEAAC_PS_PDIFF + i];
+        float peak = SI.ld(i, HEAAC_PS_PEAK), smooth = SI.ld(i, HEAAC_PS_PSMOOTH), diff = SI.ld(i, HEAAC_PS_PDIFF);
+        if (switched) { peak = 0.0f; smooth = 0.0f; diff = 0.0f; }
         float prow[32];
 #pragma unroll
         for (int n = 0; n < 32; n++) prow[n] = w.pw[i][n];
@@ -589,15 +597,16 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
             const float denom = 1.5f * diff;
             w.pw[i][n] = (denom > smooth) ? smooth / denom : 1.0f;
         }
-        st_out[HEAAC_PS_PEAK + i] = peak;
-        st_out[HEAAC_PS_PSMOOTH + i] = smooth;
-        st_out[HEAAC_PS_PDIFF + i] = diff;
+        SO.st(peak, i, HEAAC_PS_PEAK);
+        SO.st(smooth, i, HEAAC_PS_PSMOOTH);
+        SO.st(diff, i, HEAAC_PS_PDIFF);
     } else if (lane < 34) {
         // parameter bands 20..33 are not touched in 20-band mode
         const int i = lane;
-        st_out[HEAAC_PS_PEAK + i]    = switched ? 0.0f : st_in[HEAAC_PS_PEAK + i];
-        st_out[HEAAC_PS_PSMOOTH + i] = switched ? 0.0f : st_in[HEAAC_PS_PSMOOTH + i];
-        st_out[HEAAC_PS_PDIFF + i]   = switched ? 0.0f : st_in[HEAAC_PS_PDIFF + i];
+        const float a = SI.ld(i, HEAAC_PS_PEAK), b = SI.ld(i, HEAAC_PS_PSMOOTH), c = SI.ld(i, HEAAC_PS_PDIFF);
+        SO.st(switched ? 0.0f : a, i, HEAAC_PS_PEAK);
+        SO.st(switched ? 0.0f : b, i, HEAAC_PS_PSMOOTH);
+        SO.st(switched ? 0.0f : c, i, HEAAC_PS_PDIFF);
     }
 
     STAMP(4);
@@ -690,25 +699,21 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
             const bool imag = j & 1;
             float v;
             if (!imag || p.enable_ipdopd) v = b < nr_par ? w.Hs[p.num_env][j][b] : 0.0f;
-            else v = st_in[HEAAC_PS_H + t];
-            st_out[HEAAC_PS_H + t] = v;
+            else v = SI.ld(t, HEAAC_PS_H);
+            SO.st(v, t, HEAAC_PS_H);
         }
     } else {
         for (int t = lane; t < 4 * 34; t += WAVE) {
             const int j = t / 34, b = t % 34;
-            st_out[HEAAC_PS_H + 2 * j * 34 + b] = b < 20 ? w.Hs[p.num_env][j][b] : 0.0f;
+            SO.st(b < 20 ? w.Hs[p.num_env][j][b] : 0.0f, 2 * j * 34 + b, HEAAC_PS_H);
         }
         if (st_out != st_in)
             for (int t = lane; t < 4 * 34; t += WAVE) {
                 const int j = t / 34, b = t % 34;
-                st_out[HEAAC_PS_H + (2 * j + 1) * 34 + b] = st_in[HEAAC_PS_H + (2 * j + 1) * 34 + b];
+                SO.st(SI.ld((2 * j + 1) * 34 + b, HEAAC_PS_H), (2 * j + 1) * 34 + b, HEAAC_PS_H);
             }
     }
 
-    const float *dl_in = st_in + HEAAC_PS_DELAY;
-    float *dl_out = st_out + HEAAC_PS_DELAY;
-    const float *ap_in = st_in + HEAAC_PS_APDELAY;
-    float *ap_out = st_out + HEAAC_PS_APDELAY;
     STAMP(5);
     // every border at 8k - 1 (what frame_class 0 produces): fast straight-line variant
     bool aligned8 = true;
@@ -719,26 +724,22 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
         const int kh = lane;
         const bool is_sub = kh < nsub;
         if (aligned8)
-            ps_band<true, true>(w, g_tab, M.kti, is34, kh, switched || kh >= top,
-                                dl_in + kh * 2, dl_out + kh * 2, ap_in + kh * 2, ap_out + kh * 2,
-                                is_sub, kh - nsub + nlow, cre, cim, XL0, XL1, XR0, XR1);
+            ps_band<true, true>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X,
+                                 is_sub, kh - nsub + nlow, cre, cim);
         else
-            ps_band<true, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top,
-                                 dl_in + kh * 2, dl_out + kh * 2, ap_in + kh * 2, ap_out + kh * 2,
-                                 is_sub, kh - nsub + nlow, cre, cim, XL0, XL1, XR0, XR1);
+            ps_band<true, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X,
+                                 is_sub, kh - nsub + nlow, cre, cim);
     }
     STAMP(6);
     // ---- pass 2: hybrid bands 64.. (all use the one-slot delay) ----
     if (lane < nr_bands - 64) {
         const int kh = 64 + lane;
         if (aligned8)
-            ps_band<false, true>(w, g_tab, M.kti, is34, kh, switched || kh >= top,
-                                 dl_in + kh * 2, dl_out + kh * 2, ap_in, ap_out,
-                                 false, kh - nsub + nlow, cre, cim, XL0, XL1, XR0, XR1);
+            ps_band<false, true>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X,
+                                 false, kh - nsub + nlow, cre, cim);
         else
-            ps_band<false, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top,
-                                  dl_in + kh * 2, dl_out + kh * 2, ap_in, ap_out,
-                                  false, kh - nsub + nlow, cre, cim, XL0, XL1, XR0, XR1);
+            ps_band<false, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X,
+                                 false, kh - nsub + nlow, cre, cim);
     }
     STAMP(7);
     // bands that exist in the state record but not in this layout / all-pass set
@@ -746,16 +747,18 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     for (int t = lane; t < 14 * 91; t += WAVE) {
         const int k = t % 91;
         if (k >= nr_bands) {
-            dl_out[t * 2]     = switched ? 0.0f : dl_in[t * 2];
-            dl_out[t * 2 + 1] = switched ? 0.0f : dl_in[t * 2 + 1];
+            const float a = SI.ld(t * 2, HEAAC_PS_DELAY), b = SI.ld(t * 2, HEAAC_PS_DELAY + 1);
+            SO.st(switched ? 0.0f : a, t * 2, HEAAC_PS_DELAY);
+            SO.st(switched ? 0.0f : b, t * 2, HEAAC_PS_DELAY + 1);
         }
     }
     if (st_out != st_in || switched)
     for (int t = lane; t < 15 * 50; t += WAVE) {
         const int k = t % 50;
         if (k >= nr_allpass) {
-            ap_out[t * 2]     = switched ? 0.0f : ap_in[t * 2];
-            ap_out[t * 2 + 1] = switched ? 0.0f : ap_in[t * 2 + 1];
+            const float a = SI.ld(t * 2, HEAAC_PS_APDELAY), b = SI.ld(t * 2, HEAAC_PS_APDELAY + 1);
+            SO.st(switched ? 0.0f : a, t * 2, HEAAC_PS_APDELAY);
+            SO.st(switched ? 0.0f : b, t * 2, HEAAC_PS_APDELAY + 1);
         }
     }
     wave_sync();
@@ -765,7 +768,7 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     {
         const int n = lane & 31, side = lane >> 5;
         const float *rows = side ? &w.subR[0][0] : &w.subL[0][0];
-        float *O0 = side ? XR0 : XL0, *O1 = side ? XR1 : XL1;
+        const int o0 = side * 2 * XP + n * 64, o1 = o0 + XP;
 #define SUBV(i, c) rows[(i) * SUB_STRIDE + 2 * n + (c)]
         if (is34) {
             const int first[5] = { 0, 12, 20, 24, 28 }, cnt[5] = { 12, 8, 4, 4, 4 };
@@ -773,16 +776,16 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
             for (int qq = 0; qq < 5; qq++) {
                 float re = 0.0f, im = 0.0f;
                 for (int i = 0; i < cnt[qq]; i++) { re += SUBV(first[qq] + i, 0); im += SUBV(first[qq] + i, 1); }
-                O0[n * 64 + qq] = re;
-                O1[n * 64 + qq] = im;
+                X.st(re, o0, qq);
+                X.st(im, o1, qq);
             }
         } else {
-            O0[n * 64 + 0] = SUBV(0, 0) + SUBV(1, 0) + SUBV(2, 0) + SUBV(3, 0) + SUBV(4, 0) + SUBV(5, 0);
-            O1[n * 64 + 0] = SUBV(0, 1) + SUBV(1, 1) + SUBV(2, 1) + SUBV(3, 1) + SUBV(4, 1) + SUBV(5, 1);
-            O0[n * 64 + 1] = SUBV(6, 0) + SUBV(7, 0);
-            O1[n * 64 + 1] = SUBV(6, 1) + SUBV(7, 1);
-            O0[n * 64 + 2] = SUBV(8, 0) + SUBV(9, 0);
-            O1[n * 64 + 2] = SUBV(8, 1) + SUBV(9, 1);
+            X.st(SUBV(0, 0) + SUBV(1, 0) + SUBV(2, 0) + SUBV(3, 0) + SUBV(4, 0) + SUBV(5, 0), o0, 0);
+            X.st(SUBV(0, 1) + SUBV(1, 1) + SUBV(2, 1) + SUBV(3, 1) + SUBV(4, 1) + SUBV(5, 1), o1, 0);
+            X.st(SUBV(6, 0) + SUBV(7, 0), o0, 1);
+            X.st(SUBV(6, 1) + SUBV(7, 1), o1, 1);
+            X.st(SUBV(8, 0) + SUBV(9, 0), o0, 2);
+            X.st(SUBV(8, 1) + SUBV(9, 1), o1, 2);
         }
 #undef SUBV
     }
@@ -818,7 +821,7 @@ void k_ps(const float *__restrict__ g_tab, const HeaacPsFrame *__restrict__ g_ps
         const int top = h.kx + h.m;                 // ff_ps_apply(..., sbr->kx[1] + sbr->m[1])
         float *XL = g_X + (f * 2) * (2 * 38 * 64);
         ps_frame<GENERAL>(W, g_tab, &g_ps[f], top, g_state_in + f * state_words + off_ps,
-                          g_state_out + f * state_words + off_ps, XL, XL + 2 * 38 * 64, lane, wave);
+                          g_state_out + f * state_words + off_ps, XL, lane, wave);
     }
 }
 
