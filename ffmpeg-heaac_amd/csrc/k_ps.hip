@@ -18,7 +18,7 @@ __device__ unsigned long long g_ps_stamps[16];
 #define STAMP(i) do {} while (0)
 #endif
 #ifndef PS_SCHED_GROUP
-#define PS_SCHED_GROUP 2
+#define PS_SCHED_GROUP 4
 #endif
 #define SUB_STRIDE 66          // one sub-subband row: 32 slots * (re,im) + 2 pad
 
@@ -227,8 +227,9 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
     float hre[14], him[14];
 #pragma unroll
     for (int j = HEAVY ? 0 : 13; j < 14; j++) {
-        const float a = SI.ld(kh * 2, HEAAC_PS_DELAY + j * dl_stride);
-        const float b = SI.ld(kh * 2, HEAAC_PS_DELAY + j * dl_stride + 1);
+        const int kv = opaque(kh * 8);
+        const float a = SI.ldb(kv, HEAAC_PS_DELAY + j * dl_stride);
+        const float b = SI.ldb(kv, HEAAC_PS_DELAY + j * dl_stride + 1);
         hre[j] = clear_state ? 0.0f : a;
         him[j] = clear_state ? 0.0f : b;
     }
@@ -250,8 +251,9 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
             qim[m] = g_tab[TB_QFRACT + ((is34 * 50 + kh) * 3 + m) * 2 + 1];
 #pragma unroll
             for (int j = 0; j < 5; j++) {
-                const float a = SI.ld(kh * 2, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride);
-                const float b = SI.ld(kh * 2, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride + 1);
+                const int kv = opaque(kh * 8);
+                const float a = SI.ldb(kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride);
+                const float b = SI.ldb(kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride + 1);
                 are[m][j] = clear_state ? 0.0f : a;
                 aim[m][j] = clear_state ? 0.0f : b;
             }
@@ -389,8 +391,9 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
             const float2 v = srow[18 + j];
             vr = is_sub ? v.x : vr; vi = is_sub ? v.y : vi;
         }
-        SO.st(vr, kh * 2, HEAAC_PS_DELAY + j * dl_stride);
-        SO.st(vi, kh * 2, HEAAC_PS_DELAY + j * dl_stride + 1);
+        const int kv = opaque(kh * 8);
+        SO.stb(vr, kv, HEAAC_PS_DELAY + j * dl_stride);
+        SO.stb(vi, kv, HEAAC_PS_DELAY + j * dl_stride + 1);
     }
     if (allpass) {
         // times 27..31 sit at ring positions (27 + j) % 5
@@ -398,8 +401,9 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
         for (int m = 0; m < 3; m++)
 #pragma unroll
             for (int j = 0; j < 5; j++) {
-                SO.st(are[m][(27 + j) % 5], kh * 2, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride);
-                SO.st(aim[m][(27 + j) % 5], kh * 2, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride + 1);
+                const int kv = opaque(kh * 8);
+                SO.stb(are[m][(27 + j) % 5], kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride);
+                SO.stb(aim[m][(27 + j) % 5], kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride + 1);
             }
     }
 }
