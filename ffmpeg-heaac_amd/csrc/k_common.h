@@ -110,6 +110,13 @@ constexpr SrSchedule sr_make(int bits)
 // ---------------------------------------------------------------------------
 struct cpx { float re, im; };
 
+// (re, im) in an aligned VGPR pair: v_pk_mul_f32 / v_pk_add_f32 issue at the rate of
+// the scalar forms on CDNA3/4, and broadcasts / swaps / sign flips ride on their op_sel
+// and neg modifiers.  Used where the data layout keeps pairs together end to end.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f bc(float s) { return v2f{s, s}; }
+__device__ __forceinline__ v2f rot90(v2f a) { return v2f{-a.y, a.x}; }     // multiplication by i
+
 // TRANSFORM(a0,a1,a2,a3,wre,wim) + BUTTERFLIES
 __device__ __forceinline__ void sr_transform(cpx &a0, cpx &a1, cpx &a2, cpx &a3,
                                              float wre, float wim)

@@ -200,7 +200,7 @@ __device__ __forceinline__ void hybrid_fir(const float *in, const float *filt, f
 // loop of stereo_processing (:900-969).
 //   HEAVY = true : any band (all-pass chain, 14-slot or 1-slot delay)
 //   HEAVY = false: bands >= 64 only, all of which use the 1-slot delay
-//   input  : QMF bands -- this lane's column cre/cim[32] (registers);
+//   input  : QMF bands -- this lane's column col[32] (register pairs);
 //            sub-subbands (is_sub) -- LDS row w.sub[kh]
 //   output : sub-subbands -> w.subL / w.subR rows; QMF column q -> X planes
 // Envelope borders are walked once in ascending order (border[0] = -1,
@@ -212,7 +212,7 @@ template <bool HEAVY, bool ALIGNED8, class W>
 __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, const signed char *kti,
                                         int is34, int kh, bool clear_state,
                                         const GBuf &SI, const GBuf &SO, const GBuf &X,
-                                        bool is_sub, int q, const float (&cre)[32], const float (&cim)[32])
+                                        bool is_sub, int q, const v2f (&col)[32])
 {
     constexpr int dl_stride = 91 * 2, ap_stride = 50 * 2;
     constexpr int XP = 38 * 64;                       // X record: [L, R][re, im][38][64]
@@ -221,25 +221,27 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
     const int enable_ipdopd = W::IS_GENERAL ? w.p.enable_ipdopd : 0;
     const bool allpass = HEAVY && kh < nr_allpass;
     const bool d14 = HEAVY && !allpass && kh < short_delay;
+    const v2f zero = {0.0f, 0.0f};
 
+    // Complex values live in (re, im) register pairs; the arithmetic below is the
+    // reference's, two products or sums per packed instruction.
     // Delay line: s[k][n - D] with D = 2 (all-pass input), 14 or 1: the lane's own column
     // for n >= D, before that the state tail hst[j] = s[k][j - 14].
-    float hre[14], him[14];
+    v2f hst[14];
 #pragma unroll
     for (int j = HEAVY ? 0 : 13; j < 14; j++) {
         const int kv = opaque(kh * 8);
-        const float a = SI.ldb(kv, HEAAC_PS_DELAY + j * dl_stride);
-        const float b = SI.ldb(kv, HEAAC_PS_DELAY + j * dl_stride + 1);
-        hre[j] = clear_state ? 0.0f : a;
-        him[j] = clear_state ? 0.0f : b;
+        const v2f t = { SI.ldb(kv, HEAAC_PS_DELAY + j * dl_stride), SI.ldb(kv, HEAAC_PS_DELAY + j * dl_stride + 1) };
+        hst[j] = clear_state ? zero : t;
     }
     // all-pass history: ring of 5 per link, position = time mod 5 (state j = time j - 5)
-    float are[3][5], aim[3][5];
-    float ag[3] = {0, 0, 0}, qre[3] = {0, 0, 0}, qim[3] = {0, 0, 0}, phre = 0.0f, phim = 0.0f;
+    v2f ring[3][5];
+    float ag[3] = {0, 0, 0};
+    v2f qf[3] = {zero, zero, zero}, qfi[3] = {zero, zero, zero}, ph = zero, phi = zero;
 #pragma unroll
     for (int m = 0; m < 3; m++)
 #pragma unroll
-        for (int j = 0; j < 5; j++) { are[m][j] = 0.0f; aim[m][j] = 0.0f; }
+        for (int j = 0; j < 5; j++) ring[m][j] = zero;
     if (allpass) {
         float g_decay_slope = 1.f - 0.05f * (kh - (is34 ? 32 : 10));
         g_decay_slope = g_decay_slope < 0.f ? 0.f : (g_decay_slope > 1.f ? 1.f : g_decay_slope);   // av_clipf
@@ -247,30 +249,33 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
 #pragma unroll
         for (int m = 0; m < 3; m++) {
             ag[m] = a[m] * g_decay_slope;
-            qre[m] = g_tab[TB_QFRACT + ((is34 * 50 + kh) * 3 + m) * 2];
-            qim[m] = g_tab[TB_QFRACT + ((is34 * 50 + kh) * 3 + m) * 2 + 1];
+            const float qre = g_tab[TB_QFRACT + ((is34 * 50 + kh) * 3 + m) * 2];
+            const float qim = g_tab[TB_QFRACT + ((is34 * 50 + kh) * 3 + m) * 2 + 1];
+            qf[m] = v2f{qre, qim};
+            qfi[m] = v2f{-qim, qre};                 // i * Q_fract
 #pragma unroll
             for (int j = 0; j < 5; j++) {
                 const int kv = opaque(kh * 8);
-                const float a = SI.ldb(kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride);
-                const float b = SI.ldb(kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride + 1);
-                are[m][j] = clear_state ? 0.0f : a;
-                aim[m][j] = clear_state ? 0.0f : b;
+                const v2f t = { SI.ldb(kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride),
+                                SI.ldb(kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride + 1) };
+                ring[m][j] = clear_state ? zero : t;
             }
         }
-        phre = g_tab[TB_PHIFRACT + (is34 * 50 + kh) * 2];
-        phim = g_tab[TB_PHIFRACT + (is34 * 50 + kh) * 2 + 1];
+        const float phre = g_tab[TB_PHIFRACT + (is34 * 50 + kh) * 2];
+        const float phim = g_tab[TB_PHIFRACT + (is34 * 50 + kh) * 2 + 1];
+        ph = v2f{phre, phim};
+        phi = v2f{-phim, phre};                      // i * phi_fract
     }
     const bool neg_im = (is34 && kh <= 13 && kh >= 9) || (!is34 && kh <= 1);
     const float *tgrow = w.pw[b];
-    const float2 *srow = reinterpret_cast<const float2 *>(w.sub[is_sub ? kh : 0]);
+    const v2f *srow = reinterpret_cast<const v2f *>(w.sub[is_sub ? kh : 0]);
     float *lrow = w.subL[is_sub ? kh : W::NSUB], *rrow = w.subR[is_sub ? kh : W::NSUB];   // row NSUB = scratch
     // column 0 of every row is rewritten by the hybrid synthesis at the end of the frame
     const int qs4 = is_sub ? 0 : q * 4;
 
-    float h11r = 0, h12r = 0, h21r = 0, h22r = 0, h11i = 0, h12i = 0, h21i = 0, h22i = 0;
-    float h11r_step = 0, h12r_step = 0, h21r_step = 0, h22r_step = 0;
-    float h11i_step = 0, h12i_step = 0, h21i_step = 0, h22i_step = 0;
+    // H11/H12 and H21/H22 share a pair each, so one packed add steps two of them
+    v2f hA = zero, hB = zero, hA_step = zero, hB_step = zero;        // (h11r, h12r), (h21r, h22r)
+    v2f hAi = zero, hBi = zero, hAi_step = zero, hBi_step = zero;    // imaginary parts (IPD/OPD)
     int e = -1, stop = -1;
 
     // Fully unrolled over the 32 slots: ring positions and column indices are static.
@@ -283,101 +288,76 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
             stop = __builtin_amdgcn_readfirstlane(w.p.border_position[e + 1]);
             const float width = 1.f / (stop - start);
             constexpr int R = W::IS_GENERAL ? 2 : 1;     // row step between H11, H12, H21, H22
-            h11r = w.Hs[e][0][b]; h12r = w.Hs[e][R][b]; h21r = w.Hs[e][2 * R][b]; h22r = w.Hs[e][3 * R][b];
-            h11r_step = (w.Hs[e + 1][0][b] - h11r) * width;
-            h12r_step = (w.Hs[e + 1][R][b] - h12r) * width;
-            h21r_step = (w.Hs[e + 1][2 * R][b] - h21r) * width;
-            h22r_step = (w.Hs[e + 1][3 * R][b] - h22r) * width;
+            hA = v2f{w.Hs[e][0][b], w.Hs[e][R][b]};
+            hB = v2f{w.Hs[e][2 * R][b], w.Hs[e][3 * R][b]};
+            hA_step = (v2f{w.Hs[e + 1][0][b], w.Hs[e + 1][R][b]} - hA) * bc(width);
+            hB_step = (v2f{w.Hs[e + 1][2 * R][b], w.Hs[e + 1][3 * R][b]} - hB) * bc(width);
             if constexpr (W::IS_GENERAL) if (enable_ipdopd) {
-                h11i = w.Hs[e][1][b]; h12i = w.Hs[e][3][b]; h21i = w.Hs[e][5][b]; h22i = w.Hs[e][7][b];
-                if (neg_im) { h11i = -h11i; h12i = -h12i; h21i = -h21i; h22i = -h22i; }
-                h11i_step = (w.Hs[e + 1][1][b] - h11i) * width;
-                h12i_step = (w.Hs[e + 1][3][b] - h12i) * width;
-                h21i_step = (w.Hs[e + 1][5][b] - h21i) * width;
-                h22i_step = (w.Hs[e + 1][7][b] - h22i) * width;
+                hAi = v2f{w.Hs[e][1][b], w.Hs[e][3][b]};
+                hBi = v2f{w.Hs[e][5][b], w.Hs[e][7][b]};
+                if (neg_im) { hAi = -hAi; hBi = -hBi; }
+                hAi_step = (v2f{w.Hs[e + 1][1][b], w.Hs[e + 1][3][b]} - hAi) * bc(width);
+                hBi_step = (v2f{w.Hs[e + 1][5][b], w.Hs[e + 1][7][b]} - hBi) * bc(width);
             }
         }
-        // current sample
-        float sre, sim;
+        // current sample and delayed sample s[k][n - D]
+        v2f sv, dv;
         if (HEAVY) {
-            const float2 sv = srow[n];                 // sub-subband lanes (others read row 0, unused)
-            sre = is_sub ? sv.x : cre[n];
-            sim = is_sub ? sv.y : cim[n];
+            const v2f subv = srow[n];                  // sub-subband lanes (others read row 0, unused)
+            sv = is_sub ? subv : col[n];
+            const v2f sub2 = srow[n >= 2 ? n - 2 : 0];            // sub-subbands are all-pass bands: D = 2
+            // state tail for the first slots (static register index per category)
+            const v2f ap_d = n >= 2 ? (is_sub ? sub2 : col[n >= 2 ? n - 2 : 0]) : hst[12 + (n < 2 ? n : 0)];
+            const v2f d14_d = n >= 14 ? col[n >= 14 ? n - 14 : 0] : hst[n < 14 ? n : 0];
+            const v2f d1_d = n >= 1 ? col[n >= 1 ? n - 1 : 0] : hst[13];
+            dv = allpass ? ap_d : d14 ? d14_d : d1_d;
         } else {
-            sre = cre[n]; sim = cim[n];
+            sv = col[n];
+            dv = n >= 1 ? col[n >= 1 ? n - 1 : 0] : hst[13];
         }
         const float tg = tgrow[n];
-        // delayed sample s[k][n - D]
-        float dre, dim;
-        if (HEAVY) {
-            const float2 dv = srow[n >= 2 ? n - 2 : 0];            // sub-subbands are all-pass bands: D = 2
-            const float r2 = cre[n >= 2 ? n - 2 : 0],   i2 = cim[n >= 2 ? n - 2 : 0];
-            const float r14 = cre[n >= 14 ? n - 14 : 0], i14 = cim[n >= 14 ? n - 14 : 0];
-            const float r1 = cre[n >= 1 ? n - 1 : 0],   i1 = cim[n >= 1 ? n - 1 : 0];
-            // state tail for the first slots (static register index per category)
-            const float t2r = n < 2 ? hre[12 + (n < 2 ? n : 0)] : 0.0f, t2i = n < 2 ? him[12 + (n < 2 ? n : 0)] : 0.0f;
-            const float t14r = n < 14 ? hre[n < 14 ? n : 0] : 0.0f,     t14i = n < 14 ? him[n < 14 ? n : 0] : 0.0f;
-            const float t1r = n < 1 ? hre[13] : 0.0f,                   t1i = n < 1 ? him[13] : 0.0f;
-            const float ap_r = n >= 2 ? (is_sub ? dv.x : r2) : t2r, ap_i = n >= 2 ? (is_sub ? dv.y : i2) : t2i;
-            const float d14r = n >= 14 ? r14 : t14r,                d14i = n >= 14 ? i14 : t14i;
-            const float d1r = n >= 1 ? r1 : t1r,                    d1i = n >= 1 ? i1 : t1i;
-            dre = allpass ? ap_r : d14 ? d14r : d1r;
-            dim = allpass ? ap_i : d14 ? d14i : d1i;
-        } else {
-            dre = n >= 1 ? cre[n >= 1 ? n - 1 : 0] : hre[13];
-            dim = n >= 1 ? cim[n >= 1 ? n - 1 : 0] : him[13];
-        }
-        float r_re, r_im;
+        v2f rv;
         if (HEAVY) {
             // all-pass chain, computed by every lane (no branch inside the slot);
             // lanes that are plain delays keep the delayed sample instead
-            float in_re = dre * phre - dim * phim;
-            float in_im = dre * phim + dim * phre;
+            v2f x = bc(dv.x) * ph + bc(dv.y) * phi;            // (d.re ph.re - d.im ph.im, d.re ph.im + d.im ph.re)
 #pragma unroll
             for (int m = 0; m < 3; m++) {
-                const float a_re = ag[m] * in_re, a_im = ag[m] * in_im;
+                const v2f a = bc(ag[m]) * x;
                 // link_delay = 3, 4, 5: value written at time n - delay
                 const int rp = (n + 5 - (3 + m)) % 5, wp = n % 5;
-                const float ld_re = are[m][rp], ld_im = aim[m][rp];
-                float nre = in_re, nim = in_im;
-                in_re = ld_re * qre[m] - ld_im * qim[m] - a_re;
-                in_im = ld_re * qim[m] + ld_im * qre[m] - a_im;
-                nre += ag[m] * in_re;
-                nim += ag[m] * in_im;
-                are[m][wp] = nre; aim[m][wp] = nim;
+                const v2f ld = ring[m][rp];
+                v2f nx = x;
+                x = (bc(ld.x) * qf[m] + bc(ld.y) * qfi[m]) - a;
+                nx += bc(ag[m]) * x;
+                ring[m][wp] = nx;
             }
-            r_re = tg * (allpass ? in_re : dre);
-            r_im = tg * (allpass ? in_im : dim);
+            rv = bc(tg) * (allpass ? x : dv);
         } else {
-            r_re = tg * dre;
-            r_im = tg * dim;
+            rv = bc(tg) * dv;
         }
 
-        h11r += h11r_step; h12r += h12r_step; h21r += h21r_step; h22r += h22r_step;
-        float lre, lim, rre, rim;
+        hA += hA_step; hB += hB_step;
+        // l = h11 s + h21 r,  r = h12 s + h22 r   (complex h only with IPD/OPD)
+        v2f lv = bc(hA.x) * sv + bc(hB.x) * rv;
+        v2f rr = bc(hA.y) * sv + bc(hB.y) * rv;
         if (enable_ipdopd) {
-            h11i += h11i_step; h12i += h12i_step; h21i += h21i_step; h22i += h22i_step;
-            lre = h11r * sre + h21r * r_re - h11i * sim - h21i * r_im;
-            lim = h11r * sim + h21r * r_im + h11i * sre + h21i * r_re;
-            rre = h12r * sre + h22r * r_re - h12i * sim - h22i * r_im;
-            rim = h12r * sim + h22r * r_im + h12i * sre + h22i * r_re;
-        } else {
-            lre = h11r * sre + h21r * r_re;
-            lim = h11r * sim + h21r * r_im;
-            rre = h12r * sre + h22r * r_re;
-            rim = h12r * sim + h22r * r_im;
+            hAi += hAi_step; hBi += hBi_step;
+            const v2f si = rot90(sv), ri = rot90(rv);            // (-im, re)
+            lv = (lv + bc(hAi.x) * si) + bc(hBi.x) * ri;
+            rr = (rr + bc(hAi.y) * si) + bc(hBi.y) * ri;
         }
         // Branch-free stores: sub-subband lanes keep L/R in LDS rows (hybrid synthesis sums
         // them later) and send their global store to column 0, which the hybrid synthesis
         // rewrites afterwards; QMF lanes store to X and send their LDS store to a scratch row.
         if (HEAVY) {
-            *reinterpret_cast<float2 *>(lrow + 2 * n) = make_float2(lre, lim);
-            *reinterpret_cast<float2 *>(rrow + 2 * n) = make_float2(rre, rim);
+            *reinterpret_cast<v2f *>(lrow + 2 * n) = lv;
+            *reinterpret_cast<v2f *>(rrow + 2 * n) = rr;
         }
         {
             const int qb = opaque(qs4);
-            X.stb(lre, qb, n * 64);          X.stb(lim, qb, XP + n * 64);
-            X.stb(rre, qb, 2 * XP + n * 64); X.stb(rim, qb, 3 * XP + n * 64);
+            X.stb(lv.x, qb, n * 64);          X.stb(lv.y, qb, XP + n * 64);
+            X.stb(rr.x, qb, 2 * XP + n * 64); X.stb(rr.y, qb, 3 * XP + n * 64);
         }
         // bound the scheduler's look-ahead: without it the 32 unrolled slots are
         // interleaved until the register file overflows
@@ -386,14 +366,14 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
     // new delay-line tail = s[k][18..31]
 #pragma unroll
     for (int j = 0; j < 14; j++) {
-        float vr = cre[18 + j], vi = cim[18 + j];
+        v2f v = col[18 + j];
         if (HEAVY) {
-            const float2 v = srow[18 + j];
-            vr = is_sub ? v.x : vr; vi = is_sub ? v.y : vi;
+            const v2f t = srow[18 + j];
+            v = is_sub ? t : v;
         }
         const int kv = opaque(kh * 8);
-        SO.stb(vr, kv, HEAAC_PS_DELAY + j * dl_stride);
-        SO.stb(vi, kv, HEAAC_PS_DELAY + j * dl_stride + 1);
+        SO.stb(v.x, kv, HEAAC_PS_DELAY + j * dl_stride);
+        SO.stb(v.y, kv, HEAAC_PS_DELAY + j * dl_stride + 1);
     }
     if (allpass) {
         // times 27..31 sit at ring positions (27 + j) % 5
@@ -402,8 +382,8 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
 #pragma unroll
             for (int j = 0; j < 5; j++) {
                 const int kv = opaque(kh * 8);
-                SO.stb(are[m][(27 + j) % 5], kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride);
-                SO.stb(aim[m][(27 + j) % 5], kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride + 1);
+                SO.stb(ring[m][(27 + j) % 5].x, kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride);
+                SO.stb(ring[m][(27 + j) % 5].y, kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride + 1);
             }
     }
 }
@@ -451,8 +431,12 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
                                          const HeaacPsFrame *g_p, int top_qmf,
                                          const float *st_in, float *st_out,
                                          float *Xrec /* [2][2][38][64]: in: mono in [0], out: left, right */,
-                                         int lane, int wave = 0)
+                                         int lane_in, int wave = 0)
 {
+    // `lane` is redefined opaquely at every phase: values derived from it (LDS addresses,
+    // band indices) then live for one phase instead of being hoisted out of the frame loop
+    // into registers that end up spilled.
+    int lane = opaque(lane_in);
     using WT = PsWaveT<GENERAL>;
     constexpr int XP = 38 * 64;
     const GBuf SI(st_in), SO(st_out), X(Xrec);
@@ -487,21 +471,21 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     // lanes [nsub, 64)       : q = lane - nsub + nlow   hybrid index kh = lane (pass 1)
     const int P2 = nr_bands - 64;
     const int q_own = lane < P2 ? 64 - P2 + lane : lane < nsub ? lane - P2 : lane - nsub + nlow;
-    float cre[32], cim[32];
+    v2f col[32];
 #pragma unroll
     for (int n = 0; n < 32; n++) {
         const int qb = opaque(q_own * 4);
-        cre[n] = X.ldb(qb, n * 64); cim[n] = X.ldb(qb, XP + n * 64);
+        col[n] = v2f{X.ldb(qb, n * 64), X.ldb(qb, XP + n * 64)};
     }
     {
         const int kh_own = lane >= nsub ? lane : 64 + lane;      // valid unless P2 <= lane < nsub
         if (lane >= nsub || lane < P2) {
 #pragma unroll
-            for (int n = 0; n < 32; n++) w.pn[n * WT::PNS + kh_own] = cre[n] * cre[n] + cim[n] * cim[n];
+            for (int n = 0; n < 32; n++) w.pn[n * WT::PNS + kh_own] = col[n].x * col[n].x + col[n].y * col[n].y;
         } else {
             // hybrid analysis input (aacps.c:362-367): in[i][j+6] = L[.][j][i]
 #pragma unroll
-            for (int n = 0; n < 32; n++) { w.inb[q_own][n + 6][0] = cre[n]; w.inb[q_own][n + 6][1] = cim[n]; }
+            for (int n = 0; n < 32; n++) { w.inb[q_own][n + 6][0] = col[n].x; w.inb[q_own][n + 6][1] = col[n].y; }
         }
     }
     for (int t = lane; t < nlow * 6; t += WAVE) {
@@ -514,6 +498,7 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     }
     wave_sync();
     STAMP(1);
+    lane = opaque(lane);
     // in_buf update (:391-394): in[i][0..5] <- in[i][32..37] = L[.][26..31][i], all 5 bands
     for (int t = lane; t < 5 * 6; t += WAVE) {
         const int i = t / 6, j = t % 6;
@@ -569,6 +554,7 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     wave_sync();
 
     STAMP(2);
+    lane = opaque(lane);
     // ---- band power (aacps.c:673-678): members of each parameter band in ascending
     // hybrid-band order.  The member lists are compile-time constants, so the sums
     // unroll into straight-line LDS reads; two half-waves split the parameter bands.
@@ -583,6 +569,7 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     }
     wave_sync();
     STAMP(3);
+    lane = opaque(lane);
     // ---- transient detection (:681-692), one lane per parameter band ----
     if (lane < nr_par) {
         const int i = lane;
@@ -614,6 +601,7 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     }
 
     STAMP(4);
+    lane = opaque(lane);
     // ---- parameter remapping + H matrices (aacps.c:817-899) ----
     for (int t = lane; t < 5 * WT::NPAR; t += WAVE) {
         const int e = t / WT::NPAR, b = t % WT::NPAR;
@@ -719,6 +707,7 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     }
 
     STAMP(5);
+    lane = opaque(lane);
     // every border at 8k - 1 (what frame_class 0 produces): fast straight-line variant
     bool aligned8 = true;
     for (int e = 1; e <= p.num_env; e++) aligned8 = aligned8 && ((p.border_position[e] & 7) == 7);
@@ -729,23 +718,25 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
         const bool is_sub = kh < nsub;
         if (aligned8)
             ps_band<true, true>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X,
-                                 is_sub, kh - nsub + nlow, cre, cim);
+                                 is_sub, kh - nsub + nlow, col);
         else
             ps_band<true, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X,
-                                 is_sub, kh - nsub + nlow, cre, cim);
+                                 is_sub, kh - nsub + nlow, col);
     }
     STAMP(6);
+    lane = opaque(lane);
     // ---- pass 2: hybrid bands 64.. (all use the one-slot delay) ----
     if (lane < nr_bands - 64) {
         const int kh = 64 + lane;
         if (aligned8)
             ps_band<false, true>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X,
-                                 false, kh - nsub + nlow, cre, cim);
+                                 false, kh - nsub + nlow, col);
         else
             ps_band<false, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X,
-                                 false, kh - nsub + nlow, cre, cim);
+                                 false, kh - nsub + nlow, col);
     }
     STAMP(7);
+    lane = opaque(lane);
     // bands that exist in the state record but not in this layout / all-pass set
     if (st_out != st_in || switched)
     for (int t = lane; t < 14 * 91; t += WAVE) {
@@ -768,6 +759,7 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     wave_sync();
 
     STAMP(8);
+    lane = opaque(lane);
     // ---- hybrid synthesis (aacps.c:397-445) for the lowest QMF bands ----
     {
         const int n = lane & 31, side = lane >> 5;

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 pkg = g.load_package(); synth = importlib.import_module("ffmpeg_heaac_amd.synth")
-cfg = pkg.CFG_HEV2; n = 2560
+cfg = pkg.CFG_HEV2; n = int(os.environ.get("N", 2560))
 hdr = synth.default_headers(pkg); rng = np.random.default_rng(1)
 dev = pkg.Device(n)
 frames = list(synth.he_stream(rng, cfg, 256, 3, hdr))
