@@ -14,31 +14,11 @@
 // chunks), so the intermediates do not travel to HBM.
 //
 // Reference line numbers are libavcodec/aacsbr.c and aacps.c.
+#include <stdlib.h>
 #include "k_core.h"
 #include "kernels.h"
 
-#define ENV_ADJ 2          // ENVELOPE_ADJUSTMENT_OFFSET, aacsbr.c:39
-
-#ifdef HF_STAMPS
-__device__ unsigned long long g_hf_stamps[16];
-#define HSTAMP(i) do { wave_sync(); if (lane == 0 && blockIdx.x == 7 && threadIdx.x < 64) g_hf_stamps[i] = __builtin_readcyclecounter(); } while (0)
-#else
-#define HSTAMP(i) do {} while (0)
-#endif
-
-// exp2f(twice / 2.0f) for integer `twice`: exact powers of two, or sqrt(2)
-// (0x3FB504F3, what glibc's exp2f(0.5f) returns) times a power of two.
-// sbr_dequant's arguments are always multiples of 0.5 (aacsbr.c:1099-1125).
-__device__ __forceinline__ float exp2_half(int twice)
-{
-    // outside the normal range (never reached by legal scalefactors): saturate
-    // like exp2f does; the denormal side is rounded once more than libm's
-    if (twice > 255) return __uint_as_float(0x7F800000u);
-    if (twice < -252) return twice < -400 ? 0.0f : exp2_half(twice + 256) * 2.938735877055719e-39f; // 2^-128
-    const int e = twice >> 1;
-    const unsigned mant = (twice & 1) ? 0x3FB504F3u : 0x3F800000u;
-    return __uint_as_float(mant + ((unsigned)e << 23));
-}
+#include "k_hf.h"
 
 // ===========================================================================
 // K_A  core + QMF analysis
@@ -146,641 +126,27 @@ void k_core_ana(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_
     }
 }
 
-// ===========================================================================
-// K_B  HF generation + envelope adjustment + x_gen, one wave per SBR channel
-// ===========================================================================
-// Lane = QMF band k (m = k - kx for the SBR range).  Everything that is per band
-// and per envelope (mapped scalefactors, estimated envelope, gains) lives in that
-// lane's registers; the only cross-lane steps are the limiter-band sums of
-// sbr_gain_calc, which go through small LDS arrays in the reference's order.
-#define HF_WAVES 8
-#define XL_STRIDE 81              // X_low row: 40 slots * (re,im) + 1 pad (bank spread)
-#define MAXM 48                   // e_origmapped[7][48] etc. in the reference (sbr.h:165-177)
-#define MAXE 5
-
-struct HfWave {
-    float xlow[32 * XL_STRIDE];   // X_low[k][i][re,im]
-    float alpha0[32][2], alpha1[32][2];
-    float bw[8];
-    float sumA[MAXE][MAXM], sumB[MAXE][MAXM];     // per-band terms of the limiter-band sums
-    float bandv[MAXE][32];                        // gain_max / gain_boost per (envelope, limiter band)
-    HeaacSbrHeader h;
-    HeaacSbrChannel c[2];
-};
-
-__device__ __forceinline__ void lds_copy_bytes(void *dst, const void *src, int bytes, int lane)
-{
-    // bytes % 4 == 0, both 4-byte aligned
-    const uint32_t *s = reinterpret_cast<const uint32_t *>(src);
-    uint32_t *d = reinterpret_cast<uint32_t *>(dst);
-    for (int i = lane; i < bytes / 4; i += WAVE) d[i] = s[i];
-}
-
-// sbr_dequant (aacsbr.c:1089-1128) for one envelope scalefactor of channel ch.
-__device__ __forceinline__ float deq_env(const HfWave &w, int coupling, int ch, int e, int i)
-{
-    if (coupling) {
-        const int amp = w.c[0].bs_amp_res;
-        const int q0 = w.c[0].env_facs_q[e][i], q1 = w.c[1].env_facs_q[e][i];
-        // temp1 = exp2f(q0*alpha + 7), temp2 = exp2f((pan_offset - q1)*alpha)
-        const float temp1 = exp2_half(amp ? 2 * q0 + 14 : q0 + 14);
-        const float temp2 = exp2_half(amp ? 2 * (12 - q1) : 24 - q1);
-        const float fac = temp1 / (1.0f + temp2);
-        return ch ? fac * temp2 : fac;
-    }
-    const int amp = w.c[ch].bs_amp_res;
-    const int q = w.c[ch].env_facs_q[e][i];
-    return exp2_half((amp ? 2 * q : q) + 12);            // exp2f(alpha*q + 6)
-}
-
-__device__ __forceinline__ float deq_noise(const HfWave &w, int coupling, int ch, int e, int i)
-{
-    if (coupling) {
-        const int q0 = w.c[0].noise_facs_q[e][i], q1 = w.c[1].noise_facs_q[e][i];
-        const float temp1 = exp2_half(2 * (7 - q0));      // exp2f(NOISE_FLOOR_OFFSET - q0 + 1)
-        const float temp2 = exp2_half(2 * (12 - q1));     // exp2f(12 - q1)
-        const float fac = temp1 / (1.0f + temp2);
-        return ch ? fac * temp2 : fac;
-    }
-    return exp2_half(2 * (6 - (int)w.c[ch].noise_facs_q[e][i]));   // exp2f(6 - q)
-}
-
-#define FFMIN_(a, b) ((a) > (b) ? (b) : (a))
-
-// X_high[k][idx] from three consecutive X_low samples of the patch source band
-// (sbr_hf_gen, aacsbr.c:1388-1402); x2 = X_low[p][idx-2], x1 = [idx-1], x0 = [idx].
-__device__ __forceinline__ void xhigh3(float2 x2, float2 x1, float2 x0, const float *a, float &re, float &im)
-{
-    re = x2.x * a[0] - x2.y * a[1] + x1.x * a[2] - x1.y * a[3] + x0.x;
-    im = x2.y * a[0] + x2.x * a[1] + x1.y * a[2] + x1.x * a[3] + x0.y;
-}
-
-__device__ __forceinline__ void hf_channel(HfWave &w, const float *g_noise /* LDS */,
-                                           const HeaacSbrFrame *g_fr, const HeaacSbrHeader *g_hdr,
-                                           int ch, const float *g_W,
-                                           const float *st_in, float *st_out,
-                                           float *g_X /* [2][38][64] */, int lane)
-{
-    HSTAMP(0);
-    // ---- issue every global load up front: parameters, W, state ----
-    const int hdr_idx = g_fr->hdr;
-    // channel records (2 x 336 B = 168 dwords) and the header (532 B = 133 dwords):
-    // all loads issued before any LDS store
-    uint32_t creg[3], hreg[3];
-    {
-        const uint32_t *cs = reinterpret_cast<const uint32_t *>(&g_fr->ch[0]);
-        const uint32_t *hs_ = reinterpret_cast<const uint32_t *>(&g_hdr[hdr_idx]);
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            creg[r] = lane + 64 * r < 168 ? cs[lane + 64 * r] : 0;
-            hreg[r] = lane + 64 * r < 133 ? hs_[lane + 64 * r] : 0;
-        }
-    }
-    const int start = g_fr->start, reset = g_fr->reset;
-    const int kx_old = g_fr->kx_old, m_old = g_fr->m_old;
-    const int coupling = g_fr->bs_coupling;
-    float2 wreg[16], treg[4];
-    {
-        const float2 *W2 = reinterpret_cast<const float2 *>(g_W);
-        const float2 *T2 = reinterpret_cast<const float2 *>(st_in + HEAAC_SBR_WTAIL);
-#pragma unroll
-        for (int r = 0; r < 16; r++) wreg[r] = W2[lane + 64 * r];
-#pragma unroll
-        for (int r = 0; r < 4; r++) treg[r] = T2[lane + 64 * r];
-    }
-    const int k = lane;                                  // this lane's QMF band
-    float ghist[4], qhist[4];                            // g_temp / q_temp history rows of band m
-    unsigned idxnoise = __float_as_uint(st_in[HEAAC_SBR_IDXNOISE]);
-    unsigned idxsine  = __float_as_uint(st_in[HEAAC_SBR_IDXSINE]);
-    const float bw_in = lane < 5 ? st_in[HEAAC_SBR_BW + lane] : 0.0f;
-    {
-        uint32_t *cd = reinterpret_cast<uint32_t *>(&w.c[0]);
-        uint32_t *hd = reinterpret_cast<uint32_t *>(&w.h);
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            if (lane + 64 * r < 168) cd[lane + 64 * r] = creg[r];
-            if (lane + 64 * r < 133) hd[lane + 64 * r] = hreg[r];
-        }
-    }
-    wave_sync();
-    const HeaacSbrHeader &h = w.h;
-    const HeaacSbrChannel &c = w.c[ch];
-    const int kx = h.kx, m_max = h.m, n_q = h.n_q;
-    const int m = k - kx;
-    const bool in_sbr = m >= 0 && m < m_max && m < MAXM;
-    const int num_env = c.bs_num_env;
-    const int t0 = c.t_env[0], tL = c.t_env[num_env];
-    const int h_SL = 4 * !h.bs_smoothing_mode;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        ghist[j] = in_sbr ? st_in[HEAAC_SBR_GTAIL + j * MAXM + m] : 0.0f;
-        qhist[j] = in_sbr ? st_in[HEAAC_SBR_QTAIL + j * MAXM + m] : 0.0f;
-    }
-    const int sidx0 = in_sbr ? reinterpret_cast<const uint8_t *>(st_in + HEAAC_SBR_SIDX)[m] : 0;
-    if (reset) idxnoise = 0;                     // sbr_make_f_derived, :587-588
-
-    HSTAMP(1);
-    // ---- sbr_lf_gen (:1337-1357): W -> X_low, previous tail for slots 0..7 ----
-    {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int t = lane + 64 * r, i = t >> 5, kk = t & 31;
-            float2 v = wreg[r];
-            if (kk >= kx) v = make_float2(0.0f, 0.0f);
-            float *d = w.xlow + kk * XL_STRIDE + 2 * (i + 8);
-            d[0] = v.x; d[1] = v.y;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int t = lane + 64 * r, i = t >> 5, kk = t & 31;
-            float2 v = treg[r];
-            if (kk >= kx_old) v = make_float2(0.0f, 0.0f);
-            float *d = w.xlow + kk * XL_STRIDE + 2 * i;
-            d[0] = v.x; d[1] = v.y;
-        }
-        // new tail = W[1][24..31]: registers 12..15 hold slots 24..31
-        float2 *To = reinterpret_cast<float2 *>(st_out + HEAAC_SBR_WTAIL);
-#pragma unroll
-        for (int r = 0; r < 4; r++) To[lane + 64 * r] = wreg[12 + r];
-    }
-    if (lane < 8) w.bw[lane] = bw_in;
-    wave_sync();
-
-    // per-lane registers of the envelope adjuster
-    float e_orig[MAXE], q_map[MAXE], e_curr[MAXE], gain[MAXE], q_m[MAXE], s_m[MAXE];
-    int sidx[MAXE];                               // s_indexmapped[e + 1][m]
-    unsigned smap = 0;                            // bit e: s_mapped[e][m]
-    float kc[4] = { 0, 0, 0, 0 };                 // hf_gen alpha[0..3]
-#pragma unroll
-    for (int e = 0; e < MAXE; e++) { e_orig[e] = q_map[e] = e_curr[e] = gain[e] = q_m[e] = s_m[e] = 0.0f; sidx[e] = 0; }
-    // X_low row this lane reads: its own band below kx, the patch source above
-    const int p_src = in_sbr ? (int)h.map_src[k] : 0xff;
-    const bool has_src = p_src < 32;
-    const int row = k < kx ? (k < 32 ? k : 0) : (has_src ? p_src : 0);
-    const float2 *xr = reinterpret_cast<const float2 *>(0);   // (unaligned rows: read as two floats)
-    (void)xr;
-    const float *xrow = w.xlow + row * XL_STRIDE;
-
-    if (start) {
-        HSTAMP(2);
-        // ---- sbr_hf_inverse_filter (:1261-1313) + autocorrelate (:1232-1255) ----
-        if (lane < h.k0 && lane < 32) {
-            // the whole row first (all LDS reads in flight), then the five running sums
-            float x[80];
-            const float *xs = w.xlow + lane * XL_STRIDE;
-#pragma unroll
-            for (int i = 0; i < 80; i++) x[i] = xs[i];
-            float r0 = 0.0f, r1 = 0.0f, i1 = 0.0f, r2 = 0.0f, i2 = 0.0f;
-#pragma unroll
-            for (int i = 1; i < 38; i++) {
-                const float a = x[2 * i], b = x[2 * i + 1];
-                r0 += a * a + b * b;
-                r1 += a * x[2 * i + 2] + b * x[2 * i + 3];
-                i1 += a * x[2 * i + 3] - b * x[2 * i + 2];
-                r2 += a * x[2 * i + 4] + b * x[2 * i + 5];
-                i2 += a * x[2 * i + 5] - b * x[2 * i + 4];
-            }
-            const float p210 = r0 + x[0] * x[0] + x[1] * x[1];
-            const float p100 = r0 + x[76] * x[76] + x[77] * x[77];
-            const float p110 = r1 + x[0] * x[2] + x[1] * x[3];
-            const float p111 = i1 + x[0] * x[3] - x[1] * x[2];
-            const float p000 = r1 + x[76] * x[78] + x[77] * x[79];
-            const float p001 = i1 + x[76] * x[79] - x[77] * x[78];
-            const float p010 = r2 + x[0] * x[4] + x[1] * x[5];
-            const float p011 = i2 + x[0] * x[5] - x[1] * x[4];
-
-            const float dk = p210 * p100 - (p110 * p110 + p111 * p111) / 1.000001f;
-            float a1r, a1i, a0r, a0i;
-            if (!dk) {
-                a1r = 0; a1i = 0;
-            } else {
-                const float tr = p000 * p110 - p001 * p111 - p010 * p100;
-                const float ti = p000 * p111 + p001 * p110 - p011 * p100;
-                a1r = tr / dk;
-                a1i = ti / dk;
-            }
-            if (!p100) {
-                a0r = 0; a0i = 0;
-            } else {
-                const float tr = p000 + a1r * p110 + a1i * p111;
-                const float ti = p001 + a1i * p110 - a1r * p111;
-                a0r = -tr / p100;
-                a0i = -ti / p100;
-            }
-            if (a1r * a1r + a1i * a1i >= 16.0f || a0r * a0r + a0i * a0i >= 16.0f) {
-                a1r = 0; a1i = 0; a0r = 0; a0i = 0;
-            }
-            w.alpha0[lane][0] = a0r; w.alpha0[lane][1] = a0i;
-            w.alpha1[lane][0] = a1r; w.alpha1[lane][1] = a1i;
-        }
-        HSTAMP(3);
-        // ---- sbr_chirp (:1316-1334) ----
-        if (lane < n_q) {
-            const int m0 = c.bs_invf_mode[0][lane], m1 = c.bs_invf_mode[1][lane];
-            float new_bw;
-            if (m0 + m1 == 1) new_bw = 0.6f;
-            else new_bw = m0 == 0 ? 0.0f : m0 == 1 ? 0.75f : m0 == 2 ? 0.9f : 0.98f;
-            const float old = w.bw[lane];
-            if (new_bw < old) new_bw = 0.75f    * new_bw + 0.25f    * old;
-            else              new_bw = 0.90625f * new_bw + 0.09375f * old;
-            w.bw[lane] = new_bw < 0.015625f ? 0.0f : new_bw;
-        }
-        wave_sync();
-
-        HSTAMP(4);
-        // ---- per-band constants of sbr_hf_gen (:1369-1386) ----
-        if (has_src) {
-            const int g = h.map_nq[k];
-            const float b = w.bw[g < 5 ? g : 0];
-            kc[0] = w.alpha1[p_src][0] * b * b;
-            kc[1] = w.alpha1[p_src][1] * b * b;
-            kc[2] = w.alpha0[p_src][0] * b;
-            kc[3] = w.alpha0[p_src][1] * b;
-        }
-
-        HSTAMP(5);
-        // ---- sbr_mapping (:1451-1496) ----
-        if (in_sbr) {
-            const int hi = h.map_hi[k], lo = h.map_lo[k], nq = h.map_nq[k], mid = h.map_mid[k];
-#pragma unroll
-            for (int e = 0; e < MAXE; e++) {
-                if (e < num_env) {
-                    const int res = c.bs_freq_res[e + 1];
-                    e_orig[e] = deq_env(w, coupling, ch, e, res ? hi : lo);
-                    const int kq = (c.bs_num_noise > 1) && (c.t_env[e] >= c.t_q[1]);
-                    q_map[e] = deq_noise(w, coupling, ch, kq, nq);
-                    if (c.bs_add_harmonic_flag && mid != 0xff)
-                        sidx[e] = c.bs_add_harmonic[mid] * (e >= c.e_a[1] || (sidx0 == 1));
-                }
-            }
-        }
-        // s_mapped[e][m]: any sinusoid inside the band of the envelope's resolution (:1479-1491)
-#pragma unroll
-        for (int e = 0; e < MAXE; e++) {
-            if (e < num_env) {
-                const unsigned long long present = __ballot(sidx[e] != 0);      // bit = lane = band k
-                if (in_sbr) {
-                    const int res = c.bs_freq_res[e + 1];
-                    const uint8_t *table = res ? h.f_tablehigh : h.f_tablelow;
-                    const int bi = res ? h.map_hi[k] : h.map_lo[k];
-                    const int lo_k = table[bi], hi_k = table[bi + 1];               // [lo_k, hi_k)
-                    const unsigned long long mask = (hi_k >= 64 ? ~0ull : ((1ull << hi_k) - 1)) & ~((1ull << lo_k) - 1);
-                    if (present & mask) smap |= 1u << e;
-                }
-            }
-        }
-
-        HSTAMP(6);
-        // ---- sbr_env_estimate (:1499-1546) ----
-        if (h.bs_interpol_freq) {
-            if (in_sbr) {
-#pragma unroll
-                for (int e = 0; e < MAXE; e++) {
-                    if (e < num_env) {
-                        const float recip_env_size = 0.5f / (c.t_env[e + 1] - c.t_env[e]);
-                        const int ilb = c.t_env[e] * 2 + ENV_ADJ, iub = c.t_env[e + 1] * 2 + ENV_ADJ;
-                        float sum = 0.0f;
-                        if (has_src) {
-                            float2 x2 = make_float2(xrow[2 * (ilb - 2)], xrow[2 * (ilb - 2) + 1]);
-                            float2 x1 = make_float2(xrow[2 * (ilb - 1)], xrow[2 * (ilb - 1) + 1]);
-                            for (int i = ilb; i < iub; i++) {
-                                const float2 x0 = make_float2(xrow[2 * i], xrow[2 * i + 1]);
-                                float re, im;
-                                xhigh3(x2, x1, x0, kc, re, im);
-                                sum += re * re + im * im;
-                                x2 = x1; x1 = x0;
-                            }
-                        } else {
-                            for (int i = ilb; i < iub; i++) sum += 0.0f * 0.0f + 0.0f * 0.0f;
-                        }
-                        e_curr[e] = sum * recip_env_size;
-                    }
-                }
-            }
-        } else {
-            // one lane per band of the envelope's frequency table; result broadcast through LDS
-#pragma unroll
-            for (int e = 0; e < MAXE; e++) {
-                if (e < num_env) {
-                    const int res = c.bs_freq_res[e + 1];
-                    const uint8_t *table = res ? h.f_tablehigh : h.f_tablelow;
-                    const int env_size = 2 * (c.t_env[e + 1] - c.t_env[e]);
-                    const int ilb = c.t_env[e] * 2 + ENV_ADJ, iub = c.t_env[e + 1] * 2 + ENV_ADJ;
-                    if (lane < h.n[res]) {
-                        float sum = 0.0f;
-                        const int den = env_size * (table[lane + 1] - table[lane]);
-                        for (int kk = table[lane]; kk < table[lane + 1]; kk++) {
-                            const int ps = h.map_src[kk];
-                            float a[4] = { 0, 0, 0, 0 };
-                            if (ps < 32) {
-                                const int g = h.map_nq[kk];
-                                const float b = w.bw[g < 5 ? g : 0];
-                                a[0] = w.alpha1[ps][0] * b * b; a[1] = w.alpha1[ps][1] * b * b;
-                                a[2] = w.alpha0[ps][0] * b;     a[3] = w.alpha0[ps][1] * b;
-                            }
-                            const float *xs = w.xlow + (ps < 32 ? ps : 0) * XL_STRIDE;
-                            for (int i = ilb; i < iub; i++) {
-                                float re = 0.0f, im = 0.0f;
-                                if (ps < 32)
-                                    xhigh3(make_float2(xs[2 * i - 4], xs[2 * i - 3]), make_float2(xs[2 * i - 2], xs[2 * i - 1]),
-                                           make_float2(xs[2 * i], xs[2 * i + 1]), a, re, im);
-                                sum += re * re + im * im;
-                            }
-                        }
-                        sum /= den;
-                        for (int kk = table[lane]; kk < table[lane + 1]; kk++)
-                            if (kk - kx < MAXM) w.sumA[e][kk - kx] = sum;
-                    }
-                }
-            }
-            wave_sync();
-            if (in_sbr) {
-#pragma unroll
-                for (int e = 0; e < MAXE; e++)
-                    if (e < num_env) e_curr[e] = w.sumA[e][m];
-            }
-            wave_sync();
-        }
-
-        HSTAMP(7);
-        // ---- sbr_gain_calc (:1552-1605) ----
-        // elementwise parts per lane, limiter-band sums by one lane per (envelope, band)
-        const int lim = in_sbr ? (int)h.map_lim[k] : 0xff;
-        const bool limited = lim != 0xff;
-        const float limgain = h.bs_limiter_gains == 0 ? 0.70795f :
-                              h.bs_limiter_gains == 1 ? 1.0f :
-                              h.bs_limiter_gains == 2 ? 1.41254f : 10000000000.0f;
-        const int n_lim = h.n_lim;
-#pragma unroll
-        for (int e = 0; e < MAXE; e++) {
-            if (e < num_env && limited) {
-                const int delta = !((e == c.e_a[1]) || (e == c.e_a[0]));
-                const float eo = e_orig[e], qm = q_map[e], ec = e_curr[e];
-                const float temp = eo / (1.0f + qm);
-                q_m[e] = sqrtf(temp * qm);
-                s_m[e] = sqrtf(temp * (float)sidx[e]);
-                if (!((smap >> e) & 1))
-                    gain[e] = sqrtf(eo / ((1.0f + ec) * (1.0f + qm * (float)delta)));
-                else
-                    gain[e] = sqrtf(eo * qm / ((1.0f + ec) * (1.0f + qm)));
-                w.sumA[e][m] = eo;
-                w.sumB[e][m] = ec;
-            }
-        }
-        wave_sync();
-        for (int t = lane; t < num_env * n_lim; t += WAVE) {
-            const int e = t / n_lim, kk = t - e * n_lim;
-            const int ma = h.f_tablelim[kk] - kx, mb = h.f_tablelim[kk + 1] - kx;
-            float sum0 = 0.0f, sum1 = 0.0f;
-            for (int mm = ma; mm < mb; mm++) {
-                sum0 += w.sumA[e][mm];
-                sum1 += w.sumB[e][mm];
-            }
-            float gain_max = limgain * sqrtf((1.1920928955078125e-7f + sum0) / (1.1920928955078125e-7f + sum1));
-            gain_max = FFMIN_(100000.0f, gain_max);
-            w.bandv[e][kk] = gain_max;
-        }
-        wave_sync();
-#pragma unroll
-        for (int e = 0; e < MAXE; e++) {
-            if (e < num_env && limited) {
-                const int delta = !((e == c.e_a[1]) || (e == c.e_a[0]));
-                const float gain_max = w.bandv[e][lim];
-                const float q_m_max = q_m[e] * gain_max / gain[e];
-                q_m[e]  = FFMIN_(q_m[e], q_m_max);
-                gain[e] = FFMIN_(gain[e], gain_max);
-                // term of the second sum[1] (:1590-1594); sumA still holds e_origmapped
-                w.sumB[e][m] = e_curr[e] * gain[e] * gain[e]
-                               + s_m[e] * s_m[e]
-                               + (float)(delta && !s_m[e]) * q_m[e] * q_m[e];
-            }
-        }
-        wave_sync();
-        for (int t = lane; t < num_env * n_lim; t += WAVE) {
-            const int e = t / n_lim, kk = t - e * n_lim;
-            const int ma = h.f_tablelim[kk] - kx, mb = h.f_tablelim[kk + 1] - kx;
-            float sum0 = 0.0f, sum1 = 0.0f;
-            for (int mm = ma; mm < mb; mm++) {
-                sum0 += w.sumA[e][mm];
-                sum1 += w.sumB[e][mm];
-            }
-            float gain_boost = sqrtf((1.1920928955078125e-7f + sum0) / (1.1920928955078125e-7f + sum1));
-            // FFMIN(1.584893192, gain_boost) is evaluated in double (:1597)
-            gain_boost = (float)(1.584893192 > (double)gain_boost ? (double)gain_boost : 1.584893192);
-            w.bandv[e][kk] = gain_boost;
-        }
-        wave_sync();
-#pragma unroll
-        for (int e = 0; e < MAXE; e++) {
-            if (e < num_env && limited) {
-                const float gain_boost = w.bandv[e][lim];
-                gain[e] *= gain_boost;
-                q_m[e]  *= gain_boost;
-                s_m[e]  *= gain_boost;
-            }
-        }
-        // history rows for the smoothing filter (:1630-1639)
-        if (reset) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) { ghist[j] = gain[0]; qhist[j] = q_m[0]; }
-        }
-    }
-
-    HSTAMP(8);
-    // ---- sbr_hf_assemble (:1608-1714) fused with sbr_x_gen (:1412-1446) ----
-    const int t_old = c.t_env_num_env_old;
-    const int i_Temp = 2 * t_old - 32 > 0 ? 2 * t_old - 32 : 0;
-    const float *ytail_in = st_in + HEAAC_SBR_YTAIL;
-    float *ytail_out = st_out + HEAAC_SBR_YTAIL;
-    float *X0 = g_X, *X1 = g_X + 38 * 64;
-    {
-        const bool hf = start && in_sbr;
-        const float hs[5] = { 0.33333333333333f, 0.30150283239582f, 0.21816949906249f,
-                              0.11516383427084f, 0.03183050093751f };
-        const int phi_sign0 = (1 - 2 * (kx & 1)) * ((m & 1) ? -1 : 1);
-        // g_temp / q_temp rows r = slot + h_SL kept as a ring of 5 (position r % 5);
-        // rows 2 t0 .. 2 t0 + 3 hold the history, row slot + 4 the slot's own gain
-        float gr[5] = { 0, 0, 0, 0, 0 }, qr[5] = { 0, 0, 0, 0, 0 };
-        // current envelope (uniform): advanced at even slots = 2 * t_env[e + 1]
-        int e = 0, next_border = 2 * c.t_env[1];
-        float g_e = gain[0], q_e = q_m[0], s_e = s_m[0];
-        bool plain = (0 == c.e_a[0]) || (0 == c.e_a[1]);
-        // sliding window of X_low of the source row
-        float2 x2 = make_float2(xrow[0], xrow[1]), x1 = make_float2(xrow[2], xrow[3]);
-
-#pragma unroll
-        for (int i = 0; i < 38; i++) {
-            const float2 x0 = make_float2(xrow[2 * (i + ENV_ADJ)], xrow[2 * (i + ENV_ADJ) + 1]);
-            if ((i & 1) == 0 && i <= 6 && i == 2 * t0 && h_SL) {
-                // seed the ring with the four history rows (:1630-1639)
-#pragma unroll
-                for (int j = 0; j < 4; j++) { gr[(i + j) % 5] = ghist[j]; qr[(i + j) % 5] = qhist[j]; }
-            }
-            if ((i & 1) == 0 && i > 0 && i == next_border && e + 1 < num_env) {
-                e++;
-                next_border = 2 * c.t_env[e + 1];
-                // per-envelope values of this lane (static select: e is uniform)
-                g_e = e == 1 ? gain[1] : e == 2 ? gain[2] : e == 3 ? gain[3] : gain[4];
-                q_e = e == 1 ? q_m[1] : e == 2 ? q_m[2] : e == 3 ? q_m[3] : q_m[4];
-                s_e = e == 1 ? s_m[1] : e == 2 ? s_m[2] : e == 3 ? s_m[3] : s_m[4];
-                plain = (e == c.e_a[0]) || (e == c.e_a[1]);
-            }
-            float yr = 0.0f, yi = 0.0f;
-            const bool have_y = hf && i >= 2 * t0 && i < 2 * tL;
-            if (have_y) {
-                float xr_, xi_;
-                if (has_src) xhigh3(x2, x1, x0, kc, xr_, xi_); else { xr_ = 0.0f; xi_ = 0.0f; }
-                gr[(i + 4) % 5] = g_e;
-                qr[(i + 4) % 5] = q_e;
-                float g_filt;
-                if (h_SL && !plain) {
-                    g_filt = 0.0f;
-#pragma unroll
-                    for (int j = 0; j < 5; j++) g_filt += gr[(i + 4 - j) % 5] * hs[j];
-                } else {
-                    g_filt = h_SL ? g_e : g_e;       // g_temp[i + h_SL][m] = this slot's gain
-                }
-                yr = xr_ * g_filt;
-                yi = xi_ * g_filt;
-                const int slot = i - 2 * t0;
-                const int isine = (idxsine + slot) & 3;
-                const int phi_re = isine == 0 ? 1 : isine == 2 ? -1 : 0;
-                const int phi_im = isine == 1 ? 1 : isine == 3 ? -1 : 0;
-                if (!plain) {
-                    if (s_e) {
-                        yr += s_e * (float)phi_re;
-                        yi += s_e * (float)(phi_im * phi_sign0);
-                    } else {
-                        float q_filt;
-                        if (h_SL) {
-                            q_filt = 0.0f;
-#pragma unroll
-                            for (int j = 0; j < 5; j++) q_filt += qr[(i + 4 - j) % 5] * hs[j];
-                        } else {
-                            q_filt = q_e;              // q_temp[i][m], h_SL == 0
-                        }
-                        const unsigned in = (idxnoise + (unsigned)slot * m_max + m + 1) & 0x1ff;
-                        yr += q_filt * g_noise[2 * in];
-                        yi += q_filt * g_noise[2 * in + 1];
-                    }
-                } else {
-                    yr += s_e * (float)phi_re;
-                    yi += s_e * (float)(phi_im * phi_sign0);
-                }
-            }
-            // ytail: Y[1][32..37]
-            if (i >= 32) {
-                const int o = ((i - 32) * 64 + k) * 2;
-                if (have_y) { ytail_out[o] = yr; ytail_out[o + 1] = yi; }
-                else if (ytail_out != ytail_in) { ytail_out[o] = ytail_in[o]; ytail_out[o + 1] = ytail_in[o + 1]; }
-            }
-            // x_gen
-            float xo_r = 0.0f, xo_i = 0.0f;
-            if (i < 6 && i < i_Temp) {
-                if (k < kx_old) {
-                    if (k < 32) { xo_r = w.xlow[k * XL_STRIDE + 2 * (i + ENV_ADJ)]; xo_i = w.xlow[k * XL_STRIDE + 2 * (i + ENV_ADJ) + 1]; }
-                } else if (k < kx_old + m_old) {
-                    xo_r = ytail_in[(i * 64 + k) * 2]; xo_i = ytail_in[(i * 64 + k) * 2 + 1];
-                }
-            } else {
-                if (k < kx) {
-                    if (k < 32) { xo_r = x0.x; xo_i = x0.y; }
-                } else if (k < kx + m_max && i < 32) {
-                    xo_r = yr; xo_i = yi;
-                }
-            }
-            X0[i * 64 + k] = xo_r;
-            X1[i * 64 + k] = xo_i;
-            x2 = x1; x1 = x0;
-        }
-    }
-
-    HSTAMP(9);
-    // ---- remaining state ----
-    if (start) {
-        if (lane < 5) st_out[HEAAC_SBR_BW + lane] = w.bw[lane];
-        if (lane == 0) {
-            const unsigned slots = 2 * (tL - t0);
-            st_out[HEAAC_SBR_IDXNOISE] = __uint_as_float((idxnoise + slots * m_max) & 0x1ff);
-            st_out[HEAAC_SBR_IDXSINE]  = __uint_as_float((idxsine + slots) & 3);
-        }
-        // s_indexmapped[0] <- s_indexmapped[bs_num_env]  (bytes, one per band m < 48)
-        {
-            int v = 0;
-#pragma unroll
-            for (int e = 0; e < MAXE; e++) if (e == num_env - 1) v = sidx[e];
-            // gather the byte of band m = lane (not k): shuffle from lane kx + m
-            const int src_lane = kx + lane;
-            const int byte = __shfl(v, src_lane < 64 ? src_lane : 0);
-            const int valid = lane < MAXM && src_lane < 64 && lane < m_max;
-            const int b0 = valid ? (byte & 0xff) : 0;
-            // pack 4 bytes per dword via shuffles
-            const int p0 = __shfl(b0, (lane & 15) * 4 + 0 < 64 ? (lane & 15) * 4 + 0 : 0);
-            const int p1 = __shfl(b0, (lane & 15) * 4 + 1 < 64 ? (lane & 15) * 4 + 1 : 0);
-            const int p2 = __shfl(b0, (lane & 15) * 4 + 2 < 64 ? (lane & 15) * 4 + 2 : 0);
-            const int p3 = __shfl(b0, (lane & 15) * 4 + 3 < 64 ? (lane & 15) * 4 + 3 : 0);
-            if (lane < 12)
-                reinterpret_cast<uint32_t *>(st_out + HEAAC_SBR_SIDX)[lane] =
-                    (uint32_t)p0 | ((uint32_t)p1 << 8) | ((uint32_t)p2 << 16) | ((uint32_t)p3 << 24);
-        }
-        if (h_SL) {
-            // rows 2 tL + j: the gains of slots 2 tL - 4 + j
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int slot = 2 * tL - 4 + j;
-                int ee = 0;
-                for (int q = 1; q < num_env; q++)
-                    if (slot >= 2 * c.t_env[q]) ee = q;
-                float g = 0.0f, q = 0.0f;
-#pragma unroll
-                for (int e2 = 0; e2 < MAXE; e2++) if (e2 == ee) { g = gain[e2]; q = q_m[e2]; }
-                if (m >= 0 && m < MAXM) {
-                    st_out[HEAAC_SBR_GTAIL + j * MAXM + m] = in_sbr ? g : 0.0f;
-                    st_out[HEAAC_SBR_QTAIL + j * MAXM + m] = in_sbr ? q : 0.0f;
-                }
-            }
-            // bands m that no lane covers (kx + m >= 64) are beyond m_max: zero
-            if (lane < MAXM && kx + lane >= 64) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    st_out[HEAAC_SBR_GTAIL + j * MAXM + lane] = 0.0f;
-                    st_out[HEAAC_SBR_QTAIL + j * MAXM + lane] = 0.0f;
-                }
-            }
-        } else if (st_out != st_in) {
-            for (int t = lane; t < 4 * MAXM; t += WAVE) {
-                st_out[HEAAC_SBR_GTAIL + t] = st_in[HEAAC_SBR_GTAIL + t];
-                st_out[HEAAC_SBR_QTAIL + t] = st_in[HEAAC_SBR_QTAIL + t];
-            }
-        }
-    } else if (st_out != st_in) {
-        for (int t = HEAAC_SBR_GTAIL + lane; t < HEAAC_ST_SBR; t += WAVE)
-            st_out[t] = st_in[t];
-    }
-    if (lane == 0 && st_out != st_in) st_out[HEAAC_SBR_PAD] = st_in[HEAAC_SBR_PAD];
-    wave_sync();
-    HSTAMP(10);
-}
-
 __global__ __launch_bounds__(HF_WAVES * WAVE)
 void k_hfadj(const float *__restrict__ g_tab,
              const HeaacSbrFrame *__restrict__ g_sbr, const HeaacSbrHeader *__restrict__ g_hdr,
              const float *g_W, const float *g_state_in, float *g_state_out, int state_words,
              int ncore, int off_sbr0, float *g_X, unsigned long long n_units)
 {
-    __shared__ HfWave S[HF_WAVES];
+    __shared__ float s_xlow[HF_WAVES][HF_XLOW_WORDS], s_aux[HF_WAVES][HF_AUX_WORDS], s_rec[HF_WAVES][HF_REC_WORDS];
     __shared__ float s_noise[1024];              // sbr_noise_table, staged once per workgroup
     wg_copy_f4(s_noise, g_tab + TB_NOISE, 1024);
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
+    const HfWave S = hf_wave_view(s_xlow[wave], s_aux[wave], s_rec[wave]);
     for (unsigned long long u = (unsigned long long)blockIdx.x * HF_WAVES + wave; u < n_units;
          u += (unsigned long long)gridDim.x * HF_WAVES) {
         const unsigned long long f = u / ncore;
         const int ch = (int)(u - f * ncore);
         const int off = off_sbr0 + ch * HEAAC_ST_SBR;
-        hf_channel(S[wave], s_noise, &g_sbr[f], g_hdr, ch, g_W + u * 2048,
-                   g_state_in + f * state_words + off, g_state_out + f * state_words + off,
-                   g_X + (f * 2 + ch) * (2 * 38 * 64), lane);
+        float *X0 = g_X + (f * 2 + ch) * (2 * 38 * 64), *X1 = X0 + 38 * 64;
+        hf_channel(S, s_noise, &g_sbr[f], g_hdr, ch, g_W + u * 2048,
+                   g_state_in + f * state_words + off, g_state_out + f * state_words + off, lane,
+                   [&](int i, float re, float im) { X0[i * 64 + lane] = re; X1[i * 64 + lane] = im; });
     }
 }
 
@@ -987,6 +353,13 @@ static int he_grid(unsigned long long units, int per_block)
     return (int)g;
 }
 
+// HEAAC_HE_UNFUSED=1 keeps the HF and PS stages in separate kernels (A/B measurements)
+static bool he_fused()
+{
+    static const bool fused = []() { const char *e = getenv("HEAAC_HE_UNFUSED"); return !(e && e[0] == '1'); }();
+    return fused;
+}
+
 extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cfg,
                                const float *d_coeffs, const HeaacIcs *d_ics,
                                const HeaacSbrFrame *d_sbr, const HeaacSbrHeader *d_hdr,
@@ -1013,14 +386,25 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
     hipLaunchKernelGGL(k_core_ana, dim3(he_grid(units, ANA_WAVES)), dim3(ANA_WAVES * WAVE), 0, s,
                        d_tab, d_rev, d_coeffs, d_ics, d_state_in, d_state_out, words, ncore,
                        off_saved0, off_sbr0, d_ws_W, 1 / (-1024 * sf_scale), units);
-    hipLaunchKernelGGL(k_hfadj, dim3(he_grid(units, HF_WAVES)), dim3(HF_WAVES * WAVE), 0, s,
-                       d_tab, d_sbr, d_hdr, d_ws_W, d_state_in, d_state_out, words, ncore, off_sbr0,
-                       d_ws_X, units);
     int copy_mono = 0;
-    if (cfg == HEAAC_CFG_HEV2) {
-        int rc = heaac_launch_ps(d_tab, d_ps, d_sbr, d_hdr, d_state_in, d_state_out, words,
-                                 off_syn0 + 2 * HEAAC_ST_SYNTH, d_ws_X, n, s);
+    if (cfg == HEAAC_CFG_HEV2 && he_fused()) {
+        // HF adjustment + baseline PS in one kernel; the general PS kernel finishes the
+        // frames with another PS layout (it skips the rest)
+        const int off_ps = off_syn0 + 2 * HEAAC_ST_SYNTH;
+        int rc = heaac_launch_hfps(d_tab, d_sbr, d_hdr, d_ps, d_ws_W, d_state_in, d_state_out, words,
+                                   off_sbr0, off_ps, d_ws_X, n, s);
         if (rc != HEAAC_OK) return rc;
+        rc = heaac_launch_ps(d_tab, d_ps, d_sbr, d_hdr, d_state_in, d_state_out, words, off_ps, d_ws_X, n, 2, s);
+        if (rc != HEAAC_OK) return rc;
+    } else {
+        hipLaunchKernelGGL(k_hfadj, dim3(he_grid(units, HF_WAVES)), dim3(HF_WAVES * WAVE), 0, s,
+                           d_tab, d_sbr, d_hdr, d_ws_W, d_state_in, d_state_out, words, ncore, off_sbr0,
+                           d_ws_X, units);
+        if (cfg == HEAAC_CFG_HEV2) {
+            int rc = heaac_launch_ps(d_tab, d_ps, d_sbr, d_hdr, d_state_in, d_state_out, words,
+                                     off_syn0 + 2 * HEAAC_ST_SYNTH, d_ws_X, n, 3, s);
+            if (rc != HEAAC_OK) return rc;
+        }
     }
     const float scale = -1024 * sf_scale, bias = HEAAC_ADD_BIAS;
     const dim3 g(he_grid(n, SYN_WAVES)), b(SYN_WAVES * WAVE);

@@ -11,783 +11,8 @@
 #include "k_common.h"
 #include "kernels.h"
 
-#ifdef PS_STAMPS
-__device__ unsigned long long g_ps_stamps[16];
-#define STAMP(i) do { wave_sync(); if (lane == 0 && blockIdx.x == 7 && wave == 0) g_ps_stamps[i] = __builtin_readcyclecounter(); } while (0)
-#else
-#define STAMP(i) do {} while (0)
-#endif
-#ifndef PS_SCHED_GROUP
-#define PS_SCHED_GROUP 4
-#endif
-#define SUB_STRIDE 66          // one sub-subband row: 32 slots * (re,im) + 2 pad
-
-// Table 8.48 / 8.49 of ISO/IEC 14496-3 (aacpsdata.c:145-158): hybrid band -> parameter band
-struct KtoI { signed char v[91]; };
-constexpr KtoI k_to_i_20_c = {{
-     1,  0,  0,  1,  2,  3,  4,  5,  6,  7,  8,  9, 10, 11, 12, 13, 14, 14, 15,
-    15, 15, 16, 16, 16, 16, 17, 17, 17, 17, 17, 18, 18, 18, 18, 18, 18, 18, 18,
-    18, 18, 18, 18, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19,
-    19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19 }};
-constexpr KtoI k_to_i_34_c = {{
-     0,  1,  2,  3,  4,  5,  6,  6,  7,  2,  1,  0, 10, 10,  4,  5,  6,  7,  8,
-     9, 10, 11, 12,  9, 14, 11, 12, 13, 14, 15, 16, 13, 16, 17, 18, 19, 20, 21,
-    22, 22, 23, 23, 24, 24, 25, 25, 26, 26, 27, 27, 27, 28, 28, 28, 29, 29, 29,
-    30, 30, 30, 31, 31, 31, 31, 32, 32, 32, 32, 33, 33, 33, 33, 33, 33, 33, 33,
-    33, 33, 33, 33, 33, 33, 33, 33, 33, 33, 33, 33, 33, 33, 33 }};
-
-// Members of every parameter band in ascending hybrid-band order: the order in
-// which decorrelation() accumulates power[i][n] (aacps.c:673-678).
-struct BandMembers {
-    signed char kti[92];
-    unsigned char order[92];      // hybrid bands sorted by (parameter band, k)
-    unsigned char first[36];      // first[i] .. first[i+1]: members of band i
-    int split;                    // bands [0,split) and [split,nr_par) hold about half the members each
-};
-constexpr BandMembers make_members(const KtoI &t, int nr_bands, int nr_par)
-{
-    BandMembers m{};
-    int pos = 0;
-    for (int k = 0; k < nr_bands; k++) m.kti[k] = t.v[k];
-    for (int i = 0; i < nr_par; i++) {
-        m.first[i] = (unsigned char)pos;
-        for (int k = 0; k < nr_bands; k++)
-            if (t.v[k] == i) m.order[pos++] = (unsigned char)k;
-    }
-    m.first[nr_par] = (unsigned char)pos;
-    m.split = nr_par;
-    for (int i = 0; i <= nr_par; i++)
-        if (2 * m.first[i] >= pos) { m.split = i; break; }
-    return m;
-}
-__device__ constexpr BandMembers kMem20 = make_members(k_to_i_20_c, 71, 20);
-__device__ constexpr BandMembers kMem34 = make_members(k_to_i_34_c, 91, 34);
-
-// Per-wave LDS.  GENERAL = false: baseline PS -- frames that are and were 20-band with
-// IPD/OPD off (what HE-AACv2 encoders emit) -- small enough for 8 waves per CU.  GENERAL = true: any
-// layout, including 20 <-> 34 switches.
-template <bool GENERAL>
-struct PsWaveT {
-    static constexpr int NSUB = GENERAL ? 32 : 10;
-    static constexpr int NLOW = GENERAL ? 5 : 3;
-    static constexpr int NB = GENERAL ? 91 : 71;
-    static constexpr int NPAR = GENERAL ? 34 : 20;
-    static constexpr bool IS_GENERAL = GENERAL;
-    static constexpr int NH = GENERAL ? 8 : 4;      // H rows kept: re+im, or re only (IPD/OPD off)
-    static constexpr int PNS = NB + 1;              // |s|^2 row stride (72 / 92 floats)
-    // scratch shared by |s|^2 (until the band powers are formed) and the mixed
-    // sub-subband outputs (written afterwards): max of the two, in floats
-    static constexpr int SCR = (32 * PNS > 2 * (NSUB + 1) * SUB_STRIDE) ? 32 * PNS : 2 * (NSUB + 1) * SUB_STRIDE;
-    // Views of separate __shared__ arrays (distinct objects for the alias analysis).
-    HeaacPsFrame &p;
-    float (*inb)[44][2];               // [NLOW] hybrid analysis input: 6 history + 38 current slots
-    float *pn;                         // [32][PNS] |s|^2 per slot and hybrid band
-    float (*sub)[SUB_STRIDE];          // [NSUB] sub-subband signals s[ks][n] (re,im interleaved)
-    float (*subL)[SUB_STRIDE];         // [NSUB + 1] mixed sub-subband outputs (alias pn's memory)
-    float (*subR)[SUB_STRIDE];
-    float (*pw)[33];                   // [NPAR] band power, then transient gain
-    float (*Hs)[NH][NPAR];             // [6]    H11,H12,H21,H22 (re[,im]) rows per envelope border
-    signed char (*iid_m)[NPAR], (*icc_m)[NPAR], (*ipd_m)[NPAR], (*opd_m)[NPAR];   // [5]
-};
-
-// map_idx_* (aacps.c:461-643) as a gather: mapped value of band b.
-__device__ __forceinline__ int remap_idx(const signed char *par, int num_par, int to34, int b)
-{
-    if (to34) {
-        if (num_par == 20 || num_par == 11) {
-            // map_idx_20_to_34
-            const signed char src[34] = { 0, -1, 1, 2, -2, 3, 4, 4, 5, 5, 6, 7, 8, 8, 9, 9, 10,
-                                          11, 12, 13, 14, 14, 15, 15, 16, 16, 17, 17, 18, 18, 18, 18, 19, 19 };
-            const int s = src[b];
-            if (s == -1) return (par[0] + par[1]) / 2;
-            if (s == -2) return (par[2] + par[3]) / 2;
-            return par[s];
-        }
-        if (num_par == 10 || num_par == 5) {
-            const signed char src[34] = { 0, 0, 0, 1, 1, 1, 2, 2, 2, 2, 3, 3, 4, 4, 4, 4, 5, 5, 6, 6,
-                                          7, 7, 7, 7, 8, 8, 8, 8, 9, 9, 9, 9, 9, 9 };
-            if (num_par == 5 && b >= 16) return 0;            // full == 0: par_mapped[16] = 0
-            return par[src[b]];
-        }
-        return par[b];
-    }
-    if (num_par == 34 || num_par == 17) {
-        // map_idx_34_to_20
-        switch (b) {
-        case 0:  return (2 * par[0] + par[1]) / 3;
-        case 1:  return (par[1] + 2 * par[2]) / 3;
-        case 2:  return (2 * par[3] + par[4]) / 3;
-        case 3:  return (par[4] + 2 * par[5]) / 3;
-        case 4:  return (par[6] + par[7]) / 2;
-        case 5:  return (par[8] + par[9]) / 2;
-        case 6:  return par[10];
-        case 7:  return par[11];
-        case 8:  return (par[12] + par[13]) / 2;
-        case 9:  return (par[14] + par[15]) / 2;
-        case 10: return par[16];
-        case 11: return par[17];
-        case 12: return par[18];
-        case 13: return par[19];
-        case 14: return (par[20] + par[21]) / 2;
-        case 15: return (par[22] + par[23]) / 2;
-        case 16: return (par[24] + par[25]) / 2;
-        case 17: return (par[26] + par[27]) / 2;
-        case 18: return (par[28] + par[29] + par[30] + par[31]) / 4;
-        case 19: return (par[32] + par[33]) / 2;
-        }
-        return 0;
-    }
-    if (num_par == 10 || num_par == 5) {
-        if (num_par == 5 && b >= 10) return 0;                // full == 0: par_mapped[10] = 0
-        return par[b >> 1];
-    }
-    return par[b];
-}
-
-// map_val_20_to_34 / map_val_34_to_20 (aacps.c:491-514, 598-634) as gathers.
-__device__ __forceinline__ float remap_val(const float *par, int to34, int b)
-{
-    if (to34) {
-        const signed char src[34] = { 0, -1, 1, 2, -2, 3, 4, 4, 5, 5, 6, 7, 8, 8, 9, 9, 10,
-                                      11, 12, 13, 14, 14, 15, 15, 16, 16, 17, 17, 18, 18, 18, 18, 19, 19 };
-        const int s = src[b];
-        if (s == -1) return (par[0] + par[1]) * 0.5f;
-        if (s == -2) return (par[2] + par[3]) * 0.5f;
-        return par[s];
-    }
-    switch (b) {
-    case 0:  return (2 * par[0] + par[1]) * 0.33333333f;
-    case 1:  return (par[1] + 2 * par[2]) * 0.33333333f;
-    case 2:  return (2 * par[3] + par[4]) * 0.33333333f;
-    case 3:  return (par[4] + 2 * par[5]) * 0.33333333f;
-    case 4:  return (par[6] + par[7]) * 0.5f;
-    case 5:  return (par[8] + par[9]) * 0.5f;
-    case 6:  return par[10];
-    case 7:  return par[11];
-    case 8:  return (par[12] + par[13]) * 0.5f;
-    case 9:  return (par[14] + par[15]) * 0.5f;
-    case 10: return par[16];
-    case 11: return par[17];
-    case 12: return par[18];
-    case 13: return par[19];
-    case 14: return (par[20] + par[21]) * 0.5f;
-    case 15: return (par[22] + par[23]) * 0.5f;
-    case 16: return (par[24] + par[25]) * 0.5f;
-    case 17: return (par[26] + par[27]) * 0.5f;
-    case 18: return (par[28] + par[29] + par[30] + par[31]) * 0.25f;
-    case 19: return (par[32] + par[33]) * 0.5f;
-    }
-    return par[b];          // 34 -> 20 leaves par[20..33] untouched
-}
-
-// 13-tap complex FIR of hybrid6_cx / hybrid4_8_12_cx (aacps.c:310-321, :343-353).
-// in: 13 consecutive complex slots, filt: [7][2]
-__device__ __forceinline__ void hybrid_fir(const float *in, const float *filt, float &o_re, float &o_im)
-{
-    float sum_re = filt[12] * in[12], sum_im = filt[12] * in[13];
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-        const float in0_re = in[2 * j], in0_im = in[2 * j + 1];
-        const float in1_re = in[2 * (12 - j)], in1_im = in[2 * (12 - j) + 1];
-        sum_re += filt[2 * j] * (in0_re + in1_re) - filt[2 * j + 1] * (in0_im - in1_im);
-        sum_im += filt[2 * j] * (in0_im + in1_im) + filt[2 * j + 1] * (in0_re - in1_re);
-    }
-    o_re = sum_re;
-    o_im = sum_im;
-}
-
-// One band, all 32 slots: decorrelation (aacps.c:696-753) fused with the mixing
-// loop of stereo_processing (:900-969).
-//   HEAVY = true : any band (all-pass chain, 14-slot or 1-slot delay)
-//   HEAVY = false: bands >= 64 only, all of which use the 1-slot delay
-//   input  : QMF bands -- this lane's column col[32] (register pairs);
-//            sub-subbands (is_sub) -- LDS row w.sub[kh]
-//   output : sub-subbands -> w.subL / w.subR rows; QMF column q -> X planes
-// Envelope borders are walked once in ascending order (border[0] = -1,
-// border[num_env] = 31, monotonic: what ff_ps_read_data produces).
-// ALIGNED8: every border is 8k - 1 (frame_class 0, aacps.c:203-205), so the H
-// interpolation can only restart at slots 0, 8, 16, 24 and the unrolled slot code in
-// between is one straight-line block.
-template <bool HEAVY, bool ALIGNED8, class W>
-__device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, const signed char *kti,
-                                        int is34, int kh, bool clear_state,
-                                        const GBuf &SI, const GBuf &SO, const GBuf &X,
-                                        bool is_sub, int q, const v2f (&col)[32])
-{
-    constexpr int dl_stride = 91 * 2, ap_stride = 50 * 2;
-    constexpr int XP = 38 * 64;                       // X record: [L, R][re, im][38][64]
-    const int nr_allpass = is34 ? 50 : 30, short_delay = is34 ? 62 : 42;
-    const int b = kti[kh];
-    const int enable_ipdopd = W::IS_GENERAL ? w.p.enable_ipdopd : 0;
-    const bool allpass = HEAVY && kh < nr_allpass;
-    const bool d14 = HEAVY && !allpass && kh < short_delay;
-    const v2f zero = {0.0f, 0.0f};
-
-    // Complex values live in (re, im) register pairs; the arithmetic below is the
-    // reference's, two products or sums per packed instruction.
-    // Delay line: s[k][n - D] with D = 2 (all-pass input), 14 or 1: the lane's own column
-    // for n >= D, before that the state tail hst[j] = s[k][j - 14].
-    v2f hst[14];
-#pragma unroll
-    for (int j = HEAVY ? 0 : 13; j < 14; j++) {
-        const int kv = opaque(kh * 8);
-        const v2f t = { SI.ldb(kv, HEAAC_PS_DELAY + j * dl_stride), SI.ldb(kv, HEAAC_PS_DELAY + j * dl_stride + 1) };
-        hst[j] = clear_state ? zero : t;
-    }
-    // all-pass history: ring of 5 per link, position = time mod 5 (state j = time j - 5)
-    v2f ring[3][5];
-    float ag[3] = {0, 0, 0};
-    v2f qf[3] = {zero, zero, zero}, qfi[3] = {zero, zero, zero}, ph = zero, phi = zero;
-#pragma unroll
-    for (int m = 0; m < 3; m++)
-#pragma unroll
-        for (int j = 0; j < 5; j++) ring[m][j] = zero;
-    if (allpass) {
-        float g_decay_slope = 1.f - 0.05f * (kh - (is34 ? 32 : 10));
-        g_decay_slope = g_decay_slope < 0.f ? 0.f : (g_decay_slope > 1.f ? 1.f : g_decay_slope);   // av_clipf
-        const float a[3] = { 0.65143905753106f, 0.56471812200776f, 0.48954165955695f };
-#pragma unroll
-        for (int m = 0; m < 3; m++) {
-            ag[m] = a[m] * g_decay_slope;
-            const float qre = g_tab[TB_QFRACT + ((is34 * 50 + kh) * 3 + m) * 2];
-            const float qim = g_tab[TB_QFRACT + ((is34 * 50 + kh) * 3 + m) * 2 + 1];
-            qf[m] = v2f{qre, qim};
-            qfi[m] = v2f{-qim, qre};                 // i * Q_fract
-#pragma unroll
-            for (int j = 0; j < 5; j++) {
-                const int kv = opaque(kh * 8);
-                const v2f t = { SI.ldb(kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride),
-                                SI.ldb(kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride + 1) };
-                ring[m][j] = clear_state ? zero : t;
-            }
-        }
-        const float phre = g_tab[TB_PHIFRACT + (is34 * 50 + kh) * 2];
-        const float phim = g_tab[TB_PHIFRACT + (is34 * 50 + kh) * 2 + 1];
-        ph = v2f{phre, phim};
-        phi = v2f{-phim, phre};                      // i * phi_fract
-    }
-    const bool neg_im = (is34 && kh <= 13 && kh >= 9) || (!is34 && kh <= 1);
-    const float *tgrow = w.pw[b];
-    const v2f *srow = reinterpret_cast<const v2f *>(w.sub[is_sub ? kh : 0]);
-    float *lrow = w.subL[is_sub ? kh : W::NSUB], *rrow = w.subR[is_sub ? kh : W::NSUB];   // row NSUB = scratch
-    // column 0 of every row is rewritten by the hybrid synthesis at the end of the frame
-    const int qs4 = is_sub ? 0 : q * 4;
-
-    // H11/H12 and H21/H22 share a pair each, so one packed add steps two of them
-    v2f hA = zero, hB = zero, hA_step = zero, hB_step = zero;        // (h11r, h12r), (h21r, h22r)
-    v2f hAi = zero, hBi = zero, hAi_step = zero, hBi_step = zero;    // imaginary parts (IPD/OPD)
-    int e = -1, stop = -1;
-
-    // Fully unrolled over the 32 slots: ring positions and column indices are static.
-#pragma unroll
-    for (int n = 0; n < 32; n++) {
-        if ((!ALIGNED8 || (n & 7) == 0) && n > stop) {
-            // next envelope (aacps.c:900-938)
-            e++;
-            const int start = __builtin_amdgcn_readfirstlane(w.p.border_position[e]);
-            stop = __builtin_amdgcn_readfirstlane(w.p.border_position[e + 1]);
-            const float width = 1.f / (stop - start);
-            constexpr int R = W::IS_GENERAL ? 2 : 1;     // row step between H11, H12, H21, H22
-            hA = v2f{w.Hs[e][0][b], w.Hs[e][R][b]};
-            hB = v2f{w.Hs[e][2 * R][b], w.Hs[e][3 * R][b]};
-            hA_step = (v2f{w.Hs[e + 1][0][b], w.Hs[e + 1][R][b]} - hA) * bc(width);
-            hB_step = (v2f{w.Hs[e + 1][2 * R][b], w.Hs[e + 1][3 * R][b]} - hB) * bc(width);
-            if constexpr (W::IS_GENERAL) if (enable_ipdopd) {
-                hAi = v2f{w.Hs[e][1][b], w.Hs[e][3][b]};
-                hBi = v2f{w.Hs[e][5][b], w.Hs[e][7][b]};
-                if (neg_im) { hAi = -hAi; hBi = -hBi; }
-                hAi_step = (v2f{w.Hs[e + 1][1][b], w.Hs[e + 1][3][b]} - hAi) * bc(width);
-                hBi_step = (v2f{w.Hs[e + 1][5][b], w.Hs[e + 1][7][b]} - hBi) * bc(width);
-            }
-        }
-        // current sample and delayed sample s[k][n - D]
-        v2f sv, dv;
-        if (HEAVY) {
-            const v2f subv = srow[n];                  // sub-subband lanes (others read row 0, unused)
-            sv = is_sub ? subv : col[n];
-            const v2f sub2 = srow[n >= 2 ? n - 2 : 0];            // sub-subbands are all-pass bands: D = 2
-            // state tail for the first slots (static register index per category)
-            const v2f ap_d = n >= 2 ? (is_sub ? sub2 : col[n >= 2 ? n - 2 : 0]) : hst[12 + (n < 2 ? n : 0)];
-            const v2f d14_d = n >= 14 ? col[n >= 14 ? n - 14 : 0] : hst[n < 14 ? n : 0];
-            const v2f d1_d = n >= 1 ? col[n >= 1 ? n - 1 : 0] : hst[13];
-            dv = allpass ? ap_d : d14 ? d14_d : d1_d;
-        } else {
-            sv = col[n];
-            dv = n >= 1 ? col[n >= 1 ? n - 1 : 0] : hst[13];
-        }
-        const float tg = tgrow[n];
-        v2f rv;
-        if (HEAVY) {
-            // all-pass chain, computed by every lane (no branch inside the slot);
-            // lanes that are plain delays keep the delayed sample instead
-            v2f x = bc(dv.x) * ph + bc(dv.y) * phi;            // (d.re ph.re - d.im ph.im, d.re ph.im + d.im ph.re)
-#pragma unroll
-            for (int m = 0; m < 3; m++) {
-                const v2f a = bc(ag[m]) * x;
-                // link_delay = 3, 4, 5: value written at time n - delay
-                const int rp = (n + 5 - (3 + m)) % 5, wp = n % 5;
-                const v2f ld = ring[m][rp];
-                v2f nx = x;
-                x = (bc(ld.x) * qf[m] + bc(ld.y) * qfi[m]) - a;
-                nx += bc(ag[m]) * x;
-                ring[m][wp] = nx;
-            }
-            rv = bc(tg) * (allpass ? x : dv);
-        } else {
-            rv = bc(tg) * dv;
-        }
-
-        hA += hA_step; hB += hB_step;
-        // l = h11 s + h21 r,  r = h12 s + h22 r   (complex h only with IPD/OPD)
-        v2f lv = bc(hA.x) * sv + bc(hB.x) * rv;
-        v2f rr = bc(hA.y) * sv + bc(hB.y) * rv;
-        if (enable_ipdopd) {
-            hAi += hAi_step; hBi += hBi_step;
-            const v2f si = rot90(sv), ri = rot90(rv);            // (-im, re)
-            lv = (lv + bc(hAi.x) * si) + bc(hBi.x) * ri;
-            rr = (rr + bc(hAi.y) * si) + bc(hBi.y) * ri;
-        }
-        // Branch-free stores: sub-subband lanes keep L/R in LDS rows (hybrid synthesis sums
-        // them later) and send their global store to column 0, which the hybrid synthesis
-        // rewrites afterwards; QMF lanes store to X and send their LDS store to a scratch row.
-        if (HEAVY) {
-            *reinterpret_cast<v2f *>(lrow + 2 * n) = lv;
-            *reinterpret_cast<v2f *>(rrow + 2 * n) = rr;
-        }
-        {
-            const int qb = opaque(qs4);
-            X.stb(lv.x, qb, n * 64);          X.stb(lv.y, qb, XP + n * 64);
-            X.stb(rr.x, qb, 2 * XP + n * 64); X.stb(rr.y, qb, 3 * XP + n * 64);
-        }
-        // bound the scheduler's look-ahead: without it the 32 unrolled slots are
-        // interleaved until the register file overflows
-        if ((n & (PS_SCHED_GROUP - 1)) == PS_SCHED_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
-    }
-    // new delay-line tail = s[k][18..31]
-#pragma unroll
-    for (int j = 0; j < 14; j++) {
-        v2f v = col[18 + j];
-        if (HEAVY) {
-            const v2f t = srow[18 + j];
-            v = is_sub ? t : v;
-        }
-        const int kv = opaque(kh * 8);
-        SO.stb(v.x, kv, HEAAC_PS_DELAY + j * dl_stride);
-        SO.stb(v.y, kv, HEAAC_PS_DELAY + j * dl_stride + 1);
-    }
-    if (allpass) {
-        // times 27..31 sit at ring positions (27 + j) % 5
-#pragma unroll
-        for (int m = 0; m < 3; m++)
-#pragma unroll
-            for (int j = 0; j < 5; j++) {
-                const int kv = opaque(kh * 8);
-                SO.stb(ring[m][(27 + j) % 5].x, kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride);
-                SO.stb(ring[m][(27 + j) % 5].y, kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride + 1);
-            }
-    }
-}
-
-// power[i][n] = sum over the members of parameter band i (ascending hybrid band) of |s|^2.
-// The member lists are constexpr, so both loops unroll into straight-line LDS reads.
-template <bool IS34, int I>
-__device__ __forceinline__ void band_power_one(const float *row, float *pw_col)
-{
-    constexpr int J0 = IS34 ? kMem34.first[I] : kMem20.first[I];
-    constexpr int J1 = IS34 ? kMem34.first[I + 1] : kMem20.first[I + 1];
-    float acc = 0.0f;
-#pragma unroll
-    for (int j = J0; j < J1; j++) {
-        acc += row[IS34 ? kMem34.order[j] : kMem20.order[j]];      // |s|^2 = re*re + im*im
-    }
-    pw_col[I * 33] = acc;          // pw[I][n]
-}
-template <bool IS34, int I0, int I1>
-__device__ __forceinline__ void band_power_range(const float *row, float *pw_col)
-{
-    if constexpr (I0 < I1) {
-        band_power_one<IS34, I0>(row, pw_col);
-        band_power_range<IS34, I0 + 1, I1>(row, pw_col);
-    }
-}
-template <bool IS34>
-__device__ __forceinline__ void band_power(const float *row, float *pw_col, int half)
-{
-    constexpr int SPLIT = IS34 ? kMem34.split : kMem20.split;
-    constexpr int NPAR_ = IS34 ? 34 : 20;
-    if (half == 0) band_power_range<IS34, 0, SPLIT>(row, pw_col);
-    else           band_power_range<IS34, SPLIT, NPAR_>(row, pw_col);
-}
-
-// Which kernel variant owns a frame: the small-LDS one takes frames that are and
-// were 20-band (and frames with PS off), the general one everything else.
-__device__ __forceinline__ bool ps_frame_is_general(const HeaacPsFrame *g_p)
-{
-    return g_p->start && (g_p->is34bands || g_p->is34bands_old || g_p->enable_ipdopd);
-}
-
-template <bool GENERAL>
-__device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__restrict__ g_tab,
-                                         const HeaacPsFrame *g_p, int top_qmf,
-                                         const float *st_in, float *st_out,
-                                         float *Xrec /* [2][2][38][64]: in: mono in [0], out: left, right */,
-                                         int lane_in, int wave = 0)
-{
-    // `lane` is redefined opaquely at every phase: values derived from it (LDS addresses,
-    // band indices) then live for one phase instead of being hoisted out of the frame loop
-    // into registers that end up spilled.
-    int lane = opaque(lane_in);
-    using WT = PsWaveT<GENERAL>;
-    constexpr int XP = 38 * 64;
-    const GBuf SI(st_in), SO(st_out), X(Xrec);
-    {
-        const uint32_t *s = reinterpret_cast<const uint32_t *>(g_p);
-        uint32_t *d = reinterpret_cast<uint32_t *>(&w.p);   // w.p is a reference into LDS
-        for (int i = lane; i < (int)(sizeof(HeaacPsFrame) / 4); i += WAVE) d[i] = s[i];
-    }
-    wave_sync();
-    STAMP(0);
-    const HeaacPsFrame &p = w.p;
-
-    if (!p.start) {
-        // memcpy(sbr->X[1], sbr->X[0]) (aacsbr.c:1755); PS state untouched
-        for (int t = lane; t < 2 * XP; t += WAVE) X.st(X.ld(t), t, 2 * XP);
-        if (st_out != st_in)
-            for (int t = lane; t < HEAAC_ST_PS; t += WAVE) SO.st(SI.ld(t), t);
-        wave_sync();
-        return;
-    }
-
-    const int is34 = GENERAL ? p.is34bands : 0;
-    const int nr_bands = is34 ? 91 : 71, nr_par = is34 ? 34 : 20, nr_allpass = is34 ? 50 : 30;
-    const int nsub = is34 ? 32 : 10, nlow = is34 ? 5 : 3;     // sub-subbands / hybrid QMF bands
-    const int top = top_qmf + nr_bands - 64;                  // aacps.c:980
-    const bool switched = GENERAL && is34 != p.is34bands_old;
-    const BandMembers &M = is34 ? kMem34 : kMem20;
-
-    // ---- every lane loads ONE QMF column (32 slots, all loads in flight at once) ----
-    // lanes [0, P2)          : q = 64 - P2 + lane   the bands of pass 2 (hybrid index 64 + lane)
-    // lanes [P2, nsub)       : q = lane - P2        the nlow bands that feed the hybrid filters
-    // lanes [nsub, 64)       : q = lane - nsub + nlow   hybrid index kh = lane (pass 1)
-    const int P2 = nr_bands - 64;
-    const int q_own = lane < P2 ? 64 - P2 + lane : lane < nsub ? lane - P2 : lane - nsub + nlow;
-    v2f col[32];
-#pragma unroll
-    for (int n = 0; n < 32; n++) {
-        const int qb = opaque(q_own * 4);
-        col[n] = v2f{X.ldb(qb, n * 64), X.ldb(qb, XP + n * 64)};
-    }
-    {
-        const int kh_own = lane >= nsub ? lane : 64 + lane;      // valid unless P2 <= lane < nsub
-        if (lane >= nsub || lane < P2) {
-#pragma unroll
-            for (int n = 0; n < 32; n++) w.pn[n * WT::PNS + kh_own] = col[n].x * col[n].x + col[n].y * col[n].y;
-        } else {
-            // hybrid analysis input (aacps.c:362-367): in[i][j+6] = L[.][j][i]
-#pragma unroll
-            for (int n = 0; n < 32; n++) { w.inb[q_own][n + 6][0] = col[n].x; w.inb[q_own][n + 6][1] = col[n].y; }
-        }
-    }
-    for (int t = lane; t < nlow * 6; t += WAVE) {
-        const int i = t / 6, j = t % 6;
-        w.inb[i][j][0] = SI.ld(t * 2, HEAAC_PS_INBUF);
-        w.inb[i][j][1] = SI.ld(t * 2, HEAAC_PS_INBUF + 1);
-        // lookahead slots 32..37
-        w.inb[i][38 + j][0] = X.ld((32 + j) * 64 + i);
-        w.inb[i][38 + j][1] = X.ld((32 + j) * 64 + i, XP);
-    }
-    wave_sync();
-    STAMP(1);
-    lane = opaque(lane);
-    // in_buf update (:391-394): in[i][0..5] <- in[i][32..37] = L[.][26..31][i], all 5 bands
-    for (int t = lane; t < 5 * 6; t += WAVE) {
-        const int i = t / 6, j = t % 6;
-        float re, im;
-        if (i < nlow) { re = w.inb[i][32 + j][0]; im = w.inb[i][32 + j][1]; }
-        else          { re = X.ld((26 + j) * 64 + i); im = X.ld((26 + j) * 64 + i, XP); }
-        SO.st(re, t * 2, HEAAC_PS_INBUF);
-        SO.st(im, t * 2, HEAAC_PS_INBUF + 1);
-    }
-    // ---- hybrid filters -> sub[ks][n] ----
-    for (int t = lane; t < nsub * 32; t += WAVE) {
-        const int ks = t >> 5, n = t & 31;
-        float re, im;
-        if (is34) {
-            int qb, f, off;
-            if (ks < 12)      { qb = 0; f = ks;      off = TB_F34_0_12; }
-            else if (ks < 20) { qb = 1; f = ks - 12; off = TB_F34_1_8; }
-            else              { qb = 2 + ((ks - 20) >> 2); f = (ks - 20) & 3; off = TB_F34_2_4; }
-            hybrid_fir(&w.inb[qb][n][0], g_tab + off + f * 14, re, im);
-        } else if (ks < 6) {
-            // hybrid6_cx (:303-336): out = temp[fa] (+ temp[fb]); order 6,7,0,1,2+5,3+4
-            const float *in = &w.inb[0][n][0];
-            const float *F = g_tab + TB_F20_0_8;
-            const int fa = ks == 0 ? 6 : ks == 1 ? 7 : ks == 2 ? 0 : ks == 3 ? 1 : ks == 4 ? 2 : 3;
-            hybrid_fir(in, F + fa * 14, re, im);
-            if (ks >= 4) {
-                float br, bi;
-                hybrid_fir(in, F + (ks == 4 ? 5 : 4) * 14, br, bi);
-                re = re + br;
-                im = im + bi;
-            }
-        } else {
-            // hybrid2_re (:283-301): band 1 reversed, band 2 not
-            const int qb = ks < 8 ? 1 : 2, reverse = ks < 8 ? 1 : 0;
-            const int which = (ks - (qb == 1 ? 6 : 8));       // 0 -> out[0], 1 -> out[1]
-            const float *in = &w.inb[qb][n][0];
-            const float *f = g_tab + TB_G1_Q2;
-            const float re_in = f[6] * in[12], im_in = f[6] * in[13];
-            float re_op = 0.0f, im_op = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 6; j += 2) {
-                re_op += f[j + 1] * (in[2 * (j + 1)] + in[2 * (12 - j - 1)]);
-                im_op += f[j + 1] * (in[2 * (j + 1) + 1] + in[2 * (12 - j - 1) + 1]);
-            }
-            // out[reverse] = in + op, out[!reverse] = in - op
-            if (which == reverse) { re = re_in + re_op; im = im_in + im_op; }
-            else                  { re = re_in - re_op; im = im_in - im_op; }
-        }
-        w.sub[ks][2 * n] = re;
-        w.sub[ks][2 * n + 1] = im;
-        w.pn[n * WT::PNS + ks] = re * re + im * im;
-    }
-    wave_sync();
-
-    STAMP(2);
-    lane = opaque(lane);
-    // ---- band power (aacps.c:673-678): members of each parameter band in ascending
-    // hybrid-band order.  The member lists are compile-time constants, so the sums
-    // unroll into straight-line LDS reads; two half-waves split the parameter bands.
-    {
-        const int n = lane & 31, half = lane >> 5;
-        const float *row = w.pn + n * WT::PNS;
-        if (is34) {
-            if constexpr (GENERAL) band_power<true>(row, &w.pw[0][n], half);
-        } else {
-            band_power<false>(row, &w.pw[0][n], half);
-        }
-    }
-    wave_sync();
-    STAMP(3);
-    lane = opaque(lane);
-    // ---- transient detection (:681-692), one lane per parameter band ----
-    if (lane < nr_par) {
-        const int i = lane;
-        float peak = SI.ld(i, HEAAC_PS_PEAK), smooth = SI.ld(i, HEAAC_PS_PSMOOTH), diff = SI.ld(i, HEAAC_PS_PDIFF);
-        if (switched) { peak = 0.0f; smooth = 0.0f; diff = 0.0f; }
-        float prow[32];
-#pragma unroll
-        for (int n = 0; n < 32; n++) prow[n] = w.pw[i][n];
-#pragma unroll
-        for (int n = 0; n < 32; n++) {
-            const float pwr = prow[n];
-            const float decayed_peak = 0.76592833836465f * peak;
-            peak = decayed_peak > pwr ? decayed_peak : pwr;
-            smooth += 0.25f * (pwr - smooth);
-            diff += 0.25f * (peak - pwr - diff);
-            const float denom = 1.5f * diff;
-            w.pw[i][n] = (denom > smooth) ? smooth / denom : 1.0f;
-        }
-        SO.st(peak, i, HEAAC_PS_PEAK);
-        SO.st(smooth, i, HEAAC_PS_PSMOOTH);
-        SO.st(diff, i, HEAAC_PS_PDIFF);
-    } else if (lane < 34) {
-        // parameter bands 20..33 are not touched in 20-band mode
-        const int i = lane;
-        const float a = SI.ld(i, HEAAC_PS_PEAK), b = SI.ld(i, HEAAC_PS_PSMOOTH), c = SI.ld(i, HEAAC_PS_PDIFF);
-        SO.st(switched ? 0.0f : a, i, HEAAC_PS_PEAK);
-        SO.st(switched ? 0.0f : b, i, HEAAC_PS_PSMOOTH);
-        SO.st(switched ? 0.0f : c, i, HEAAC_PS_PDIFF);
-    }
-
-    STAMP(4);
-    lane = opaque(lane);
-    // ---- parameter remapping + H matrices (aacps.c:817-899) ----
-    for (int t = lane; t < 5 * WT::NPAR; t += WAVE) {
-        const int e = t / WT::NPAR, b = t % WT::NPAR;
-        int iid = 0, icc = 0, ipd = 0, opd = 0;
-        if (e < p.num_env && b < nr_par) {
-            iid = remap_idx(p.iid_par[e], p.nr_iid_par, is34, b);
-            icc = remap_idx(p.icc_par[e], p.nr_icc_par, is34, b);
-            if (p.enable_ipdopd && b < 17) {
-                ipd = remap_idx(p.ipd_par[e], p.nr_ipdopd_par, is34, b);
-                opd = remap_idx(p.opd_par[e], p.nr_ipdopd_par, is34, b);
-            }
-        }
-        w.iid_m[e][b] = (signed char)iid; w.icc_m[e][b] = (signed char)icc;
-        w.ipd_m[e][b] = (signed char)ipd; w.opd_m[e][b] = (signed char)opd;
-    }
-    // row 0 = H of the last envelope of the previous frame, remapped on a 20<->34 switch
-    for (int t = lane; t < WT::NH * WT::NPAR; t += WAVE) {
-        const int j = t / WT::NPAR, b = t % WT::NPAR;
-        const float *row = st_in + HEAAC_PS_H + (GENERAL ? j : 2 * j) * 34;   // baseline keeps the real rows
-        w.Hs[0][j][b] = switched ? remap_val(row, is34, b) : row[b];
-    }
-    wave_sync();
-    if (lane < nr_par) {
-        const int b = lane;
-        const float *LUT = g_tab + ((p.icc_mode < 3) ? TB_HA : TB_HB);
-        const signed char *hist = reinterpret_cast<const signed char *>(st_in + HEAAC_PS_HIST);
-        int opd_hist = hist[b], ipd_hist = hist[34 + b];
-        if (switched && b < 17) { opd_hist = 0; ipd_hist = 0; }        // ipdopd_reset
-        // fetch every envelope's LUT row first (independent loads), then run the
-        // IPD/OPD history chain over them
-        float hl[5][4];
-#pragma unroll
-        for (int e = 0; e < 5; e++) {
-            const int ee = e < p.num_env ? e : 0;
-            const float4 h4 = *reinterpret_cast<const float4 *>(
-                LUT + ((w.iid_m[ee][b] + 7 + 23 * p.iid_quant) * 8 + w.icc_m[ee][b]) * 4);
-            hl[e][0] = h4.x; hl[e][1] = h4.y; hl[e][2] = h4.z; hl[e][3] = h4.w;
-        }
-#pragma unroll
-        for (int e = 0; e < 5; e++) {
-            if (e >= p.num_env) break;
-            float h11 = hl[e][0], h12 = hl[e][1], h21 = hl[e][2], h22 = hl[e][3];
-            float h11i = 0.0f, h12i = 0.0f, h21i = 0.0f, h22i = 0.0f;
-            if (GENERAL && p.enable_ipdopd && b < p.nr_ipdopd_par) {
-                const int opd_idx = opd_hist * 8 + w.opd_m[e][b];
-                const int ipd_idx = ipd_hist * 8 + w.ipd_m[e][b];
-                const float opd_re = g_tab[TB_PD_RE + opd_idx], opd_im = g_tab[TB_PD_IM + opd_idx];
-                const float ipd_re = g_tab[TB_PD_RE + ipd_idx], ipd_im = g_tab[TB_PD_IM + ipd_idx];
-                opd_hist = opd_idx & 0x3F;
-                ipd_hist = ipd_idx & 0x3F;
-                const float ipd_adj_re = opd_re * ipd_re + opd_im * ipd_im;
-                const float ipd_adj_im = opd_im * ipd_re - opd_re * ipd_im;
-                h11i = h11 * opd_im;     h11 = h11 * opd_re;
-                h12i = h12 * ipd_adj_im; h12 = h12 * ipd_adj_re;
-                h21i = h21 * opd_im;     h21 = h21 * opd_re;
-                h22i = h22 * ipd_adj_im; h22 = h22 * ipd_adj_re;
-            }
-            if constexpr (GENERAL) {
-                w.Hs[e + 1][0][b] = h11; w.Hs[e + 1][1][b] = h11i;
-                w.Hs[e + 1][2][b] = h12; w.Hs[e + 1][3][b] = h12i;
-                w.Hs[e + 1][4][b] = h21; w.Hs[e + 1][5][b] = h21i;
-                w.Hs[e + 1][6][b] = h22; w.Hs[e + 1][7][b] = h22i;
-            } else {
-                w.Hs[e + 1][0][b] = h11; w.Hs[e + 1][1][b] = h12;
-                w.Hs[e + 1][2][b] = h21; w.Hs[e + 1][3][b] = h22;
-            }
-        }
-        // new history (bytes of two packed rows)
-        signed char *ho = reinterpret_cast<signed char *>(st_out + HEAAC_PS_HIST);
-        ho[b] = (signed char)opd_hist;
-        ho[34 + b] = (signed char)ipd_hist;
-    } else if (lane < 34) {
-        const signed char *hist = reinterpret_cast<const signed char *>(st_in + HEAAC_PS_HIST);
-        signed char *ho = reinterpret_cast<signed char *>(st_out + HEAAC_PS_HIST);
-        ho[lane] = hist[lane];
-        ho[34 + lane] = hist[34 + lane];
-    }
-    if (lane == 0) {
-        signed char *ho = reinterpret_cast<signed char *>(st_out + HEAAC_PS_HIST);
-        ho[68] = ho[69] = ho[70] = ho[71] = 0;
-    }
-    wave_sync();
-    // H state out: real rows always, imaginary rows only while IPD/OPD is on
-    if constexpr (GENERAL) {
-        for (int t = lane; t < 8 * 34; t += WAVE) {
-            const int j = t / 34, b = t % 34;
-            const bool imag = j & 1;
-            float v;
-            if (!imag || p.enable_ipdopd) v = b < nr_par ? w.Hs[p.num_env][j][b] : 0.0f;
-            else v = SI.ld(t, HEAAC_PS_H);
-            SO.st(v, t, HEAAC_PS_H);
-        }
-    } else {
-        for (int t = lane; t < 4 * 34; t += WAVE) {
-            const int j = t / 34, b = t % 34;
-            SO.st(b < 20 ? w.Hs[p.num_env][j][b] : 0.0f, 2 * j * 34 + b, HEAAC_PS_H);
-        }
-        if (st_out != st_in)
-            for (int t = lane; t < 4 * 34; t += WAVE) {
-                const int j = t / 34, b = t % 34;
-                SO.st(SI.ld((2 * j + 1) * 34 + b, HEAAC_PS_H), (2 * j + 1) * 34 + b, HEAAC_PS_H);
-            }
-    }
-
-    STAMP(5);
-    lane = opaque(lane);
-    // every border at 8k - 1 (what frame_class 0 produces): fast straight-line variant
-    bool aligned8 = true;
-    for (int e = 1; e <= p.num_env; e++) aligned8 = aligned8 && ((p.border_position[e] & 7) == 7);
-    aligned8 = __builtin_amdgcn_readfirstlane(aligned8);
-    // ---- pass 1: hybrid bands 0..63 = all sub-subbands + the first QMF bands ----
-    {
-        const int kh = lane;
-        const bool is_sub = kh < nsub;
-        if (aligned8)
-            ps_band<true, true>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X,
-                                 is_sub, kh - nsub + nlow, col);
-        else
-            ps_band<true, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X,
-                                 is_sub, kh - nsub + nlow, col);
-    }
-    STAMP(6);
-    lane = opaque(lane);
-    // ---- pass 2: hybrid bands 64.. (all use the one-slot delay) ----
-    if (lane < nr_bands - 64) {
-        const int kh = 64 + lane;
-        if (aligned8)
-            ps_band<false, true>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X,
-                                 false, kh - nsub + nlow, col);
-        else
-            ps_band<false, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X,
-                                 false, kh - nsub + nlow, col);
-    }
-    STAMP(7);
-    lane = opaque(lane);
-    // bands that exist in the state record but not in this layout / all-pass set
-    if (st_out != st_in || switched)
-    for (int t = lane; t < 14 * 91; t += WAVE) {
-        const int k = t % 91;
-        if (k >= nr_bands) {
-            const float a = SI.ld(t * 2, HEAAC_PS_DELAY), b = SI.ld(t * 2, HEAAC_PS_DELAY + 1);
-            SO.st(switched ? 0.0f : a, t * 2, HEAAC_PS_DELAY);
-            SO.st(switched ? 0.0f : b, t * 2, HEAAC_PS_DELAY + 1);
-        }
-    }
-    if (st_out != st_in || switched)
-    for (int t = lane; t < 15 * 50; t += WAVE) {
-        const int k = t % 50;
-        if (k >= nr_allpass) {
-            const float a = SI.ld(t * 2, HEAAC_PS_APDELAY), b = SI.ld(t * 2, HEAAC_PS_APDELAY + 1);
-            SO.st(switched ? 0.0f : a, t * 2, HEAAC_PS_APDELAY);
-            SO.st(switched ? 0.0f : b, t * 2, HEAAC_PS_APDELAY + 1);
-        }
-    }
-    wave_sync();
-
-    STAMP(8);
-    lane = opaque(lane);
-    // ---- hybrid synthesis (aacps.c:397-445) for the lowest QMF bands ----
-    {
-        const int n = lane & 31, side = lane >> 5;
-        const float *rows = side ? &w.subR[0][0] : &w.subL[0][0];
-        const int o0 = side * 2 * XP + n * 64, o1 = o0 + XP;
-#define SUBV(i, c) rows[(i) * SUB_STRIDE + 2 * n + (c)]
-        if (is34) {
-            const int first[5] = { 0, 12, 20, 24, 28 }, cnt[5] = { 12, 8, 4, 4, 4 };
-#pragma unroll
-            for (int qq = 0; qq < 5; qq++) {
-                float re = 0.0f, im = 0.0f;
-                for (int i = 0; i < cnt[qq]; i++) { re += SUBV(first[qq] + i, 0); im += SUBV(first[qq] + i, 1); }
-                X.st(re, o0, qq);
-                X.st(im, o1, qq);
-            }
-        } else {
-            X.st(SUBV(0, 0) + SUBV(1, 0) + SUBV(2, 0) + SUBV(3, 0) + SUBV(4, 0) + SUBV(5, 0), o0, 0);
-            X.st(SUBV(0, 1) + SUBV(1, 1) + SUBV(2, 1) + SUBV(3, 1) + SUBV(4, 1) + SUBV(5, 1), o1, 0);
-            X.st(SUBV(6, 0) + SUBV(7, 0), o0, 1);
-            X.st(SUBV(6, 1) + SUBV(7, 1), o1, 1);
-            X.st(SUBV(8, 0) + SUBV(9, 0), o0, 2);
-            X.st(SUBV(8, 1) + SUBV(9, 1), o1, 2);
-        }
-#undef SUBV
-    }
-    wave_sync();
-    STAMP(9);
-}
+#include "k_hf.h"
+#include "k_psf.h"
 
 template <bool GENERAL, int WAVES>
 __global__ __launch_bounds__(WAVES * WAVE)
@@ -803,12 +28,15 @@ void k_ps(const float *__restrict__ g_tab, const HeaacPsFrame *__restrict__ g_ps
     __shared__ float s_sub[WAVES][WT::NSUB][SUB_STRIDE];
     __shared__ float s_pw[WAVES][WT::NPAR][33];
     __shared__ float s_Hs[WAVES][6][WT::NH][WT::NPAR];
-    __shared__ signed char s_idx[WAVES][4][5][WT::NPAR];
+    // IPD/OPD index rows exist only in the general variant (the baseline one never touches them)
+    __shared__ signed char s_idx[WAVES][GENERAL ? 4 : 2][5][WT::NPAR];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
     WT W = { s_p[wave], s_inb[wave], s_scr[wave], s_sub[wave],
              reinterpret_cast<float (*)[SUB_STRIDE]>(s_scr[wave]),
              reinterpret_cast<float (*)[SUB_STRIDE]>(s_scr[wave] + (WT::NSUB + 1) * SUB_STRIDE),
-             s_pw[wave], s_Hs[wave], s_idx[wave][0], s_idx[wave][1], s_idx[wave][2], s_idx[wave][3] };
+             s_pw[wave], s_Hs[wave], s_idx[wave][0], s_idx[wave][1],
+             s_idx[wave][GENERAL ? 2 : 0], s_idx[wave][GENERAL ? 3 : 0] };
+    const v2f no_cols[32] = {};
     for (unsigned long long f = (unsigned long long)blockIdx.x * WAVES + wave; f < n;
          f += (unsigned long long)gridDim.x * WAVES) {
         if (ps_frame_is_general(&g_ps[f]) != GENERAL)
@@ -817,27 +45,114 @@ void k_ps(const float *__restrict__ g_tab, const HeaacPsFrame *__restrict__ g_ps
         const int top = h.kx + h.m;                 // ff_ps_apply(..., sbr->kx[1] + sbr->m[1])
         float *XL = g_X + (f * 2) * (2 * 38 * 64);
         ps_frame<GENERAL>(W, g_tab, &g_ps[f], top, g_state_in + f * state_words + off_ps,
-                          g_state_out + f * state_words + off_ps, XL, lane, wave);
+                          g_state_out + f * state_words + off_ps, XL, lane, wave, no_cols);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Fused HF adjustment + Parametric Stereo for HE-AACv2 (mono core): the wave that
+// finishes sbr_x_gen for a frame keeps X[.][0..31][k] of its band k in registers and
+// runs ff_ps_apply on it, so the mono QMF signal never travels through HBM.  The HF
+// stage's LDS (X_low, limiter sums, side info) is dead by then and is laid under the PS
+// arrays.  Frames whose PS layout is not the baseline one (34 bands, IPD/OPD, PS off)
+// get X written out and are finished by k_ps<true>.
+// ---------------------------------------------------------------------------
+#define HFPS_WAVES 8
+#define HFPS_C_WORDS (HF_REC_WORDS > 20 * 33 ? HF_REC_WORDS : 20 * 33)
+
+__global__ __launch_bounds__(HFPS_WAVES * WAVE)
+void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g_sbr,
+            const HeaacSbrHeader *__restrict__ g_hdr, const HeaacPsFrame *__restrict__ g_ps,
+            const float *g_W, const float *g_state_in, float *g_state_out, int state_words,
+            int off_sbr, int off_ps, float *g_X, unsigned long long n)
+{
+    using WT = PsWaveT<false>;
+    static_assert(WT::SCR <= HF_XLOW_WORDS, "|s|^2 / subL / subR lie over X_low");
+    static_assert(WT::NSUB * SUB_STRIDE <= HF_AUX_WORDS, "sub-subband rows lie over the limiter sums");
+    __shared__ float s_a[HFPS_WAVES][HF_XLOW_WORDS];      // HF: X_low           | PS: |s|^2, subL / subR
+    __shared__ float s_b[HFPS_WAVES][HF_AUX_WORDS];       // HF: alpha, sums     | PS: sub-subband rows
+    __shared__ float s_c[HFPS_WAVES][HFPS_C_WORDS];       // HF: header, channel | PS: band power / transient gain
+    __shared__ HeaacPsFrame s_p[HFPS_WAVES];
+    __shared__ float s_inb[HFPS_WAVES][WT::NLOW][44][2];
+    __shared__ float s_Hs[HFPS_WAVES][6][WT::NH][WT::NPAR];
+    __shared__ signed char s_idx[HFPS_WAVES][2][5][WT::NPAR];
+    __shared__ float s_noise[1024];                       // sbr_noise_table, staged once per workgroup
+    wg_copy_f4(s_noise, g_tab + TB_NOISE, 1024);
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
+    const HfWave H = hf_wave_view(s_a[wave], s_b[wave], s_c[wave]);
+    WT W = { s_p[wave], s_inb[wave], s_a[wave], reinterpret_cast<float (*)[SUB_STRIDE]>(s_b[wave]),
+             reinterpret_cast<float (*)[SUB_STRIDE]>(s_a[wave]),
+             reinterpret_cast<float (*)[SUB_STRIDE]>(s_a[wave] + (WT::NSUB + 1) * SUB_STRIDE),
+             reinterpret_cast<float (*)[33]>(s_c[wave]), s_Hs[wave], s_idx[wave][0], s_idx[wave][1],
+             s_idx[wave][0], s_idx[wave][0] };
+    for (unsigned long long f = (unsigned long long)blockIdx.x * HFPS_WAVES + wave; f < n;
+         f += (unsigned long long)gridDim.x * HFPS_WAVES) {
+        const bool base = __builtin_amdgcn_readfirstlane(!ps_frame_is_general(&g_ps[f]));
+        float *Xf = g_X + (f * 2) * (2 * 38 * 64);
+        const float *st_in = g_state_in + f * state_words;
+        float *st_out = g_state_out + f * state_words;
+        v2f col[32];
+        float (*inb)[44][2] = s_inb[wave];
+        hf_channel(H, s_noise, &g_sbr[f], g_hdr, 0, g_W + f * 2048, st_in + off_sbr, st_out + off_sbr, lane,
+                   [&](int i, float re, float im) {
+                       if (i < 32) {
+                           col[i] = v2f{re, im};
+                       } else if (base) {
+                           // look-ahead slots of the hybrid analysis (aacps.c:362-367)
+                           if (lane < WT::NLOW) { inb[lane][6 + i][0] = re; inb[lane][6 + i][1] = im; }
+                       } else {
+                           Xf[i * 64 + lane] = re;
+                           Xf[38 * 64 + i * 64 + lane] = im;
+                       }
+                   });
+        if (!base) {
+#pragma unroll
+            for (int i = 0; i < 32; i++) { Xf[i * 64 + lane] = col[i].x; Xf[38 * 64 + i * 64 + lane] = col[i].y; }
+            continue;
+        }
+        const HeaacSbrHeader &h = g_hdr[g_sbr[f].hdr];
+        const int top = h.kx + h.m;                 // ff_ps_apply(..., sbr->kx[1] + sbr->m[1])
+        ps_frame<false, true>(W, g_tab, &g_ps[f], top, st_in + off_ps, st_out + off_ps, Xf, lane, wave, col);
     }
 }
 
 #define PS_WAVES_20 8
 #define PS_WAVES_GEN 4
 
+// variants: bit 0 = baseline kernel, bit 1 = general kernel
 extern "C" int heaac_launch_ps(const float *d_tab, const HeaacPsFrame *d_ps, const HeaacSbrFrame *d_sbr,
                                const HeaacSbrHeader *d_hdr, const float *d_state_in, float *d_state_out,
-                               int state_words, int off_ps, float *d_ws_X, size_t n, hipStream_t s)
+                               int state_words, int off_ps, float *d_ws_X, size_t n, int variants,
+                               hipStream_t s)
 {
     if (!n) return HEAAC_OK;
     unsigned long long g = (n + PS_WAVES_20 - 1) / PS_WAVES_20;
     if (g > 256) g = 256;
-    hipLaunchKernelGGL((k_ps<false, PS_WAVES_20>), dim3((unsigned)g), dim3(PS_WAVES_20 * WAVE), 0, s, d_tab,
-                       d_ps, d_sbr, d_hdr, d_state_in, d_state_out, state_words, off_ps, d_ws_X,
-                       (unsigned long long)n);
+    if (variants & 1)
+        hipLaunchKernelGGL((k_ps<false, PS_WAVES_20>), dim3((unsigned)g), dim3(PS_WAVES_20 * WAVE), 0, s, d_tab,
+                           d_ps, d_sbr, d_hdr, d_state_in, d_state_out, state_words, off_ps, d_ws_X,
+                           (unsigned long long)n);
     g = (n + PS_WAVES_GEN - 1) / PS_WAVES_GEN;
     if (g > 256) g = 256;
-    hipLaunchKernelGGL((k_ps<true, PS_WAVES_GEN>), dim3((unsigned)g), dim3(PS_WAVES_GEN * WAVE), 0, s, d_tab,
-                       d_ps, d_sbr, d_hdr, d_state_in, d_state_out, state_words, off_ps, d_ws_X,
+    if (variants & 2)
+        hipLaunchKernelGGL((k_ps<true, PS_WAVES_GEN>), dim3((unsigned)g), dim3(PS_WAVES_GEN * WAVE), 0, s, d_tab,
+                           d_ps, d_sbr, d_hdr, d_state_in, d_state_out, state_words, off_ps, d_ws_X,
+                           (unsigned long long)n);
+    return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
+}
+
+// HF adjustment of the mono core channel fused with baseline Parametric Stereo
+extern "C" int heaac_launch_hfps(const float *d_tab, const HeaacSbrFrame *d_sbr, const HeaacSbrHeader *d_hdr,
+                                 const HeaacPsFrame *d_ps, const float *d_ws_W,
+                                 const float *d_state_in, float *d_state_out, int state_words,
+                                 int off_sbr, int off_ps, float *d_ws_X, size_t n, hipStream_t s)
+{
+    if (!n) return HEAAC_OK;
+    unsigned long long g = (n + HFPS_WAVES - 1) / HFPS_WAVES;
+    if (g > 256) g = 256;
+    hipLaunchKernelGGL(k_hfps, dim3((unsigned)g), dim3(HFPS_WAVES * WAVE), 0, s, d_tab, d_sbr, d_hdr, d_ps,
+                       d_ws_W, d_state_in, d_state_out, state_words, off_sbr, off_ps, d_ws_X,
                        (unsigned long long)n);
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
 }
