@@ -264,7 +264,7 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
     const v2f *srow = reinterpret_cast<const v2f *>(w.sub[is_sub ? kh : 0]);
     float *lrow = w.subL[is_sub ? kh : W::NSUB], *rrow = w.subR[is_sub ? kh : W::NSUB];   // row NSUB = scratch
     // column 0 of every row is rewritten by the hybrid synthesis at the end of the frame
-    const int qs4 = is_sub ? 0 : q * 4;
+    const int qs4 = q * 4;
 
     // H11/H12 and H21/H22 share a pair each, so one packed add steps two of them
     v2f hA = zero, hB = zero, hA_step = zero, hB_step = zero;        // (h11r, h12r), (h21r, h22r)
@@ -463,20 +463,21 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     const bool switched = GENERAL && is34 != p.is34bands_old;
     const BandMembers &M = is34 ? kMem34 : kMem20;
 
-    // ---- every lane loads ONE QMF column (32 slots, all loads in flight at once) ----
-    // lanes [0, P2)          : q = 64 - P2 + lane   the bands of pass 2 (hybrid index 64 + lane)
-    // lanes [P2, nsub)       : q = lane - P2        the nlow bands that feed the hybrid filters
-    // lanes [nsub, 64)       : q = lane - nsub + nlow   hybrid index kh = lane (pass 1)
+    // ---- every lane holds ONE QMF column (32 slots) in registers ----
+    // general layout (20 or 34 bands):
+    //   lanes [0, P2)    : q = 64 - P2 + lane        the bands of pass 2 (hybrid index 64 + lane)
+    //   lanes [P2, nsub) : q = lane - P2             the nlow bands that feed the hybrid filters
+    //   lanes [nsub, 64) : q = lane - nsub + nlow    hybrid index kh = lane (pass 1)
+    // baseline layout (20 bands, the HF stage's own: lane = QMF band):
+    //   lanes 0..2       : feed the hybrid filters;  pass 1: sub-subbands 0..2
+    //   lanes 3..56      : pass 1: hybrid index lane + 7
+    //   lanes 57..63     : pass 1: sub-subbands 3..9;  pass 2: hybrid index lane + 7 (their own column)
     const int P2 = nr_bands - 64;
-    const int q_own = lane < P2 ? 64 - P2 + lane : lane < nsub ? lane - P2 : lane - nsub + nlow;
+    const int q_own = GENERAL ? (lane < P2 ? 64 - P2 + lane : lane < nsub ? lane - P2 : lane - nsub + nlow) : lane;
     v2f col[32];
     if constexpr (FUSED) {
-        // lane permutation band k = lane -> the layout above
 #pragma unroll
-        for (int n = 0; n < 32; n++) {
-            col[n].x = __int_as_float(__builtin_amdgcn_ds_bpermute(q_own * 4, __float_as_int(hfcol[n].x)));
-            col[n].y = __int_as_float(__builtin_amdgcn_ds_bpermute(q_own * 4, __float_as_int(hfcol[n].y)));
-        }
+        for (int n = 0; n < 32; n++) col[n] = hfcol[n];
     } else {
 #pragma unroll
         for (int n = 0; n < 32; n++) {
@@ -485,8 +486,9 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
         }
     }
     {
-        const int kh_own = lane >= nsub ? lane : 64 + lane;      // valid unless P2 <= lane < nsub
-        if (lane >= nsub || lane < P2) {
+        // hybrid index of the lane's column (unless it is one of the nlow hybrid-filter inputs)
+        const int kh_own = GENERAL ? (lane >= nsub ? lane : 64 + lane) : lane + 7;
+        if (GENERAL ? (lane >= nsub || lane < P2) : lane >= 3) {
 #pragma unroll
             for (int n = 0; n < 32; n++) w.pn[n * WT::PNS + kh_own] = col[n].x * col[n].x + col[n].y * col[n].y;
         } else {
@@ -735,20 +737,21 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     aligned8 = __builtin_amdgcn_readfirstlane(aligned8);
     // ---- pass 1: hybrid bands 0..63 = all sub-subbands + the first QMF bands ----
     {
-        const int kh = lane;
+        const int kh = GENERAL ? lane : (lane < 3 ? lane : lane >= 57 ? lane - 54 : lane + 7);
         const bool is_sub = kh < nsub;
+        // sub-subband lanes send their (discarded) X store to their own column: pass 2 or the
+        // hybrid synthesis rewrites it afterwards
+        const int qcol = GENERAL ? (is_sub ? 0 : kh - nsub + nlow) : lane;
         if (aligned8)
-            ps_band<true, true>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X,
-                                 is_sub, kh - nsub + nlow, col);
+            ps_band<true, true>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X, is_sub, qcol, col);
         else
-            ps_band<true, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X,
-                                 is_sub, kh - nsub + nlow, col);
+            ps_band<true, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X, is_sub, qcol, col);
     }
     STAMP(6);
     lane = opaque(lane);
     // ---- pass 2: hybrid bands 64.. (all use the one-slot delay) ----
-    if (lane < nr_bands - 64) {
-        const int kh = 64 + lane;
+    if (GENERAL ? lane < nr_bands - 64 : lane >= 57) {
+        const int kh = GENERAL ? 64 + lane : lane + 7;
         if (aligned8)
             ps_band<false, true>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X,
                                  false, kh - nsub + nlow, col);
