@@ -8,7 +8,7 @@
 #define ENV_ADJ 2          // ENVELOPE_ADJUSTMENT_OFFSET, aacsbr.c:39
 
 #ifdef HF_STAMPS
-__device__ unsigned long long g_hf_stamps[16];
+static __device__ unsigned long long g_hf_stamps[16];     // one copy per translation unit
 #define HSTAMP(i) do { wave_sync(); if (lane == 0 && blockIdx.x == 7 && threadIdx.x < 64) g_hf_stamps[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define HSTAMP(i) do {} while (0)

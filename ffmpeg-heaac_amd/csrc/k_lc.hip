@@ -9,6 +9,7 @@
 // HBM traffic per frame is exactly the algorithmic minimum: coefficients and
 // overlap read once with 16-byte loads, PCM and overlap written once.
 #include "k_core.h"
+#include "k_core2.h"
 #include "kernels.h"
 
 #define LC_WAVES 4
@@ -20,67 +21,76 @@ struct LcWaveLds {
     uint16_t pcm0[1024];
 };
 
+// ---------------------------------------------------------------------------
+// k_lc_decode: one wavefront = two channels at a time (the two channels of a CPE, or
+// two consecutive SCE frames), FFT in registers (k_core2.h).
+// ---------------------------------------------------------------------------
+#define LC2_WAVES 8
+
+struct Lc2Wave {
+    cpx T[2][C2_TSTRIDE];         // per channel: coefficients, transposes, then buf[1024]
+    uint16_t pcm0[1024];          // left channel of an interleaved int16 pair
+};
+
 template <int CH, int FMT>
-__global__ __launch_bounds__(LC_WAVES * WAVE)
+__global__ __launch_bounds__(LC2_WAVES * WAVE)
 void k_lc_decode(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_rev,
                  const float *__restrict__ g_coeffs, const HeaacIcs *__restrict__ g_ics,
                  const float *g_state_in, float *g_state_out,
                  void *__restrict__ g_pcm, unsigned long long n)
 {
-    __shared__ CoreLds L;
-    __shared__ LcWaveLds W[LC_WAVES];
-    core_lds_init(L, g_tab, g_rev);
+    __shared__ Core2Lds L;
+    __shared__ Lc2Wave W[LC2_WAVES];
+    core2_lds_init(L, g_tab, g_rev);
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
-    LcWaveLds &w = W[wave];
+    Lc2Wave &w = W[wave];
+    const unsigned long long units = (unsigned long long)n * CH;      // channels
+    const unsigned long long pairs = (units + 1) / 2;
 
-    for (unsigned long long f = (unsigned long long)blockIdx.x * LC_WAVES + wave; f < n;
-         f += (unsigned long long)gridDim.x * LC_WAVES) {
-#pragma unroll
-        for (int c = 0; c < CH; c++) {
-            const unsigned long long u = f * CH + c;
-            const HeaacIcs ics = g_ics[u];
-            core_channel(L, g_coeffs + u * 1024, g_state_in + u * 512, g_state_out + u * 512,
-                         ics, HEAAC_ADD_BIAS, w.sbuf, w.zbuf, w.svd, lane);
-            if (FMT == HEAAC_PCM_F32_PLANAR) {
-                float4 *o4 = reinterpret_cast<float4 *>(reinterpret_cast<float *>(g_pcm) + u * 1024);
-                const float4 *s4 = reinterpret_cast<const float4 *>(w.sbuf);
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    o4[lane + 64 * i] = s4[lane + 64 * i];
-            } else if (CH == 1) {
-                // 4 samples -> 8 bytes per lane per step
-                uint2 *o2 = reinterpret_cast<uint2 *>(reinterpret_cast<int16_t *>(g_pcm) + u * 1024);
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const float4 v = reinterpret_cast<const float4 *>(w.sbuf)[lane + 64 * i];
-                    const unsigned a = (unsigned)(float_to_int16_one(v.x) & 0xffff) |
-                                       ((unsigned)(float_to_int16_one(v.y) & 0xffff) << 16);
-                    const unsigned b = (unsigned)(float_to_int16_one(v.z) & 0xffff) |
-                                       ((unsigned)(float_to_int16_one(v.w) & 0xffff) << 16);
-                    o2[lane + 64 * i] = make_uint2(a, b);
-                }
-            } else if (c == 0) {
-                for (int i = lane; i < 1024; i += WAVE)
-                    w.pcm0[i] = (uint16_t)float_to_int16_one(w.sbuf[i]);
-            } else {
-                // interleave L (kept in LDS) with R: 4 stereo samples = 16 bytes per lane
-                uint4 *o4 = reinterpret_cast<uint4 *>(reinterpret_cast<int16_t *>(g_pcm) + f * 2048);
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int s = (lane + 64 * i) * 4;
-                    const float4 v = reinterpret_cast<const float4 *>(w.sbuf)[lane + 64 * i];
-                    uint4 q;
-                    q.x = w.pcm0[s + 0] | ((unsigned)(float_to_int16_one(v.x) & 0xffff) << 16);
-                    q.y = w.pcm0[s + 1] | ((unsigned)(float_to_int16_one(v.y) & 0xffff) << 16);
-                    q.z = w.pcm0[s + 2] | ((unsigned)(float_to_int16_one(v.z) & 0xffff) << 16);
-                    q.w = w.pcm0[s + 3] | ((unsigned)(float_to_int16_one(v.w) & 0xffff) << 16);
-                    o4[lane + 64 * i] = q;
-                }
-            }
-            wave_sync();
+    for (unsigned long long pr = (unsigned long long)blockIdx.x * LC2_WAVES + wave; pr < pairs;
+         pr += (unsigned long long)gridDim.x * LC2_WAVES) {
+        const unsigned long long u0 = 2 * pr;
+        const bool have1 = u0 + 1 < units;                              // uniform
+        const unsigned long long u1 = have1 ? u0 + 1 : u0;
+        const HeaacIcs ics0 = g_ics[u0], ics1 = g_ics[u1];
+        core2_stage_coeffs(reinterpret_cast<float *>(w.T[0]), g_coeffs + u0 * 1024, lane);
+        core2_stage_coeffs(reinterpret_cast<float *>(w.T[1]), g_coeffs + u1 * 1024, lane);
+        wave_sync();
+        {
+            const int half = lane >> 5, hl = lane & 31;
+            const bool eight = (half ? ics1.window_sequence[0] : ics0.window_sequence[0]) == HEAAC_EIGHT_SHORT_SEQUENCE;
+            imdct_half_regs(L, reinterpret_cast<const float *>(w.T[half]), w.T[half], eight, hl);
         }
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            if (c == 1 && !have1) break;
+            const unsigned long long u = c ? u1 : u0;
+            const HeaacIcs ics = c ? ics1 : ics0;
+            const float *buf = reinterpret_cast<const float *>(w.T[c]);
+            const float *sin_ = g_state_in + u * 512;
+            float *sout = g_state_out + u * 512;
+            if (FMT == HEAAC_PCM_F32_PLANAR) {
+                float *o = reinterpret_cast<float *>(g_pcm) + u * 1024;
+                core2_window(L, ics, HEAAC_ADD_BIAS, buf, sin_, sout, lane, [&](int q, float v) { o[q] = v; });
+            } else if (CH == 1) {
+                int16_t *o = reinterpret_cast<int16_t *>(g_pcm) + u * 1024;
+                core2_window(L, ics, HEAAC_ADD_BIAS, buf, sin_, sout, lane,
+                             [&](int q, float v) { o[q] = (int16_t)float_to_int16_one(v); });
+            } else if (c == 0) {
+                core2_window(L, ics, HEAAC_ADD_BIAS, buf, sin_, sout, lane,
+                             [&](int q, float v) { w.pcm0[q] = (uint16_t)float_to_int16_one(v); });
+                wave_sync();
+            } else {
+                // float_to_int16_interleave (dsputil.c:3989-4001): L from LDS, R fresh
+                uint32_t *o = reinterpret_cast<uint32_t *>(g_pcm) + (u0 / 2) * 1024;
+                core2_window(L, ics, HEAAC_ADD_BIAS, buf, sin_, sout, lane, [&](int q, float v) {
+                    o[q] = (uint32_t)w.pcm0[q] | ((uint32_t)(float_to_int16_one(v) & 0xffff) << 16);
+                });
+            }
+        }
+        wave_sync();
     }
 }
 
@@ -212,8 +222,9 @@ extern "C" int heaac_launch_lc(const float *d_tab, const uint16_t *d_rev, int ch
                                void *d_pcm, int pcm_format, size_t n, hipStream_t s)
 {
     if (n == 0) return HEAAC_OK;
-    const int grid = grid_for(n, LC_WAVES, 2);
-    const dim3 b(LC_WAVES * WAVE);
+    const unsigned long long pairs = ((unsigned long long)n * channels + 1) / 2;
+    const int grid = grid_for(pairs, LC2_WAVES, 1);
+    const dim3 b(LC2_WAVES * WAVE);
 #define LAUNCH(CH, FMT) \
     hipLaunchKernelGGL((k_lc_decode<CH, FMT>), dim3(grid), b, 0, s, d_tab, d_rev, d_coeffs, d_ics, \
                        d_state_in, d_state_out, d_pcm, (unsigned long long)n)

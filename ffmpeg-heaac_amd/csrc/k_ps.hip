@@ -157,6 +157,14 @@ extern "C" int heaac_launch_hfps(const float *d_tab, const HeaacSbrFrame *d_sbr,
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
 }
 
+#ifdef HF_STAMPS
+// stamps of the HF stage inside the fused kernel
+extern "C" int heaac_debug_hfps_stamps(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hf_stamps), sizeof(g_hf_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 #ifdef PS_STAMPS
 extern "C" int heaac_debug_ps_stamps(unsigned long long *out)
 {
