@@ -16,6 +16,7 @@
 // Reference line numbers are libavcodec/aacsbr.c and aacps.c.
 #include <stdlib.h>
 #include "k_core.h"
+#include "k_core2.h"
 #include "kernels.h"
 
 #include "k_hf.h"
@@ -79,50 +80,139 @@ __device__ __forceinline__ void qmf_analysis_wave(const float *qmf_ds, const flo
     wave_sync();
 }
 
-__global__ __launch_bounds__(ANA_WAVES * WAVE)
+// ---------------------------------------------------------------------------
+// k_core_ana: one wavefront = two SBR channels at a time (the two channels of a CPE, or
+// two consecutive mono frames).  Core IMDCT in registers (k_core2.h), then the analysis
+// filterbank with one 128-point IMDCT per lane: 2 x 32 slots fill the wave.
+// ---------------------------------------------------------------------------
+#define CA_WAVES 5
+#define CA_U     2080             // fold rows u[32][65] of one channel
+
+struct CaWave {
+    float tu[2 * 2 * C2_TSTRIDE]; // core: T[2][C2_TSTRIDE] complex; afterwards u of channel 0
+    float u1[CA_U];               // u of channel 1
+    float x[2][1312];             // analysis input: 288 history + 1024 new samples
+};
+static_assert(CA_U <= 2 * 2 * C2_TSTRIDE, "u rows of channel 0 lie over the core's transpose regions");
+
+__global__ __launch_bounds__(CA_WAVES * WAVE)
 void k_core_ana(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_rev,
                 const float *__restrict__ g_coeffs, const HeaacIcs *__restrict__ g_ics,
                 const float *g_state_in, float *g_state_out, int state_words,
                 int ncore, int off_saved0, int off_sbr0,
                 float *__restrict__ g_W, float scale, unsigned long long n_units)
 {
-    __shared__ AnaLds S;
-    core_lds_init(S.core, g_tab, g_rev);
-    for (int i = threadIdx.x; i < 320; i += blockDim.x) S.qmf_ds[i] = g_tab[TB_QMF_DS + i];
-    for (int i = threadIdx.x; i < 64; i += blockDim.x)  S.rot[i] = g_tab[TB_ROT128A + i];
+    __shared__ Core2Lds L;
+    __shared__ float s_qmf_ds[320];
+    __shared__ float s_rot[64];                  // SBR analysis MDCT: tcos[32], tsin[32]
+    __shared__ CaWave S[CA_WAVES];
+    core2_lds_init(L, g_tab, g_rev);
+    for (int i = threadIdx.x; i < 320; i += blockDim.x) s_qmf_ds[i] = g_tab[TB_QMF_DS + i];
+    for (int i = threadIdx.x; i < 64; i += blockDim.x)  s_rot[i] = g_tab[TB_ROT128A + i];
     __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
-    float *pool = S.pool[wave];
-    const float *c16 = S.core.tab + TB_COS16, *c32 = S.core.tab + TB_COS32;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane0 = threadIdx.x % WAVE;
+    CaWave &w = S[wave];
+    cpx *T0 = reinterpret_cast<cpx *>(w.tu), *T1 = T0 + C2_TSTRIDE;
+    const float *c16 = L.tab + TB_COS16, *c32 = L.tab + TB_COS32;
+    const unsigned long long pairs = (n_units + 1) / 2;
 
-    for (unsigned long long u = (unsigned long long)blockIdx.x * ANA_WAVES + wave; u < n_units;
-         u += (unsigned long long)gridDim.x * ANA_WAVES) {
-        const unsigned long long f = u / ncore;
-        const int ch = (int)(u - f * ncore);
-        const float *st_in = g_state_in + f * state_words;
-        float *st_out = g_state_out + f * state_words;
-        const int off_saved = off_saved0 + ch * HEAAC_ST_SAVED;
-        const int off_sbr = off_sbr0 + ch * HEAAC_ST_SBR;
-
-        float *sbuf = pool, *zbuf = pool + 1024, *svd = pool + 2048;
-        core_channel(S.core, g_coeffs + u * 1024, st_in + off_saved, st_out + off_saved,
-                     g_ics[u], 0.0f, sbuf, zbuf, svd, lane);
-
-        // After the core stage only sbuf (= out[1024], pool[0..1024)) is live.
-        // x = [history 288 | in * scale 1024] goes to pool[2080 .. 3392); the
-        // fold rows u[32][65] then overwrite pool[0 .. 2080).
-        float *x = pool + 2080;
-        const float *xh_in = st_in + off_sbr + HEAAC_SBR_XHIST;
-        float *xh_out = st_out + off_sbr + HEAAC_SBR_XHIST;
-        for (int i = lane; i < 288; i += WAVE) x[i] = xh_in[i];
-        if (scale != 1.0f) {
-            for (int i = lane; i < 1024; i += WAVE) x[288 + i] = sbuf[i] * scale;   // vector_fmul_scalar
-        } else {
-            for (int i = lane; i < 1024; i += WAVE) x[288 + i] = sbuf[i];
+    for (unsigned long long pr = (unsigned long long)blockIdx.x * CA_WAVES + wave; pr < pairs;
+         pr += (unsigned long long)gridDim.x * CA_WAVES) {
+        const unsigned long long u0 = 2 * pr;
+        const bool have1 = u0 + 1 < n_units;                            // uniform
+        const unsigned long long u1 = have1 ? u0 + 1 : u0;
+        const HeaacIcs ics0 = g_ics[u0], ics1 = g_ics[u1];
+        int lane = opaque(lane0);      // lane-derived addresses are recomputed per pair, not hoisted and spilled
+        core2_stage_coeffs(reinterpret_cast<float *>(T0), g_coeffs + u0 * 1024, lane);
+        core2_stage_coeffs(reinterpret_cast<float *>(T1), g_coeffs + u1 * 1024, lane);
+        wave_sync();
+        {
+            const int half = lane >> 5, hl = lane & 31;
+            const bool eight = (half ? ics1.window_sequence[0] : ics0.window_sequence[0]) == HEAAC_EIGHT_SHORT_SEQUENCE;
+            cpx *T = half ? T1 : T0;
+            imdct_half_regs(L, reinterpret_cast<const float *>(T), T, eight, hl);
+        }
+        // windowing (bias 0) -> x = [history 288 | out * scale] per channel (vector_fmul_scalar,
+        // aacsbr.c:1142), x history in / out
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            if (c == 1 && !have1) break;
+            const unsigned long long u = c ? u1 : u0;
+            const unsigned long long f = u / ncore;
+            const int ch = (int)(u - f * ncore);
+            const float *st_in = g_state_in + f * state_words;
+            float *st_out = g_state_out + f * state_words;
+            const int off_saved = off_saved0 + ch * HEAAC_ST_SAVED;
+            const int off_sbr = off_sbr0 + ch * HEAAC_ST_SBR;
+            float *x = w.x[c];
+            const float *xh_in = st_in + off_sbr + HEAAC_SBR_XHIST;
+            float xh[5];
+#pragma unroll
+            for (int t = 0; t < 5; t++) xh[t] = 64 * t + lane < 288 ? xh_in[64 * t + lane] : 0.0f;
+            const float *buf = reinterpret_cast<const float *>(c ? T1 : T0);
+            if (scale != 1.0f)
+                core2_window(L, c ? ics1 : ics0, 0.0f, buf, st_in + off_saved, st_out + off_saved, lane,
+                             [&](int q, float v) { x[288 + q] = v * scale; });
+            else
+                core2_window(L, c ? ics1 : ics0, 0.0f, buf, st_in + off_saved, st_out + off_saved, lane,
+                             [&](int q, float v) { x[288 + q] = v; });
+#pragma unroll
+            for (int t = 0; t < 5; t++) if (64 * t + lane < 288) x[64 * t + lane] = xh[t];
         }
         wave_sync();
-        for (int i = lane; i < 288; i += WAVE) xh_out[i] = x[1024 + i];
-        qmf_analysis_wave(S.qmf_ds, S.rot, c16, c32, x, pool + 0, g_W + u * 2048, lane);
+        lane = opaque(lane);
+        // sbr_qmf_analysis (aacsbr.c:1136-1169).  z[n] = ds[n] * x[319 - n]; f[k] = sum of five
+        // taps 64 apart: lane = k keeps its taps in registers and walks the 32 slots.
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            if (c == 1 && !have1) break;
+            const unsigned long long u = c ? u1 : u0;
+            const unsigned long long f = u / ncore;
+            const int ch = (int)(u - f * ncore);
+            float *xh_out = g_state_out + f * state_words + off_sbr0 + ch * HEAAC_ST_SBR + HEAAC_SBR_XHIST;
+            const float *x = w.x[c];
+            float *uu = c ? w.u1 : w.tu;
+#pragma unroll
+            for (int t = 0; t < 5; t++) if (64 * t + lane < 288) xh_out[64 * t + lane] = x[1024 + 64 * t + lane];
+            const int k = lane;
+            const float w0 = s_qmf_ds[k], w1 = s_qmf_ds[k + 64], w2 = s_qmf_ds[k + 128],
+                        w3 = s_qmf_ds[k + 192], w4 = s_qmf_ds[k + 256];
+            for (int i = 0; i < 32; i++) {
+                const float *xs = x + 32 * i + 319 - k;
+                uu[i * 65 + k] = w0 * xs[0] + w1 * xs[-64] + w2 * xs[-128] + w3 * xs[-192] + w4 * xs[-256];
+            }
+        }
+        wave_sync();
+        lane = opaque(lane);
+        // shuffle to the IMDCT input (:1155-1160): in[0] = f[0]; in[2k-1] = f[k];
+        // in[2k] = -f[64-k] (k = 1..31); in[63] = f[32];  then ff_imdct_half (N = 128),
+        // lane = (channel, slot)
+        {
+            float *row = (lane >> 5 ? w.u1 : w.tu) + (lane & 31) * 65;
+            const float *f = row;
+            float o[64];
+            imdct128_reg([&](int j) -> float {
+                             if (j == 0)  return f[0];
+                             if (j == 63) return f[32];
+                             return (j & 1) ? f[(j + 1) >> 1] : -f[64 - (j >> 1)];
+                         }, o, s_rot, c16, c32);
+            // W[1][i][k] = (-z[63-k], z[k])                              (:1163-1166)
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                row[2 * k]     = -o[63 - k];
+                row[2 * k + 1] = o[k];
+            }
+        }
+        wave_sync();
+        // coalesced store: 2048 floats per channel
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            if (c == 1 && !have1) break;
+            const float *uu = c ? w.u1 : w.tu;
+            float *Wo = g_W + (c ? u1 : u0) * 2048;
+            for (int t = lane; t < 2048; t += WAVE) Wo[t] = uu[(t >> 6) * 65 + (t & 63)];
+        }
+        wave_sync();
     }
 }
 
@@ -383,7 +473,7 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
     const unsigned long long units = (unsigned long long)n * ncore;
     const float sf_scale = HEAAC_SF_SCALE;
 
-    hipLaunchKernelGGL(k_core_ana, dim3(he_grid(units, ANA_WAVES)), dim3(ANA_WAVES * WAVE), 0, s,
+    hipLaunchKernelGGL(k_core_ana, dim3(he_grid((units + 1) / 2, CA_WAVES)), dim3(CA_WAVES * WAVE), 0, s,
                        d_tab, d_rev, d_coeffs, d_ics, d_state_in, d_state_out, words, ncore,
                        off_saved0, off_sbr0, d_ws_W, 1 / (-1024 * sf_scale), units);
     int copy_mono = 0;
