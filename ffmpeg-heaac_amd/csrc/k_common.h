@@ -32,6 +32,8 @@ __device__ __forceinline__ void wave_sync()
 // per-access VGPR addresses, which the compiler otherwise hoists out of the
 // unrolled slot loops and spills.  Indices are in 32-bit words.
 // ---------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 struct GBuf {
     __amdgpu_buffer_rsrc_t r;
     __device__ __forceinline__ explicit GBuf(const void *base)
@@ -56,6 +58,18 @@ struct GBuf {
     __device__ __forceinline__ void stb(float x, int vb, int s = 0) const
     {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), r,
+                                              vb + ((s * 4) & 4095), (s * 4) & ~4095, 0);
+    }
+    // (re, im) pair at an 8-byte aligned byte offset
+    typedef unsigned int u32x2 __attribute__((vector_size(8)));
+    __device__ __forceinline__ v2f ldb2(int vb, int s = 0) const
+    {
+        const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(r, vb + ((s * 4) & 4095), (s * 4) & ~4095, 0);
+        return __builtin_bit_cast(v2f, r2);
+    }
+    __device__ __forceinline__ void stb2(v2f x, int vb, int s = 0) const
+    {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r,
                                               vb + ((s * 4) & 4095), (s * 4) & ~4095, 0);
     }
 };
@@ -113,7 +127,6 @@ struct cpx { float re, im; };
 // (re, im) in an aligned VGPR pair: v_pk_mul_f32 / v_pk_add_f32 issue at the rate of
 // the scalar forms on CDNA3/4, and broadcasts / swaps / sign flips ride on their op_sel
 // and neg modifiers.  Used where the data layout keeps pairs together end to end.
-typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f bc(float s) { return v2f{s, s}; }
 __device__ __forceinline__ v2f rot90(v2f a) { return v2f{-a.y, a.x}; }     // multiplication by i
 

@@ -224,7 +224,7 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
 #pragma unroll
     for (int j = HEAVY ? 0 : 13; j < 14; j++) {
         const int kv = opaque(kh * 8);
-        const v2f t = { SI.ldb(kv, HEAAC_PS_DELAY + j * dl_stride), SI.ldb(kv, HEAAC_PS_DELAY + j * dl_stride + 1) };
+        const v2f t = SI.ldb2(kv, HEAAC_PS_DELAY + j * dl_stride);
         hst[j] = clear_state ? zero : t;
     }
     // all-pass history: ring of 5 per link, position = time mod 5 (state j = time j - 5)
@@ -249,8 +249,7 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
 #pragma unroll
             for (int j = 0; j < 5; j++) {
                 const int kv = opaque(kh * 8);
-                const v2f t = { SI.ldb(kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride),
-                                SI.ldb(kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride + 1) };
+                const v2f t = SI.ldb2(kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride);
                 ring[m][j] = clear_state ? zero : t;
             }
         }
@@ -365,8 +364,7 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
             v = is_sub ? t : v;
         }
         const int kv = opaque(kh * 8);
-        SO.stb(v.x, kv, HEAAC_PS_DELAY + j * dl_stride);
-        SO.stb(v.y, kv, HEAAC_PS_DELAY + j * dl_stride + 1);
+        SO.stb2(v, kv, HEAAC_PS_DELAY + j * dl_stride);
     }
     if (allpass) {
         // times 27..31 sit at ring positions (27 + j) % 5
@@ -375,8 +373,7 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
 #pragma unroll
             for (int j = 0; j < 5; j++) {
                 const int kv = opaque(kh * 8);
-                SO.stb(ring[m][(27 + j) % 5].x, kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride);
-                SO.stb(ring[m][(27 + j) % 5].y, kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride + 1);
+                SO.stb2(ring[m][(27 + j) % 5], kv, HEAAC_PS_APDELAY + (m * 5 + j) * ap_stride);
             }
     }
 }

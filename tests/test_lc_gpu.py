@@ -83,6 +83,25 @@ def test_lc_in_place_state_and_odd_sizes(pkg, oracle, dev):
         assert np.array_equal(_bits(d_state.cpu().numpy()), _bits(ref_state))
 
 
+@pytest.mark.parametrize("fmt", ["f32", "s16"])
+def test_lc_mono_odd_counts(pkg, oracle, dev, fmt):
+    """SCE frames are paired two per wavefront: odd counts leave the last one alone."""
+    import torch
+    synth = _synth(pkg)
+    pf = pkg.PCM_F32 if fmt == "f32" else pkg.PCM_S16
+    for n in (1, 3, 77):
+        rng = np.random.default_rng(100 + n)
+        state = (rng.standard_normal((n, 512)) * 1e-3).astype(np.float32)
+        d_state = torch.from_numpy(state).cuda()
+        for coeffs, ics in synth.lc_stream(rng, n, 3, 1):
+            ref_pcm, state = oracle.lc_decode_batch(1, coeffs, ics, state, pf)
+            pcm, d_state = dev.lc_decode(1, torch.from_numpy(coeffs).cuda(), pkg.to_device(ics), d_state,
+                                         pcm_format=pf)
+            got = pcm.cpu().numpy()
+            assert np.array_equal(_bits(got), _bits(ref_pcm)) if fmt == "f32" else np.array_equal(got, ref_pcm)
+            assert np.array_equal(_bits(d_state.cpu().numpy()), _bits(state))
+
+
 def test_lc_empty_batch(pkg, dev):
     import torch
     z = torch.zeros((0, 2, 1024), device="cuda")
