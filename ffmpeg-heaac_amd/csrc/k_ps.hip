@@ -37,15 +37,24 @@ void k_ps(const float *__restrict__ g_tab, const HeaacPsFrame *__restrict__ g_ps
              s_pw[wave], s_Hs[wave], s_idx[wave][0], s_idx[wave][1],
              s_idx[wave][GENERAL ? 2 : 0], s_idx[wave][GENERAL ? 3 : 0] };
     const v2f no_cols[32] = {};
-    for (unsigned long long f = (unsigned long long)blockIdx.x * WAVES + wave; f < n;
-         f += (unsigned long long)gridDim.x * WAVES) {
-        if (ps_frame_is_general(&g_ps[f]) != GENERAL)
-            continue;                               // the other variant owns this frame
-        const HeaacSbrHeader &h = g_hdr[g_sbr[f].hdr];
-        const int top = h.kx + h.m;                 // ff_ps_apply(..., sbr->kx[1] + sbr->m[1])
-        float *XL = g_X + (f * 2) * (2 * 38 * 64);
-        ps_frame<GENERAL>(W, g_tab, &g_ps[f], top, g_state_in + f * state_words + off_ps,
-                          g_state_out + f * state_words + off_ps, XL, lane, wave, no_cols);
+    // Frames are dealt round-robin to the waves of the grid; a wave checks the ownership of its
+    // next 64 frames at once (one per lane), so a launch that owns few frames costs microseconds.
+    const unsigned long long wid = (unsigned long long)blockIdx.x * WAVES + wave;
+    const unsigned long long nw = (unsigned long long)gridDim.x * WAVES;
+    for (unsigned long long base = wid; base < n; base += nw * WAVE) {
+        const unsigned long long fl = base + (unsigned long long)lane * nw;
+        const bool mine = fl < n && ps_frame_is_general(&g_ps[fl]) == GENERAL;
+        unsigned long long todo = __ballot(mine);
+        while (todo) {
+            const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+            todo &= todo - 1;
+            const unsigned long long f = base + (unsigned long long)j * nw;
+            const HeaacSbrHeader &h = g_hdr[g_sbr[f].hdr];
+            const int top = h.kx + h.m;             // ff_ps_apply(..., sbr->kx[1] + sbr->m[1])
+            float *XL = g_X + (f * 2) * (2 * 38 * 64);
+            ps_frame<GENERAL>(W, g_tab, &g_ps[f], top, g_state_in + f * state_words + off_ps,
+                              g_state_out + f * state_words + off_ps, XL, lane, wave, no_cols);
+        }
     }
 }
 
