@@ -17,15 +17,22 @@ static __device__ unsigned long long g_hf_stamps[16];     // one copy per transl
 // exp2f(twice / 2.0f) for integer `twice`: exact powers of two, or sqrt(2)
 // (0x3FB504F3, what glibc's exp2f(0.5f) returns) times a power of two.
 // sbr_dequant's arguments are always multiples of 0.5 (aacsbr.c:1099-1125).
-__device__ __forceinline__ float exp2_half(int twice)
+__device__ __forceinline__ float exp2_half_normal(int twice)
 {
-    // outside the normal range (never reached by legal scalefactors): saturate
-    // like exp2f does; the denormal side is rounded once more than libm's
-    if (twice > 255) return __uint_as_float(0x7F800000u);
-    if (twice < -252) return twice < -400 ? 0.0f : exp2_half(twice + 256) * 2.938735877055719e-39f; // 2^-128
     const int e = twice >> 1;
     const unsigned mant = (twice & 1) ? 0x3FB504F3u : 0x3F800000u;
     return __uint_as_float(mant + ((unsigned)e << 23));
+}
+__device__ __forceinline__ float exp2_half(int twice)
+{
+    // outside the normal range (never reached by legal scalefactors): saturate
+    // like exp2f does; the denormal side is rounded once more than libm's.
+    // (No recursion: a recursive helper is not inlined and every call then
+    // saves and restores registers.)
+    if (twice > 255) return __uint_as_float(0x7F800000u);
+    if (twice < -252)
+        return twice < -400 ? 0.0f : exp2_half_normal(twice + 256) * 2.938735877055719e-39f;   // 2^-128
+    return exp2_half_normal(twice);
 }
 
 // ===========================================================================
