@@ -516,9 +516,39 @@ __device__ __forceinline__ void hf_channel(const HfWave &w, const float *g_noise
         // sliding window of X_low of the source row
         float2 x2 = make_float2(xrow[0], xrow[1]), x1 = make_float2(xrow[2], xrow[3]);
 
+        // Slots are walked in groups of four: the LDS reads of a group (X_low samples, noise
+        // table entries) are issued together ahead of the group's (uniform) branches, so the
+        // loop pays one LDS latency per group instead of several per slot.  The Y tail and
+        // X_low samples sbr_x_gen takes for the first slots (i < i_Temp <= 6) are fetched
+        // before the loop for the same reason.
+        float2 ytin[6], xlin[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            ytin[i] = make_float2(0.0f, 0.0f);
+            xlin[i] = make_float2(0.0f, 0.0f);
+            if (i < i_Temp) {
+                if (k >= kx_old && k < kx_old + m_old)
+                    ytin[i] = make_float2(ytail_in[(i * 64 + k) * 2], ytail_in[(i * 64 + k) * 2 + 1]);
+                if (k < kx_old && k < 32)
+                    xlin[i] = make_float2(w.xlow[k * XL_STRIDE + 2 * (i + ENV_ADJ)], w.xlow[k * XL_STRIDE + 2 * (i + ENV_ADJ) + 1]);
+            }
+        }
+        const unsigned noise0 = idxnoise + (unsigned)(m + 1) - (unsigned)(2 * t0) * (unsigned)m_max;
+        float2 xq[4], nq[4];
 #pragma unroll
         for (int i = 0; i < 38; i++) {
-            const float2 x0 = make_float2(xrow[2 * (i + ENV_ADJ)], xrow[2 * (i + ENV_ADJ) + 1]);
+            if ((i & 3) == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (i + j < 38) {
+                        xq[j] = make_float2(xrow[2 * (i + j + ENV_ADJ)], xrow[2 * (i + j + ENV_ADJ) + 1]);
+                        const unsigned in = (noise0 + (unsigned)(i + j) * (unsigned)m_max) & 0x1ff;
+                        nq[j] = make_float2(g_noise[2 * in], g_noise[2 * in + 1]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float2 x0 = xq[i & 3];
             if ((i & 1) == 0 && i <= 6 && i == 2 * t0 && h_SL) {
                 // seed the ring with the four history rows (:1630-1639)
 #pragma unroll
@@ -567,9 +597,9 @@ __device__ __forceinline__ void hf_channel(const HfWave &w, const float *g_noise
                         } else {
                             q_filt = q_e;              // q_temp[i][m], h_SL == 0
                         }
-                        const unsigned in = (idxnoise + (unsigned)slot * m_max + m + 1) & 0x1ff;
-                        yr += q_filt * g_noise[2 * in];
-                        yi += q_filt * g_noise[2 * in + 1];
+                        // sbr_noise_table[(f_indexnoise + slot * m_max + m + 1) & 0x1ff], prefetched
+                        yr += q_filt * nq[i & 3].x;
+                        yi += q_filt * nq[i & 3].y;
                     }
                 } else {
                     yr += s_e * (float)phi_re;
@@ -586,9 +616,9 @@ __device__ __forceinline__ void hf_channel(const HfWave &w, const float *g_noise
             float xo_r = 0.0f, xo_i = 0.0f;
             if (i < 6 && i < i_Temp) {
                 if (k < kx_old) {
-                    if (k < 32) { xo_r = w.xlow[k * XL_STRIDE + 2 * (i + ENV_ADJ)]; xo_i = w.xlow[k * XL_STRIDE + 2 * (i + ENV_ADJ) + 1]; }
+                    if (k < 32) { xo_r = xlin[i < 6 ? i : 0].x; xo_i = xlin[i < 6 ? i : 0].y; }
                 } else if (k < kx_old + m_old) {
-                    xo_r = ytail_in[(i * 64 + k) * 2]; xo_i = ytail_in[(i * 64 + k) * 2 + 1];
+                    xo_r = ytin[i < 6 ? i : 0].x; xo_i = ytin[i < 6 ? i : 0].y;
                 }
             } else {
                 if (k < kx) {
