@@ -118,6 +118,17 @@ __device__ __forceinline__ void xhigh3(float2 x2, float2 x1, float2 x0, const fl
     re = x2.x * a[0] - x2.y * a[1] + x1.x * a[2] - x1.y * a[3] + x0.x;
     im = x2.y * a[0] + x2.x * a[1] + x1.y * a[2] + x1.x * a[3] + x0.y;
 }
+// the same sums on (re, im) pairs: a * (i x) is written (-a, a) * swap(x), which the packed
+// multiply takes as op_sel / neg modifiers
+__device__ __forceinline__ v2f swp(v2f a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ v2f xhigh3_pk(v2f x2, v2f x1, v2f x0, const float *a)
+{
+    v2f t = bc(a[0]) * x2;
+    t = t + v2f{-a[1], a[1]} * swp(x2);
+    t = t + bc(a[2]) * x1;
+    t = t + v2f{-a[3], a[3]} * swp(x1);
+    return t + x0;
+}
 
 // emit(i, re, im) receives X[.][i][k] of this lane's band k = lane for the slots i = 0..37
 // (i is a compile-time constant at every call).
@@ -508,13 +519,15 @@ __device__ __forceinline__ void hf_channel(const HfWave &w, const float *g_noise
         const int phi_sign0 = (1 - 2 * (kx & 1)) * ((m & 1) ? -1 : 1);
         // g_temp / q_temp rows r = slot + h_SL kept as a ring of 5 (position r % 5);
         // rows 2 t0 .. 2 t0 + 3 hold the history, row slot + 4 the slot's own gain
-        float gr[5] = { 0, 0, 0, 0, 0 }, qr[5] = { 0, 0, 0, 0, 0 };
+        v2f gq[5];                                   // (g_temp, q_temp) rows of this band
+#pragma unroll
+        for (int j = 0; j < 5; j++) gq[j] = v2f{0.0f, 0.0f};
         // current envelope (uniform): advanced at even slots = 2 * t_env[e + 1]
         int e = 0, next_border = 2 * c.t_env[1];
         float g_e = gain[0], q_e = q_m[0], s_e = s_m[0];
         bool plain = (0 == c.e_a[0]) || (0 == c.e_a[1]);
         // sliding window of X_low of the source row
-        float2 x2 = make_float2(xrow[0], xrow[1]), x1 = make_float2(xrow[2], xrow[3]);
+        v2f x2 = v2f{xrow[0], xrow[1]}, x1 = v2f{xrow[2], xrow[3]};
 
         // Slots are walked in groups of four: the LDS reads of a group (X_low samples, noise
         // table entries) are issued together ahead of the group's (uniform) branches, so the
@@ -534,25 +547,25 @@ __device__ __forceinline__ void hf_channel(const HfWave &w, const float *g_noise
             }
         }
         const unsigned noise0 = idxnoise + (unsigned)(m + 1) - (unsigned)(2 * t0) * (unsigned)m_max;
-        float2 xq[4], nq[4];
+        v2f xq[4], nq[4];
 #pragma unroll
         for (int i = 0; i < 38; i++) {
             if ((i & 3) == 0) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (i + j < 38) {
-                        xq[j] = make_float2(xrow[2 * (i + j + ENV_ADJ)], xrow[2 * (i + j + ENV_ADJ) + 1]);
+                        xq[j] = v2f{xrow[2 * (i + j + ENV_ADJ)], xrow[2 * (i + j + ENV_ADJ) + 1]};
                         const unsigned in = (noise0 + (unsigned)(i + j) * (unsigned)m_max) & 0x1ff;
-                        nq[j] = make_float2(g_noise[2 * in], g_noise[2 * in + 1]);
+                        nq[j] = v2f{g_noise[2 * in], g_noise[2 * in + 1]};
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const float2 x0 = xq[i & 3];
+            const v2f x0 = xq[i & 3];
             if ((i & 1) == 0 && i <= 6 && i == 2 * t0 && h_SL) {
                 // seed the ring with the four history rows (:1630-1639)
 #pragma unroll
-                for (int j = 0; j < 4; j++) { gr[(i + j) % 5] = ghist[j]; qr[(i + j) % 5] = qhist[j]; }
+                for (int j = 0; j < 4; j++) gq[(i + j) % 5] = v2f{ghist[j], qhist[j]};
             }
             if ((i & 1) == 0 && i > 0 && i == next_border && e + 1 < num_env) {
                 e++;
@@ -563,49 +576,34 @@ __device__ __forceinline__ void hf_channel(const HfWave &w, const float *g_noise
                 s_e = e == 1 ? s_m[1] : e == 2 ? s_m[2] : e == 3 ? s_m[3] : s_m[4];
                 plain = (e == c.e_a[0]) || (e == c.e_a[1]);
             }
-            float yr = 0.0f, yi = 0.0f;
+            v2f Y = v2f{0.0f, 0.0f};
             const bool have_y = hf && i >= 2 * t0 && i < 2 * tL;
             if (have_y) {
-                float xr_, xi_;
-                if (has_src) xhigh3(x2, x1, x0, kc, xr_, xi_); else { xr_ = 0.0f; xi_ = 0.0f; }
-                gr[(i + 4) % 5] = g_e;
-                qr[(i + 4) % 5] = q_e;
-                float g_filt;
+                v2f xh = v2f{0.0f, 0.0f};
+                if (has_src) xh = xhigh3_pk(x2, x1, x0, kc);
+                gq[(i + 4) % 5] = v2f{g_e, q_e};
+                // (g_filt, q_filt): this slot's values, or the 5-tap smoothing of both rows at once
+                v2f f = v2f{g_e, q_e};
                 if (h_SL && !plain) {
-                    g_filt = 0.0f;
+                    v2f a = v2f{0.0f, 0.0f};
 #pragma unroll
-                    for (int j = 0; j < 5; j++) g_filt += gr[(i + 4 - j) % 5] * hs[j];
-                } else {
-                    g_filt = h_SL ? g_e : g_e;       // g_temp[i + h_SL][m] = this slot's gain
+                    for (int j = 0; j < 5; j++) a = a + gq[(i + 4 - j) % 5] * bc(hs[j]);
+                    f = a;
                 }
-                yr = xr_ * g_filt;
-                yi = xi_ * g_filt;
+                Y = xh * bc(f.x);
                 const int slot = i - 2 * t0;
                 const int isine = (idxsine + slot) & 3;
                 const int phi_re = isine == 0 ? 1 : isine == 2 ? -1 : 0;
                 const int phi_im = isine == 1 ? 1 : isine == 3 ? -1 : 0;
+                const v2f ph = v2f{(float)phi_re, (float)(phi_im * phi_sign0)};
                 if (!plain) {
-                    if (s_e) {
-                        yr += s_e * (float)phi_re;
-                        yi += s_e * (float)(phi_im * phi_sign0);
-                    } else {
-                        float q_filt;
-                        if (h_SL) {
-                            q_filt = 0.0f;
-#pragma unroll
-                            for (int j = 0; j < 5; j++) q_filt += qr[(i + 4 - j) % 5] * hs[j];
-                        } else {
-                            q_filt = q_e;              // q_temp[i][m], h_SL == 0
-                        }
-                        // sbr_noise_table[(f_indexnoise + slot * m_max + m + 1) & 0x1ff], prefetched
-                        yr += q_filt * nq[i & 3].x;
-                        yi += q_filt * nq[i & 3].y;
-                    }
+                    if (s_e) Y = Y + bc(s_e) * ph;
+                    else     Y = Y + bc(f.y) * nq[i & 3];   // sbr_noise_table[(f_indexnoise + slot m_max + m + 1) & 0x1ff]
                 } else {
-                    yr += s_e * (float)phi_re;
-                    yi += s_e * (float)(phi_im * phi_sign0);
+                    Y = Y + bc(s_e) * ph;
                 }
             }
+            const float yr = Y.x, yi = Y.y;
             // ytail: Y[1][32..37]
             if (i >= 32) {
                 const int o = ((i - 32) * 64 + k) * 2;
