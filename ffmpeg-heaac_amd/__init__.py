@@ -73,6 +73,20 @@ PS_FRAME_DT = np.dtype([
     ("iid_par", "i1", (5, 34)), ("icc_par", "i1", (5, 34)),
     ("ipd_par", "i1", (5, 17)), ("opd_par", "i1", (5, 17)), ("pad2", "u1", (2,)),
 ])
+TOOLS_ICS_DT = np.dtype([
+    ("num_windows", "u1"), ("num_window_groups", "u1"), ("max_sfb", "u1"), ("num_swb", "u1"),
+    ("tns_max_bands", "u1"), ("pad", "u1", (3,)), ("group_len", "u1", (8,)), ("swb_offset", "<u2", (64,)),
+])
+TNS_DT = np.dtype([
+    ("present", "u1"), ("n_filt", "u1", (8,)), ("length", "u1", (8, 4)), ("direction", "u1", (8, 4)),
+    ("order", "u1", (8, 4)), ("pad", "u1", (3,)), ("coef", "<f4", (8, 4, 20)),
+])
+TOOLS_CH_DT = np.dtype([("ics", TOOLS_ICS_DT), ("band_type", "u1", (128,)), ("sf", "<f4", (128,)), ("tns", TNS_DT)])
+TOOLS_FRAME_DT = np.dtype([
+    ("common_window", "u1"), ("ms_present", "u1"), ("pad", "u1", (2,)), ("ms_mask", "u1", (128,)),
+    ("ch", TOOLS_CH_DT, (2,)),
+])
+assert TOOLS_ICS_DT.itemsize == 144 and TNS_DT.itemsize == 2668 and TOOLS_FRAME_DT.itemsize == 7036
 assert SBR_HDR_DT.itemsize == 532 and SBR_CH_DT.itemsize == 336
 assert SBR_FRAME_DT.itemsize == 680 and PS_FRAME_DT.itemsize == 532
 
@@ -82,7 +96,7 @@ EXPORTED = [
     "heaac_device_create", "heaac_device_destroy", "heaac_device_workspace_bytes",
     "heaac_strerror", "heaac_imdct_half_batch", "heaac_lc_decode_batch",
     "heaac_he_decode_batch", "heaac_qmf_analysis_batch", "heaac_qmf_synthesis_batch",
-    "heaac_sbr_make_header", "heaac_build_info",
+    "heaac_sbr_make_header", "heaac_build_info", "heaac_spectral_tools_batch",
     # heaac_fft.h
     "ff_fft_init", "ff_fft_end", "ff_fft_permute", "ff_fft_calc",
     "ff_mdct_init", "ff_mdct_end", "ff_imdct_half", "ff_imdct_calc",
@@ -216,6 +230,16 @@ class Device:
                                            _ptr(state_out), _ptr(pcm), pcm_format, C.c_size_t(n), _stream()),
                "heaac_lc_decode_batch")
         return pcm, state_out
+
+    # -- spectral tools before the IMDCT (M/S, intensity stereo, TNS), in place --
+    def spectral_tools(self, channels, coeffs, tools):
+        import torch
+        n = coeffs.shape[0]
+        assert coeffs.dtype == torch.float32 and coeffs.numel() == n * channels * 1024
+        assert tools.dtype == torch.uint8 and tools.numel() == n * TOOLS_FRAME_DT.itemsize
+        _check(lib().heaac_spectral_tools_batch(self._h, channels, _ptr(coeffs), _ptr(tools), C.c_size_t(n),
+                                                _stream()), "heaac_spectral_tools_batch")
+        return coeffs
 
     # -- HE-AAC --
     def he_decode(self, cfg, coeffs, ics, sbr, hdr, ps, state_in, state_out=None, pcm=None,

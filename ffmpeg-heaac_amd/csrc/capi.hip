@@ -134,6 +134,18 @@ extern "C" int heaac_lc_decode_batch(HeaacDevice *dev, int channels,
                            d_pcm, pcm_format, n, (hipStream_t)stream);
 }
 
+extern "C" int heaac_spectral_tools_batch(HeaacDevice *dev, int channels, float *d_coeffs,
+                                          const HeaacToolsFrame *d_tools, size_t n, void *stream)
+{
+    if (!dev || channels < 1 || channels > 2)
+        return HEAAC_ERR_ARG;
+    if (n == 0)
+        return HEAAC_OK;
+    if (!d_coeffs || !d_tools)
+        return HEAAC_ERR_ARG;
+    return heaac_launch_spectral_tools(channels, d_coeffs, d_tools, n, (hipStream_t)stream);
+}
+
 extern "C" int heaac_he_decode_batch(HeaacDevice *dev, int cfg,
                                      const float *d_coeffs, const HeaacIcs *d_ics,
                                      const HeaacSbrFrame *d_sbr,

@@ -1,0 +1,167 @@
+// k_tools.hip -- spectral tools on the dequantised spectrum, before the IMDCT:
+// apply_mid_side_stereo (aacdec.c:1390-1411), apply_intensity_stereo (:1420-1451),
+// apply_tns (:1698-1736) with compute_lpc_coefs (lpc.h:61-103).
+//
+// One wavefront owns one channel element: both spectra (8 KiB) and the side-info record
+// sit in LDS.  M/S and intensity walk the scalefactor bands in the reference's order
+// (band conditions are wave-uniform) with the lanes spread over a band's coefficients.
+// TNS is an all-pole recursion along frequency -- serial by nature -- so one lane runs one
+// (channel, window): 2 lanes for long windows, 16 for eight short ones.  Every difference
+// and product is the reference's, in its order.
+#include "k_common.h"
+#include "kernels.h"
+
+#define TL_WAVES 8
+
+struct ToolsWave {
+    float coef[2][1024];
+    HeaacToolsFrame t;
+    float lpc[16][HEAAC_TNS_MAX_ORDER];      // per (channel, window) lane
+};
+
+__device__ __forceinline__ void tools_mid_side(ToolsWave &w, int lane)
+{
+    const HeaacToolsIcs &ics = w.t.ch[0].ics;
+    int idx = 0, base = 0;
+    for (int g = 0; g < ics.num_window_groups; g++) {
+        const int glen = ics.group_len[g];
+        for (int i = 0; i < ics.max_sfb; i++, idx++) {
+            if (w.t.ms_mask[idx] && w.t.ch[0].band_type[idx] < HEAAC_NOISE_BT &&
+                w.t.ch[1].band_type[idx] < HEAAC_NOISE_BT) {
+                const int o = ics.swb_offset[i], len = ics.swb_offset[i + 1] - o;
+                for (int e = lane; e < glen * len; e += WAVE) {
+                    const int group = e / len, k = e - group * len;
+                    const int p = base + group * 128 + o + k;
+                    const float a = w.coef[0][p], b = w.coef[1][p];     // butterflies_float_c
+                    w.coef[0][p] = a + b;
+                    w.coef[1][p] = a - b;
+                }
+            }
+        }
+        base += glen * 128;
+    }
+}
+
+__device__ __forceinline__ void tools_intensity(ToolsWave &w, int lane)
+{
+    const HeaacToolsIcs &ics = w.t.ch[1].ics;
+    int idx = 0, base = 0;
+    for (int g = 0; g < ics.num_window_groups; g++) {
+        const int glen = ics.group_len[g];
+        for (int i = 0; i < ics.max_sfb; i++, idx++) {
+            const int bt = w.t.ch[1].band_type[idx];
+            if (bt == HEAAC_INTENSITY_BT || bt == HEAAC_INTENSITY_BT2) {
+                int c = -1 + 2 * (bt - 14);
+                if (w.t.ms_present) c *= 1 - 2 * w.t.ms_mask[idx];
+                const float scale = c * w.t.ch[1].sf[idx];
+                const int o = ics.swb_offset[i], len = ics.swb_offset[i + 1] - o;
+                for (int e = lane; e < glen * len; e += WAVE) {
+                    const int group = e / len, k = e - group * len;
+                    const int p = base + group * 128 + o + k;
+                    w.coef[1][p] = scale * w.coef[0][p];
+                }
+            }
+        }
+        base += glen * 128;
+    }
+}
+
+// one lane = window `win` of channel `ch`
+__device__ __forceinline__ void tools_tns_window(ToolsWave &w, int ch, int win, float *lpc)
+{
+    const HeaacTns &tns = w.t.ch[ch].tns;
+    const HeaacToolsIcs &ics = w.t.ch[ch].ics;
+    float *coef = w.coef[ch];
+    const int mmm = ics.tns_max_bands < ics.max_sfb ? ics.tns_max_bands : ics.max_sfb;
+    int bottom = ics.num_swb;
+    for (int filt = 0; filt < tns.n_filt[win]; filt++) {
+        const int top = bottom;
+        bottom = top - tns.length[win][filt] > 0 ? top - tns.length[win][filt] : 0;
+        const int order = tns.order[win][filt];
+        if (order == 0) continue;
+        // compute_lpc_coefs(coef, order, lpc, 0, 0, 0)
+        for (int i = 0; i < order; i++) {
+            const float r = -tns.coef[win][filt][i];
+            lpc[i] = r;
+            for (int j = 0; j < (i + 1) >> 1; j++) {
+                const float f = lpc[j], b = lpc[i - 1 - j];
+                lpc[j]         = f + r * b;
+                lpc[i - 1 - j] = b + r * f;
+            }
+        }
+        int start = ics.swb_offset[bottom < mmm ? bottom : mmm];
+        const int end = ics.swb_offset[top < mmm ? top : mmm];
+        const int size = end - start;
+        if (size <= 0) continue;
+        int inc = 1;
+        if (tns.direction[win][filt]) { inc = -1; start = end - 1; }
+        start += win * 128;
+        // ar filter
+        for (int m = 0; m < size; m++, start += inc) {
+            float acc = coef[start];
+            const int lim = m < order ? m : order;
+            for (int i = 1; i <= lim; i++)
+                acc -= coef[start - i * inc] * lpc[i - 1];
+            coef[start] = acc;
+        }
+    }
+}
+
+template <int CH>
+__global__ __launch_bounds__(TL_WAVES * WAVE)
+void k_spectral_tools(float *g_coeffs, const HeaacToolsFrame *__restrict__ g_tools, unsigned long long n)
+{
+    __shared__ ToolsWave S[TL_WAVES];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
+    ToolsWave &w = S[wave];
+    for (unsigned long long f = (unsigned long long)blockIdx.x * TL_WAVES + wave; f < n;
+         f += (unsigned long long)gridDim.x * TL_WAVES) {
+        float *gc = g_coeffs + f * CH * 1024;
+        {
+            const float4 *c4 = reinterpret_cast<const float4 *>(gc);
+            float4 *d4 = reinterpret_cast<float4 *>(&w.coef[0][0]);
+#pragma unroll
+            for (int i = 0; i < 4 * CH; i++) d4[lane + 64 * i] = c4[lane + 64 * i];
+            const uint32_t *s = reinterpret_cast<const uint32_t *>(&g_tools[f]);
+            uint32_t *d = reinterpret_cast<uint32_t *>(&w.t);
+            for (int i = lane; i < (int)(sizeof(HeaacToolsFrame) / 4); i += WAVE) d[i] = s[i];
+        }
+        wave_sync();
+        if (CH == 2) {
+            if (w.t.common_window && w.t.ms_present) { tools_mid_side(w, lane); wave_sync(); }
+            tools_intensity(w, lane);
+            wave_sync();
+        }
+        {
+            // lane -> (channel, window)
+            const int ch = lane >> 3, win = lane & 7;
+            if (ch < CH && w.t.ch[ch].tns.present && win < w.t.ch[ch].ics.num_windows)
+                tools_tns_window(w, ch, win, w.lpc[lane]);
+        }
+        wave_sync();
+        {
+            float4 *c4 = reinterpret_cast<float4 *>(gc);
+            const float4 *d4 = reinterpret_cast<const float4 *>(&w.coef[0][0]);
+#pragma unroll
+            for (int i = 0; i < 4 * CH; i++) c4[lane + 64 * i] = d4[lane + 64 * i];
+        }
+        wave_sync();
+    }
+}
+
+extern "C" int heaac_launch_spectral_tools(int channels, float *d_coeffs, const HeaacToolsFrame *d_tools,
+                                           size_t n, hipStream_t s)
+{
+    if (n == 0) return HEAAC_OK;
+    unsigned long long g = (n + TL_WAVES - 1) / TL_WAVES;
+    if (g > 256) g = 256;
+    if (channels == 2)
+        hipLaunchKernelGGL(k_spectral_tools<2>, dim3((unsigned)g), dim3(TL_WAVES * WAVE), 0, s, d_coeffs, d_tools,
+                           (unsigned long long)n);
+    else if (channels == 1)
+        hipLaunchKernelGGL(k_spectral_tools<1>, dim3((unsigned)g), dim3(TL_WAVES * WAVE), 0, s, d_coeffs, d_tools,
+                           (unsigned long long)n);
+    else
+        return HEAAC_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
+}

@@ -282,3 +282,75 @@ def he_stream(rng, cfg, n, steps, hdr, ps_mode="20", hdr_choice=None, core_bins=
                 ps_chains[s].step(ps[s])
         first = False
         yield dict(coeffs=np.ascontiguousarray(coeffs), ics=np.ascontiguousarray(ics), sbr=sbr, ps=ps)
+
+
+# ---------------------------------------------------------------------------
+# Spectral tools (M/S, intensity stereo, TNS): side info as the parser leaves it.
+# Band layouts are the 48 kHz ones (ISO/IEC 14496-3 Tables 4.129 / 4.130 =
+# swb_offset_1024_48 / swb_offset_128_48, tns_max_bands 40 / 14; aactab.c:1107-1120, 1200-1206).
+# ---------------------------------------------------------------------------
+SWB_1024_48 = [0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 48, 56, 64, 72, 80, 88, 96, 108, 120, 132, 144, 160,
+               176, 196, 216, 240, 264, 292, 320, 352, 384, 416, 448, 480, 512, 544, 576, 608, 640, 672, 704,
+               736, 768, 800, 832, 864, 896, 928, 1024]
+SWB_128_48 = [0, 4, 8, 12, 16, 20, 28, 36, 44, 56, 68, 80, 96, 112, 128]
+
+
+def _tools_ics(rng, ics, short):
+    off = SWB_128_48 if short else SWB_1024_48
+    ics["num_windows"] = 8 if short else 1
+    ics["num_swb"] = len(off) - 1
+    ics["tns_max_bands"] = 14 if short else 40
+    ics["max_sfb"] = rng.integers(4, len(off)) if rng.random() < 0.8 else len(off) - 1
+    ics["swb_offset"][: len(off)] = off
+    if short:
+        # a random grouping of the eight windows (scale_factor_grouping)
+        cuts = np.flatnonzero(rng.random(7) < 0.4) + 1
+        edges = np.concatenate(([0], cuts, [8]))
+        lens = np.diff(edges)
+        ics["num_window_groups"] = len(lens)
+        ics["group_len"][: len(lens)] = lens
+    else:
+        ics["num_window_groups"] = 1
+        ics["group_len"][0] = 1
+
+
+def tools_frames(rng, pkg, n, channels=2):
+    """n HeaacToolsFrame records with every tool exercised (and the degenerate cases: zero-length
+    and zero-order filters, ranges clipped by max_sfb / tns_max_bands, both directions)."""
+    t = np.zeros(n, pkg.TOOLS_FRAME_DT)
+    for f in range(n):
+        fr = t[f]
+        short = rng.random() < 0.3
+        fr["common_window"] = channels == 2 and rng.random() < 0.8
+        fr["ms_present"] = rng.integers(0, 3) if channels == 2 else 0
+        fr["ms_mask"] = 1 if fr["ms_present"] == 2 else (rng.random(128) < 0.5)
+        _tools_ics(rng, fr["ch"][0]["ics"], short)
+        if fr["common_window"]:
+            fr["ch"][1]["ics"] = fr["ch"][0]["ics"]
+        else:
+            _tools_ics(rng, fr["ch"][1]["ics"], rng.random() < 0.3)
+        for c in range(channels):
+            ch = fr["ch"][c]
+            nb = int(ch["ics"]["num_window_groups"]) * int(ch["ics"]["max_sfb"])
+            r = rng.random(128)
+            bt = rng.integers(1, 12, 128)                 # spectral codebooks
+            bt[r < 0.10] = 0                              # ZERO_BT
+            bt[(r >= 0.10) & (r < 0.15)] = 13             # NOISE_BT
+            if c == 1:
+                bt[(r >= 0.15) & (r < 0.25)] = 14         # INTENSITY_BT2
+                bt[(r >= 0.25) & (r < 0.35)] = 15         # INTENSITY_BT
+            ch["band_type"] = bt
+            ch["band_type"][nb:] = 0
+            ch["sf"] = np.exp2(rng.integers(-12, 8, 128) / 4.0).astype(np.float32)
+            tns = ch["tns"]
+            tns["present"] = rng.random() < 0.5
+            nw = int(ch["ics"]["num_windows"])
+            for w in range(nw):
+                tns["n_filt"][w] = rng.integers(0, 2 if nw == 8 else 4)
+                for k in range(int(tns["n_filt"][w])):
+                    tns["length"][w][k] = rng.integers(0, int(ch["ics"]["num_swb"]) + 1)
+                    tns["order"][w][k] = rng.integers(0, 8 if nw == 8 else 13) if rng.random() < 0.9 else 20
+                    tns["direction"][w][k] = rng.integers(0, 2)
+                    q = rng.integers(-8, 8, 20)
+                    tns["coef"][w][k] = np.sin(q * np.pi / 17.0).astype(np.float32)
+    return t

@@ -300,6 +300,63 @@ int heaac_qmf_synthesis_batch(HeaacDevice *dev, const float *d_X,
                               float *d_out, float scale, float bias,
                               size_t n, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Spectral tools that run on the dequantised spectrum before the IMDCT
+ * (SURVEY s8f N1): apply_mid_side_stereo (aacdec.c:1390-1411),
+ * apply_intensity_stereo (:1420-1451) and apply_tns (:1698-1736, with
+ * compute_lpc_coefs, lpc.h:61-103).  With them the host/GPU boundary moves up
+ * to "dequantised spectrum + side info".
+ * ------------------------------------------------------------------------ */
+enum { HEAAC_NOISE_BT = 13, HEAAC_INTENSITY_BT2 = 14, HEAAC_INTENSITY_BT = 15 };   /* aac.h:73-80 */
+#define HEAAC_TNS_MAX_ORDER 20
+
+/* the fields of IndividualChannelStream the tools read (aac.h:128-152) */
+typedef struct HeaacToolsIcs {
+    uint8_t  num_windows;             /* 1 or 8 */
+    uint8_t  num_window_groups;
+    uint8_t  max_sfb;
+    uint8_t  num_swb;
+    uint8_t  tns_max_bands;
+    uint8_t  pad[3];
+    uint8_t  group_len[8];
+    uint16_t swb_offset[64];          /* ics->swb_offset[0 .. num_swb] */
+} HeaacToolsIcs;                      /* 144 B */
+
+/* TemporalNoiseShaping (aac.h:178-185) */
+typedef struct HeaacTns {
+    uint8_t present;
+    uint8_t n_filt[8];
+    uint8_t length[8][4];
+    uint8_t direction[8][4];
+    uint8_t order[8][4];
+    uint8_t pad[3];
+    float   coef[8][4][HEAAC_TNS_MAX_ORDER];
+} HeaacTns;                           /* 2668 B */
+
+typedef struct HeaacToolsChannel {
+    HeaacToolsIcs ics;
+    uint8_t  band_type[128];          /* sce->band_type[idx], idx = g * max_sfb + sfb.  The runs the
+                                         reference walks (band_type_run_end) are implied: all bands of a
+                                         run share one type, so testing every band is the same walk. */
+    float    sf[128];                 /* sce->sf[idx] (first 120 used) */
+    HeaacTns tns;
+} HeaacToolsChannel;                  /* 3452 B */
+
+typedef struct HeaacToolsFrame {
+    uint8_t  common_window;           /* CPE only: both channels share ch[0].ics */
+    uint8_t  ms_present;              /* 0: off, 1: ms_mask, 2: all bands (mask already all ones) */
+    uint8_t  pad[2];
+    uint8_t  ms_mask[128];            /* cpe->ms_mask[idx] */
+    HeaacToolsChannel ch[2];
+} HeaacToolsFrame;                    /* 7036 B */
+
+/* In place on d_coeffs [n][channels][1024].  channels == 2: M/S (if common_window and
+ * ms_present), intensity stereo, then TNS per channel -- the order of decode_cpe
+ * (aacdec.c:1480-1492) followed by spectral_to_sample (:1913-1916).  channels == 1: TNS of
+ * ch[0] only. */
+int heaac_spectral_tools_batch(HeaacDevice *dev, int channels, float *d_coeffs,
+                               const HeaacToolsFrame *d_tools, size_t n, void *stream);
+
 /* Host-side helper (no GPU): derive the frequency-band tables of one SBR
  * header -- sbr_make_f_master/f_derived/hf_calc_npatches/f_tablelim
  * (aacsbr.c:146-205, 296-593).  sample_rate is the SBR (output) rate.

@@ -1,0 +1,135 @@
+/* or_tools.c -- CPU restatement of the spectral tools that precede the IMDCT
+ * (SURVEY.md s8f N1).  TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * PARITY UNPINNED by the reference: its tree holds no test or vector for these
+ * functions; tests/test_oracle_props.py checks domain properties (M/S
+ * butterflies are 2x an involution, TNS with a zero filter is the identity,
+ * the all-pole TNS filter undoes the matching FIR, intensity bands are exact
+ * scaled copies).
+ */
+#include <string.h>
+#include "oracle.h"
+
+/* butterflies_float_c, dsputil.c:3899-3908 */
+static void butterflies_float(float *v1, float *v2, int len)
+{
+    for (int i = 0; i < len; i++) {
+        float t = v1[i] - v2[i];
+        v1[i] += v2[i];
+        v2[i] = t;
+    }
+}
+
+/* apply_mid_side_stereo, aacdec.c:1390-1411 */
+static void or_mid_side(const HeaacToolsFrame *t, float *ch0, float *ch1)
+{
+    const HeaacToolsIcs *ics = &t->ch[0].ics;
+    int idx = 0;
+    for (int g = 0; g < ics->num_window_groups; g++) {
+        for (int i = 0; i < ics->max_sfb; i++, idx++) {
+            if (t->ms_mask[idx] &&
+                t->ch[0].band_type[idx] < HEAAC_NOISE_BT && t->ch[1].band_type[idx] < HEAAC_NOISE_BT) {
+                for (int group = 0; group < ics->group_len[g]; group++)
+                    butterflies_float(ch0 + group * 128 + ics->swb_offset[i],
+                                      ch1 + group * 128 + ics->swb_offset[i],
+                                      ics->swb_offset[i + 1] - ics->swb_offset[i]);
+            }
+        }
+        ch0 += ics->group_len[g] * 128;
+        ch1 += ics->group_len[g] * 128;
+    }
+}
+
+/* apply_intensity_stereo, aacdec.c:1420-1451.  The reference skips whole runs of equal
+ * band type (band_type_run_end); testing each band visits the same bands. */
+static void or_intensity(const HeaacToolsFrame *t, float *coef0, float *coef1)
+{
+    const HeaacToolsIcs *ics = &t->ch[1].ics;
+    const HeaacToolsChannel *sce1 = &t->ch[1];
+    int idx = 0;
+    for (int g = 0; g < ics->num_window_groups; g++) {
+        for (int i = 0; i < ics->max_sfb; i++, idx++) {
+            if (sce1->band_type[idx] == HEAAC_INTENSITY_BT || sce1->band_type[idx] == HEAAC_INTENSITY_BT2) {
+                int c = -1 + 2 * (sce1->band_type[idx] - 14);
+                if (t->ms_present)
+                    c *= 1 - 2 * t->ms_mask[idx];
+                const float scale = c * sce1->sf[idx];
+                for (int group = 0; group < ics->group_len[g]; group++)
+                    for (int k = ics->swb_offset[i]; k < ics->swb_offset[i + 1]; k++)
+                        coef1[group * 128 + k] = scale * coef0[group * 128 + k];
+            }
+        }
+        coef0 += ics->group_len[g] * 128;
+        coef1 += ics->group_len[g] * 128;
+    }
+}
+
+/* compute_lpc_coefs(autoc, order, lpc, 0, 0, 0), lpc.h:61-103 with LPC_TYPE float */
+static void or_lpc_coefs(const float *autoc, int max_order, float *lpc)
+{
+    for (int i = 0; i < max_order; i++) {
+        float r = -autoc[i];
+        lpc[i] = r;
+        for (int j = 0; j < (i + 1) >> 1; j++) {
+            float f = lpc[j];
+            float b = lpc[i - 1 - j];
+            lpc[j]         = f + r * b;
+            lpc[i - 1 - j] = b + r * f;
+        }
+    }
+}
+
+#define OR_MIN(a, b) ((a) < (b) ? (a) : (b))
+#define OR_MAX(a, b) ((a) > (b) ? (a) : (b))
+
+/* apply_tns(coef, tns, ics, decode = 1), aacdec.c:1698-1736 */
+static void or_tns(float coef[1024], const HeaacTns *tns, const HeaacToolsIcs *ics)
+{
+    const int mmm = OR_MIN(ics->tns_max_bands, ics->max_sfb);
+    float lpc[HEAAC_TNS_MAX_ORDER];
+    for (int w = 0; w < ics->num_windows; w++) {
+        int bottom = ics->num_swb;
+        for (int filt = 0; filt < tns->n_filt[w]; filt++) {
+            const int top = bottom;
+            bottom = OR_MAX(0, top - tns->length[w][filt]);
+            const int order = tns->order[w][filt];
+            if (order == 0)
+                continue;
+            or_lpc_coefs(tns->coef[w][filt], order, lpc);
+            int start = ics->swb_offset[OR_MIN(bottom, mmm)];
+            const int end = ics->swb_offset[OR_MIN(top, mmm)];
+            const int size = end - start;
+            int inc;
+            if (size <= 0)
+                continue;
+            if (tns->direction[w][filt]) {
+                inc = -1;
+                start = end - 1;
+            } else {
+                inc = 1;
+            }
+            start += w * 128;
+            for (int m = 0; m < size; m++, start += inc)
+                for (int i = 1; i <= OR_MIN(m, order); i++)
+                    coef[start] -= coef[start - i * inc] * lpc[i - 1];
+        }
+    }
+}
+
+/* decode_cpe's tail (aacdec.c:1483-1492) + spectral_to_sample's TNS calls (:1913-1916) */
+void oracle_spectral_tools_batch(int channels, float *coeffs, const HeaacToolsFrame *tools, size_t n)
+{
+    for (size_t f = 0; f < n; f++) {
+        const HeaacToolsFrame *t = &tools[f];
+        float *c0 = coeffs + f * (size_t)channels * 1024, *c1 = c0 + 1024;
+        if (channels == 2) {
+            if (t->common_window && t->ms_present)
+                or_mid_side(t, c0, c1);
+            or_intensity(t, c0, c1);
+        }
+        if (t->ch[0].tns.present)
+            or_tns(c0, &t->ch[0].tns, &t->ch[0].ics);
+        if (channels == 2 && t->ch[1].tns.present)
+            or_tns(c1, &t->ch[1].tns, &t->ch[1].ics);
+    }
+}

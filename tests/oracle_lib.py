@@ -180,6 +180,14 @@ def lc_decode_batch(channels, coeffs, ics, state_in, pcm_format=PCM_F32):
     return pcm, state_out
 
 
+def spectral_tools_batch(channels, coeffs, tools):
+    """M/S + intensity + TNS on a copy of coeffs [n][channels][1024]."""
+    out = np.ascontiguousarray(coeffs, np.float32).copy()
+    tools = np.ascontiguousarray(tools)
+    lib().oracle_spectral_tools_batch(C.c_int(channels), _p(out), _p(tools), C.c_size_t(out.shape[0]))
+    return out
+
+
 def he_decode_batch(cfg, coeffs, ics, sbr, hdr, ps, state_in, pcm_format=PCM_F32):
     coeffs = _f32(coeffs)
     n = coeffs.shape[0]

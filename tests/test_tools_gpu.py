@@ -1,0 +1,58 @@
+"""Spectral tools before the IMDCT: HIP path vs oracle, bit-exact."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _synth():
+    import __graft_entry__ as g
+    return importlib.import_module(g.PKG_NAME + ".synth")
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+@pytest.mark.parametrize("n", [1, 7, 300])
+def test_spectral_tools_match_oracle(pkg, oracle, dev, channels, n):
+    import torch
+    rng = np.random.default_rng(7 * n + channels)
+    tools = _synth().tools_frames(rng, pkg, n, channels)
+    coeffs = (rng.standard_normal((n, channels, 1024)) * 1e-4).astype(np.float32)
+    ref = oracle.spectral_tools_batch(channels, coeffs, tools)
+    d = torch.from_numpy(coeffs).cuda()
+    dev.spectral_tools(channels, d, pkg.to_device(tools))
+    assert np.array_equal(_bits(d.cpu().numpy()), _bits(ref))
+    # the tools did something on this batch
+    assert n < 7 or not np.array_equal(_bits(ref), _bits(coeffs))
+
+
+def test_spectral_tools_then_lc_decode(pkg, oracle, dev):
+    """tools -> imdct_and_windowing: the prefix of spectral_to_sample (aacdec.c:1903-1925)."""
+    import torch
+    synth = _synth()
+    rng = np.random.default_rng(99)
+    n = 64
+    coeffs, ics = next(synth.lc_stream(rng, n, 1, 2))
+    tools = synth.tools_frames(rng, pkg, n, 2)
+    # keep the window layout of the tools consistent with the frame's window sequence
+    state = (rng.standard_normal((n, 1024)) * 1e-3).astype(np.float32)
+    ref_c = oracle.spectral_tools_batch(2, coeffs, tools)
+    ref_pcm, ref_state = oracle.lc_decode_batch(2, ref_c, ics, state, pkg.PCM_S16)
+    d = torch.from_numpy(coeffs).cuda()
+    dev.spectral_tools(2, d, pkg.to_device(tools))
+    pcm, st = dev.lc_decode(2, d, pkg.to_device(ics), torch.from_numpy(state).cuda(), pcm_format=pkg.PCM_S16)
+    assert np.array_equal(pcm.cpu().numpy(), ref_pcm)
+    assert np.array_equal(_bits(st.cpu().numpy()), _bits(ref_state))
+
+
+def test_spectral_tools_empty_and_bad_args(pkg, dev):
+    import torch
+    z = torch.zeros((0, 2, 1024), device="cuda")
+    dev.spectral_tools(2, z, torch.zeros(0, dtype=torch.uint8, device="cuda"))
+    with pytest.raises(pkg.HeaacError):
+        pkg._check(pkg.lib().heaac_spectral_tools_batch(dev._h, 3, None, None, 1, None), "bad channels")
