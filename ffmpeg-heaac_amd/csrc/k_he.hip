@@ -308,20 +308,22 @@ __device__ __forceinline__ void synth_channel(const SynLds &S, SynWave &w, const
 #pragma unroll
         for (int j = 0; j < 10; j++) wt[j] = S.win[64 * j + n];
         const bool scale_and_bias = scale != 1.0f || bias != 0.0f;
-        for (int i = 0; i < 32; i++) {
-            const float *v = w.vb + (31 - i) * VB_STRIDE + n;
-            float acc = v[0] * wt[0] + 0.0f;
-            acc = v[1 * VB_STRIDE + 64] * wt[1] + acc;
-            acc = v[2 * VB_STRIDE]      * wt[2] + acc;
-            acc = v[3 * VB_STRIDE + 64] * wt[3] + acc;
-            acc = v[4 * VB_STRIDE]      * wt[4] + acc;
-            acc = v[5 * VB_STRIDE + 64] * wt[5] + acc;
-            acc = v[6 * VB_STRIDE]      * wt[6] + acc;
-            acc = v[7 * VB_STRIDE + 64] * wt[7] + acc;
-            acc = v[8 * VB_STRIDE]      * wt[8] + acc;
-            acc = v[9 * VB_STRIDE + 64] * wt[9] + acc;
-            if (scale_and_bias) acc = acc * scale + bias;
-            emit(i, n, acc);
+        // two slots per packed multiply / add: (slot i, slot i + 1) share the window taps
+        for (int i = 0; i < 32; i += 2) {
+            const float *va = w.vb + (31 - i) * VB_STRIDE + n, *vb = va - VB_STRIDE;
+            v2f acc = v2f{va[0], vb[0]} * bc(wt[0]) + v2f{0.0f, 0.0f};
+            acc = v2f{va[1 * VB_STRIDE + 64], vb[1 * VB_STRIDE + 64]} * bc(wt[1]) + acc;
+            acc = v2f{va[2 * VB_STRIDE],      vb[2 * VB_STRIDE]}      * bc(wt[2]) + acc;
+            acc = v2f{va[3 * VB_STRIDE + 64], vb[3 * VB_STRIDE + 64]} * bc(wt[3]) + acc;
+            acc = v2f{va[4 * VB_STRIDE],      vb[4 * VB_STRIDE]}      * bc(wt[4]) + acc;
+            acc = v2f{va[5 * VB_STRIDE + 64], vb[5 * VB_STRIDE + 64]} * bc(wt[5]) + acc;
+            acc = v2f{va[6 * VB_STRIDE],      vb[6 * VB_STRIDE]}      * bc(wt[6]) + acc;
+            acc = v2f{va[7 * VB_STRIDE + 64], vb[7 * VB_STRIDE + 64]} * bc(wt[7]) + acc;
+            acc = v2f{va[8 * VB_STRIDE],      vb[8 * VB_STRIDE]}      * bc(wt[8]) + acc;
+            acc = v2f{va[9 * VB_STRIDE + 64], vb[9 * VB_STRIDE + 64]} * bc(wt[9]) + acc;
+            if (scale_and_bias) acc = acc * bc(scale) + bc(bias);
+            emit(i, n, acc.x);
+            emit(i + 1, n, acc.y);
         }
     }
     // new ring state: slots 31..23
