@@ -528,6 +528,53 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
             }
         }
     }
+    // ---- parameter remapping (aacps.c:817-860), then every HBM / table read of the later
+    // phases is issued here so that it is in flight during the hybrid filters, the band
+    // powers and the transient detector: H-matrix LUT rows, H of the previous frame,
+    // IPD/OPD histories, smoother state ----
+    for (int t = lane; t < 5 * WT::NPAR; t += WAVE) {
+        const int e = t / WT::NPAR, b = t % WT::NPAR;
+        int iid = 0, icc = 0, ipd = 0, opd = 0;
+        if (e < p.num_env && b < nr_par) {
+            iid = remap_idx(p.iid_par[e], p.nr_iid_par, is34, b);
+            icc = remap_idx(p.icc_par[e], p.nr_icc_par, is34, b);
+            if (p.enable_ipdopd && b < 17) {
+                ipd = remap_idx(p.ipd_par[e], p.nr_ipdopd_par, is34, b);
+                opd = remap_idx(p.opd_par[e], p.nr_ipdopd_par, is34, b);
+            }
+        }
+        w.iid_m[e][b] = (signed char)iid; w.icc_m[e][b] = (signed char)icc;
+        if constexpr (GENERAL) { w.ipd_m[e][b] = (signed char)ipd; w.opd_m[e][b] = (signed char)opd; }
+    }
+    wave_sync();
+    constexpr int NHL = (WT::NH * WT::NPAR + WAVE - 1) / WAVE;
+    float hl[5][4], hrow[NHL], tr_peak = 0.0f, tr_smooth = 0.0f, tr_diff = 0.0f;
+    int opd_hist0 = 0, ipd_hist0 = 0;
+#pragma unroll
+    for (int e = 0; e < 5; e++) hl[e][0] = hl[e][1] = hl[e][2] = hl[e][3] = 0.0f;
+    if (lane < 34) {
+        const signed char *hist = reinterpret_cast<const signed char *>(st_in + HEAAC_PS_HIST);
+        opd_hist0 = hist[lane]; ipd_hist0 = hist[34 + lane];
+        tr_peak = SI.ld(lane, HEAAC_PS_PEAK); tr_smooth = SI.ld(lane, HEAAC_PS_PSMOOTH);
+        tr_diff = SI.ld(lane, HEAAC_PS_PDIFF);
+    }
+    if (lane < nr_par) {
+        const int b = lane;
+        const float *LUT = g_tab + ((p.icc_mode < 3) ? TB_HA : TB_HB);
+#pragma unroll
+        for (int e = 0; e < 5; e++) {
+            const int ee = e < p.num_env ? e : 0;
+            const float4 h4 = *reinterpret_cast<const float4 *>(
+                LUT + ((w.iid_m[ee][b] + 7 + 23 * p.iid_quant) * 8 + w.icc_m[ee][b]) * 4);
+            hl[e][0] = h4.x; hl[e][1] = h4.y; hl[e][2] = h4.z; hl[e][3] = h4.w;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NHL; i++) {
+        const int t = lane + WAVE * i, j = t / WT::NPAR, b = t % WT::NPAR;
+        hrow[i] = t < WT::NH * WT::NPAR ? SI.ld((GENERAL ? j : 2 * j) * 34 + b, HEAAC_PS_H) : 0.0f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
     // ---- hybrid filters -> sub[ks][n] ----
     for (int t = lane; t < nsub * 32; t += WAVE) {
         const int ks = t >> 5, n = t & 31;
@@ -593,7 +640,7 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     // ---- transient detection (:681-692), one lane per parameter band ----
     if (lane < nr_par) {
         const int i = lane;
-        float peak = SI.ld(i, HEAAC_PS_PEAK), smooth = SI.ld(i, HEAAC_PS_PSMOOTH), diff = SI.ld(i, HEAAC_PS_PDIFF);
+        float peak = tr_peak, smooth = tr_smooth, diff = tr_diff;
         if (switched) { peak = 0.0f; smooth = 0.0f; diff = 0.0f; }
         float prow[32];
 #pragma unroll
@@ -614,52 +661,31 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     } else if (lane < 34) {
         // parameter bands 20..33 are not touched in 20-band mode
         const int i = lane;
-        const float a = SI.ld(i, HEAAC_PS_PEAK), b = SI.ld(i, HEAAC_PS_PSMOOTH), c = SI.ld(i, HEAAC_PS_PDIFF);
-        SO.st(switched ? 0.0f : a, i, HEAAC_PS_PEAK);
-        SO.st(switched ? 0.0f : b, i, HEAAC_PS_PSMOOTH);
-        SO.st(switched ? 0.0f : c, i, HEAAC_PS_PDIFF);
+        SO.st(switched ? 0.0f : tr_peak, i, HEAAC_PS_PEAK);
+        SO.st(switched ? 0.0f : tr_smooth, i, HEAAC_PS_PSMOOTH);
+        SO.st(switched ? 0.0f : tr_diff, i, HEAAC_PS_PDIFF);
     }
 
     STAMP(4);
     lane = opaque(lane);
     // ---- parameter remapping + H matrices (aacps.c:817-899) ----
-    for (int t = lane; t < 5 * WT::NPAR; t += WAVE) {
-        const int e = t / WT::NPAR, b = t % WT::NPAR;
-        int iid = 0, icc = 0, ipd = 0, opd = 0;
-        if (e < p.num_env && b < nr_par) {
-            iid = remap_idx(p.iid_par[e], p.nr_iid_par, is34, b);
-            icc = remap_idx(p.icc_par[e], p.nr_icc_par, is34, b);
-            if (p.enable_ipdopd && b < 17) {
-                ipd = remap_idx(p.ipd_par[e], p.nr_ipdopd_par, is34, b);
-                opd = remap_idx(p.opd_par[e], p.nr_ipdopd_par, is34, b);
-            }
-        }
-        w.iid_m[e][b] = (signed char)iid; w.icc_m[e][b] = (signed char)icc;
-        if constexpr (GENERAL) { w.ipd_m[e][b] = (signed char)ipd; w.opd_m[e][b] = (signed char)opd; }
-    }
     // row 0 = H of the last envelope of the previous frame, remapped on a 20<->34 switch
-    for (int t = lane; t < WT::NH * WT::NPAR; t += WAVE) {
-        const int j = t / WT::NPAR, b = t % WT::NPAR;
-        const float *row = st_in + HEAAC_PS_H + (GENERAL ? j : 2 * j) * 34;   // baseline keeps the real rows
-        w.Hs[0][j][b] = switched ? remap_val(row, is34, b) : row[b];
+#pragma unroll
+    for (int i = 0; i < NHL; i++) {
+        const int t = lane + WAVE * i, j = t / WT::NPAR, b = t % WT::NPAR;
+        if (t < WT::NH * WT::NPAR) {
+            float v = hrow[i];
+            if (switched) v = remap_val(st_in + HEAAC_PS_H + (GENERAL ? j : 2 * j) * 34, is34, b);
+            w.Hs[0][j][b] = v;                 // baseline keeps the real rows only
+        }
     }
     wave_sync();
     if (lane < nr_par) {
         const int b = lane;
-        const float *LUT = g_tab + ((p.icc_mode < 3) ? TB_HA : TB_HB);
-        const signed char *hist = reinterpret_cast<const signed char *>(st_in + HEAAC_PS_HIST);
-        int opd_hist = hist[b], ipd_hist = hist[34 + b];
+        int opd_hist = opd_hist0, ipd_hist = ipd_hist0;
         if (switched && b < 17) { opd_hist = 0; ipd_hist = 0; }        // ipdopd_reset
-        // fetch every envelope's LUT row first (independent loads), then run the
-        // IPD/OPD history chain over them
-        float hl[5][4];
-#pragma unroll
-        for (int e = 0; e < 5; e++) {
-            const int ee = e < p.num_env ? e : 0;
-            const float4 h4 = *reinterpret_cast<const float4 *>(
-                LUT + ((w.iid_m[ee][b] + 7 + 23 * p.iid_quant) * 8 + w.icc_m[ee][b]) * 4);
-            hl[e][0] = h4.x; hl[e][1] = h4.y; hl[e][2] = h4.z; hl[e][3] = h4.w;
-        }
+        // (the LUT rows hl[e] of every envelope were fetched ahead; the IPD/OPD history
+        // chain runs over them)
 #pragma unroll
         for (int e = 0; e < 5; e++) {
             if (e >= p.num_env) break;
@@ -694,10 +720,9 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
         ho[b] = (signed char)opd_hist;
         ho[34 + b] = (signed char)ipd_hist;
     } else if (lane < 34) {
-        const signed char *hist = reinterpret_cast<const signed char *>(st_in + HEAAC_PS_HIST);
         signed char *ho = reinterpret_cast<signed char *>(st_out + HEAAC_PS_HIST);
-        ho[lane] = hist[lane];
-        ho[34 + lane] = hist[34 + lane];
+        ho[lane] = (signed char)opd_hist0;
+        ho[34 + lane] = (signed char)ipd_hist0;
     }
     if (lane == 0) {
         signed char *ho = reinterpret_cast<signed char *>(st_out + HEAAC_PS_HIST);
