@@ -232,13 +232,17 @@ class Device:
         return pcm, state_out
 
     # -- spectral tools before the IMDCT (M/S, intensity stereo, TNS), in place --
-    def spectral_tools(self, channels, coeffs, tools):
+    def spectral_tools(self, channels, coeffs, tools, rng=None):
+        """rng: int32 [n] generator states (updated in place) -> noise substitution runs too."""
         import torch
         n = coeffs.shape[0]
         assert coeffs.dtype == torch.float32 and coeffs.numel() == n * channels * 1024
         assert tools.dtype == torch.uint8 and tools.numel() == n * TOOLS_FRAME_DT.itemsize
-        _check(lib().heaac_spectral_tools_batch(self._h, channels, _ptr(coeffs), _ptr(tools), C.c_size_t(n),
-                                                _stream()), "heaac_spectral_tools_batch")
+        assert rng is None or (rng.dtype == torch.int32 and rng.numel() == n)
+        _check(lib().heaac_spectral_tools_batch(self._h, channels, _ptr(coeffs), _ptr(tools),
+                                                _ptr(rng) if rng is not None else None,
+                                                _ptr(rng) if rng is not None else None,
+                                                C.c_size_t(n), _stream()), "heaac_spectral_tools_batch")
         return coeffs
 
     # -- HE-AAC --

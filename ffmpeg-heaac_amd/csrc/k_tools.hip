@@ -19,6 +19,44 @@ struct ToolsWave {
     float lpc[16][HEAAC_TNS_MAX_ORDER];      // per (channel, window) lane
 };
 
+// lcg_random (aacdec.c:502-505) j steps ahead: x -> mulA[j] * x + addC[j]  (mod 2^32)
+#define LCG_SKIP 97
+struct LcgSkip { unsigned mulA[LCG_SKIP], addC[LCG_SKIP]; };
+
+// The NOISE_BT branch of decode_spectrum_and_dequant (aacdec.c:1003-1029) for one channel.
+// The generator is sequential in the reference; element k of a band is k + 1 steps ahead of
+// the state at the band's start, so the lanes jump there directly.  The band energy is the
+// reference's left-to-right sum (every lane forms it from LDS).
+__device__ __forceinline__ unsigned tools_pns(ToolsWave &w, const LcgSkip &K, int ch, unsigned rs, int lane)
+{
+    const HeaacToolsIcs &ics = w.t.ch[ch].ics;
+    float *coef = w.coef[ch];
+    int idx = 0, base = 0;
+    for (int g = 0; g < ics.num_window_groups; g++) {
+        const int glen = ics.group_len[g];
+        for (int i = 0; i < ics.max_sfb; i++, idx++) {
+            if (w.t.ch[ch].band_type[idx] != HEAAC_NOISE_BT) continue;
+            const int o = ics.swb_offset[i], len = ics.swb_offset[i + 1] - o;
+            const float sf = w.t.ch[ch].sf[idx];
+            for (int group = 0; group < glen; group++) {
+                float *cfo = coef + base + group * 128 + o;
+                for (int k = lane; k < len; k += WAVE)
+                    cfo[k] = (float)(int)(K.mulA[k + 1] * rs + K.addC[k + 1]);
+                rs = K.mulA[len] * rs + K.addC[len];
+                wave_sync();
+                float band_energy = 0.0f;
+                for (int k = 0; k < len; k++) band_energy += cfo[k] * cfo[k];
+                const float scale = sf / sqrtf(band_energy);
+                wave_sync();
+                for (int k = lane; k < len; k += WAVE) cfo[k] = cfo[k] * scale;
+            }
+        }
+        base += glen * 128;
+    }
+    wave_sync();
+    return rs;
+}
+
 __device__ __forceinline__ void tools_mid_side(ToolsWave &w, int lane)
 {
     const HeaacToolsIcs &ics = w.t.ch[0].ics;
@@ -109,9 +147,20 @@ __device__ __forceinline__ void tools_tns_window(ToolsWave &w, int ch, int win, 
 
 template <int CH>
 __global__ __launch_bounds__(TL_WAVES * WAVE)
-void k_spectral_tools(float *g_coeffs, const HeaacToolsFrame *__restrict__ g_tools, unsigned long long n)
+void k_spectral_tools(float *g_coeffs, const HeaacToolsFrame *__restrict__ g_tools,
+                      const int *g_rng_in, int *g_rng_out, unsigned long long n)
 {
     __shared__ ToolsWave S[TL_WAVES];
+    __shared__ LcgSkip K;
+    if (threadIdx.x == 0) {
+        unsigned a = 1u, c = 0u;                 // identity, then compose one step at a time
+        for (int j = 0; j < LCG_SKIP; j++) {
+            K.mulA[j] = a; K.addC[j] = c;
+            a = a * 1664525u;
+            c = c * 1664525u + 1013904223u;
+        }
+    }
+    __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
     ToolsWave &w = S[wave];
     for (unsigned long long f = (unsigned long long)blockIdx.x * TL_WAVES + wave; f < n;
@@ -127,6 +176,12 @@ void k_spectral_tools(float *g_coeffs, const HeaacToolsFrame *__restrict__ g_too
             for (int i = lane; i < (int)(sizeof(HeaacToolsFrame) / 4); i += WAVE) d[i] = s[i];
         }
         wave_sync();
+        if (g_rng_in) {
+            unsigned rs = (unsigned)g_rng_in[f];
+#pragma unroll
+            for (int c = 0; c < CH; c++) rs = tools_pns(w, K, c, rs, lane);
+            if (lane == 0) g_rng_out[f] = (int)rs;
+        }
         if (CH == 2) {
             if (w.t.common_window && w.t.ms_present) { tools_mid_side(w, lane); wave_sync(); }
             tools_intensity(w, lane);
@@ -150,17 +205,17 @@ void k_spectral_tools(float *g_coeffs, const HeaacToolsFrame *__restrict__ g_too
 }
 
 extern "C" int heaac_launch_spectral_tools(int channels, float *d_coeffs, const HeaacToolsFrame *d_tools,
-                                           size_t n, hipStream_t s)
+                                           const int *d_rng_in, int *d_rng_out, size_t n, hipStream_t s)
 {
     if (n == 0) return HEAAC_OK;
     unsigned long long g = (n + TL_WAVES - 1) / TL_WAVES;
     if (g > 256) g = 256;
     if (channels == 2)
         hipLaunchKernelGGL(k_spectral_tools<2>, dim3((unsigned)g), dim3(TL_WAVES * WAVE), 0, s, d_coeffs, d_tools,
-                           (unsigned long long)n);
+                           d_rng_in, d_rng_out, (unsigned long long)n);
     else if (channels == 1)
         hipLaunchKernelGGL(k_spectral_tools<1>, dim3((unsigned)g), dim3(TL_WAVES * WAVE), 0, s, d_coeffs, d_tools,
-                           (unsigned long long)n);
+                           d_rng_in, d_rng_out, (unsigned long long)n);
     else
         return HEAAC_ERR_ARG;
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;

@@ -353,9 +353,18 @@ typedef struct HeaacToolsFrame {
 /* In place on d_coeffs [n][channels][1024].  channels == 2: M/S (if common_window and
  * ms_present), intensity stereo, then TNS per channel -- the order of decode_cpe
  * (aacdec.c:1480-1492) followed by spectral_to_sample (:1913-1916).  channels == 1: TNS of
- * ch[0] only. */
+ * ch[0] only.
+ * Perceptual noise substitution (the NOISE_BT branch of decode_spectrum_and_dequant,
+ * aacdec.c:1016-1029) runs first when d_rng_in is not NULL: every band of type NOISE_BT is
+ * filled from the stream's generator (lcg_random, aacdec.c:502-505; ac->random_state starts at
+ * 0x1f2e3d4c, :567) in parse order -- channel 0 then channel 1, bands in (group, sfb) order, the
+ * windows of a group, ascending k -- and scaled to sf[idx] / sqrtf(energy).  d_rng_in[n] is the
+ * state before the frame, d_rng_out[n] the state after it (may alias).  With d_rng_in == NULL
+ * noise bands are taken as given. */
 int heaac_spectral_tools_batch(HeaacDevice *dev, int channels, float *d_coeffs,
-                               const HeaacToolsFrame *d_tools, size_t n, void *stream);
+                               const HeaacToolsFrame *d_tools,
+                               const int32_t *d_rng_in, int32_t *d_rng_out,
+                               size_t n, void *stream);
 
 /* Host-side helper (no GPU): derive the frequency-band tables of one SBR
  * header -- sbr_make_f_master/f_derived/hf_calc_npatches/f_tablelim

@@ -8,6 +8,7 @@
  * scaled copies).
  */
 #include <string.h>
+#include <math.h>
 #include "oracle.h"
 
 /* butterflies_float_c, dsputil.c:3899-3908 */
@@ -116,12 +117,56 @@ static void or_tns(float coef[1024], const HeaacTns *tns, const HeaacToolsIcs *i
     }
 }
 
-/* decode_cpe's tail (aacdec.c:1483-1492) + spectral_to_sample's TNS calls (:1913-1916) */
-void oracle_spectral_tools_batch(int channels, float *coeffs, const HeaacToolsFrame *tools, size_t n)
+/* lcg_random, aacdec.c:502-505 (int arithmetic that wraps) */
+static int lcg_random(int previous_val)
+{
+    return (int)((unsigned)previous_val * 1664525u + 1013904223u);
+}
+
+/* the NOISE_BT branch of decode_spectrum_and_dequant, aacdec.c:1003-1029 */
+static int or_pns(const HeaacToolsChannel *ch, float *coef, int random_state)
+{
+    const HeaacToolsIcs *ics = &ch->ics;
+    int idx = 0;
+    for (int g = 0; g < ics->num_window_groups; g++) {
+        const int g_len = ics->group_len[g];
+        for (int i = 0; i < ics->max_sfb; i++, idx++) {
+            if (ch->band_type[idx] != HEAAC_NOISE_BT)
+                continue;
+            float *cfo = coef + ics->swb_offset[i];
+            const int off_len = ics->swb_offset[i + 1] - ics->swb_offset[i];
+            for (int group = 0; group < g_len; group++, cfo += 128) {
+                for (int k = 0; k < off_len; k++) {
+                    random_state = lcg_random(random_state);
+                    cfo[k] = random_state;
+                }
+                float band_energy = 0.0;                      /* scalarproduct_float_c, dsputil.c:3910-3919 */
+                for (int k = 0; k < off_len; k++)
+                    band_energy += cfo[k] * cfo[k];
+                const float scale = ch->sf[idx] / sqrtf(band_energy);
+                for (int k = 0; k < off_len; k++)                 /* vector_fmul_scalar_c */
+                    cfo[k] = cfo[k] * scale;
+            }
+        }
+        coef += g_len << 7;
+    }
+    return random_state;
+}
+
+/* decode_cpe's tail (aacdec.c:1483-1492) + spectral_to_sample's TNS calls (:1913-1916);
+ * rng_in != NULL: noise substitution first, channel 0 then channel 1 (decode_ics order) */
+void oracle_spectral_tools_batch(int channels, float *coeffs, const HeaacToolsFrame *tools,
+                                 const int32_t *rng_in, int32_t *rng_out, size_t n)
 {
     for (size_t f = 0; f < n; f++) {
         const HeaacToolsFrame *t = &tools[f];
         float *c0 = coeffs + f * (size_t)channels * 1024, *c1 = c0 + 1024;
+        if (rng_in) {
+            int rs = rng_in[f];
+            for (int c = 0; c < channels; c++)
+                rs = or_pns(&t->ch[c], c ? c1 : c0, rs);
+            rng_out[f] = rs;
+        }
         if (channels == 2) {
             if (t->common_window && t->ms_present)
                 or_mid_side(t, c0, c1);

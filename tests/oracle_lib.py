@@ -180,12 +180,18 @@ def lc_decode_batch(channels, coeffs, ics, state_in, pcm_format=PCM_F32):
     return pcm, state_out
 
 
-def spectral_tools_batch(channels, coeffs, tools):
-    """M/S + intensity + TNS on a copy of coeffs [n][channels][1024]."""
+def spectral_tools_batch(channels, coeffs, tools, rng=None):
+    """(PNS if rng is given,) M/S + intensity + TNS on a copy of coeffs [n][channels][1024].
+    Returns coeffs, or (coeffs, rng_out)."""
     out = np.ascontiguousarray(coeffs, np.float32).copy()
     tools = np.ascontiguousarray(tools)
-    lib().oracle_spectral_tools_batch(C.c_int(channels), _p(out), _p(tools), C.c_size_t(out.shape[0]))
-    return out
+    if rng is None:
+        lib().oracle_spectral_tools_batch(C.c_int(channels), _p(out), _p(tools), None, None, C.c_size_t(out.shape[0]))
+        return out
+    rin = np.ascontiguousarray(rng, np.int32)
+    rout = np.empty_like(rin)
+    lib().oracle_spectral_tools_batch(C.c_int(channels), _p(out), _p(tools), _p(rin), _p(rout), C.c_size_t(out.shape[0]))
+    return out, rout
 
 
 def he_decode_batch(cfg, coeffs, ics, sbr, hdr, ps, state_in, pcm_format=PCM_F32):

@@ -86,3 +86,29 @@ def test_tns_zero_filter_is_identity_and_allpole_inverts_fir(pkg, oracle):
     assert np.max(np.abs(x - c[0, 0, :end])) < 1e-3
     assert np.array_equal(out[0, 0, end:], c[0, 0, end:]) and np.array_equal(out[0, 1], c[0, 1])
     assert not np.array_equal(out[0, 0, :end], c[0, 0, :end])
+
+
+def test_noise_bands_carry_the_scalefactor_energy(pkg, oracle):
+    t = _long_frame(pkg)
+    t["ch"][0][0]["band_type"][20] = 13; t["ch"][0][0]["sf"][20] = 3.0
+    t["ch"][0][1]["band_type"][5] = 13;  t["ch"][0][1]["sf"][5] = 0.125
+    c = np.zeros((1, 2, 1024), np.float32)
+    out, rs = oracle.spectral_tools_batch(2, c, t, np.array([0x1f2e3d4c], np.int32))
+    off = _synth().SWB_1024_48
+    e0 = float(np.sum(out[0, 0, off[20]:off[21]].astype(np.float64) ** 2))
+    e1 = float(np.sum(out[0, 1, off[5]:off[6]].astype(np.float64) ** 2))
+    assert abs(e0 - 9.0) < 1e-4 and abs(e1 - 0.125 ** 2) < 1e-7
+    # the generator advanced by exactly the number of noise coefficients, channel 0 first
+    x = 0x1f2e3d4c
+    first = None
+    for k in range((off[21] - off[20]) + (off[6] - off[5])):
+        x = (x * 1664525 + 1013904223) & 0xffffffff
+        if k == 0:
+            first = x
+    assert int(rs[0]) & 0xffffffff == x
+    # first noise sample is the first draw (as a signed int) times the band's scale
+    sgn = first - (1 << 32) if first >= (1 << 31) else first
+    assert np.sign(out[0, 0, off[20]]) == np.sign(sgn)
+    # everything else untouched
+    keep = np.ones((2, 1024), bool); keep[0, off[20]:off[21]] = False; keep[1, off[5]:off[6]] = False
+    assert not out[0][keep].any()

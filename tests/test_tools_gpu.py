@@ -31,6 +31,25 @@ def test_spectral_tools_match_oracle(pkg, oracle, dev, channels, n):
     assert n < 7 or not np.array_equal(_bits(ref), _bits(coeffs))
 
 
+@pytest.mark.parametrize("channels", [1, 2])
+def test_spectral_tools_with_noise_substitution(pkg, oracle, dev, channels):
+    """PNS first (generator state in / out per stream), chained over three frames."""
+    import torch
+    n = 150
+    rng = np.random.default_rng(40 + channels)
+    state = rng.integers(-2**31, 2**31, n).astype(np.int32)
+    state[0] = 0x1f2e3d4c                                   # ac->random_state at init
+    d_state = torch.from_numpy(state.copy()).cuda()
+    for step in range(3):
+        tools = _synth().tools_frames(rng, pkg, n, channels)
+        coeffs = (rng.standard_normal((n, channels, 1024)) * 1e-4).astype(np.float32)
+        ref, state = oracle.spectral_tools_batch(channels, coeffs, tools, state)
+        d = torch.from_numpy(coeffs).cuda()
+        dev.spectral_tools(channels, d, pkg.to_device(tools), rng=d_state)
+        assert np.array_equal(_bits(d.cpu().numpy()), _bits(ref)), "step %d" % step
+        assert np.array_equal(d_state.cpu().numpy(), state), "step %d" % step
+
+
 def test_spectral_tools_then_lc_decode(pkg, oracle, dev):
     """tools -> imdct_and_windowing: the prefix of spectral_to_sample (aacdec.c:1903-1925)."""
     import torch
@@ -55,4 +74,4 @@ def test_spectral_tools_empty_and_bad_args(pkg, dev):
     z = torch.zeros((0, 2, 1024), device="cuda")
     dev.spectral_tools(2, z, torch.zeros(0, dtype=torch.uint8, device="cuda"))
     with pytest.raises(pkg.HeaacError):
-        pkg._check(pkg.lib().heaac_spectral_tools_batch(dev._h, 3, None, None, 1, None), "bad channels")
+        pkg._check(pkg.lib().heaac_spectral_tools_batch(dev._h, 3, None, None, None, None, 1, None), "bad channels")
