@@ -185,3 +185,35 @@ def test_hev1_coupled_channel_pairs(pkg, oracle, dev):
     hdr = _synth().default_headers(pkg, extra=True)
     n = 42
     _run_chain(pkg, oracle, dev, pkg.CFG_HEV1, n, 5, 25, hdr, hdr_choice=np.arange(n) % len(hdr), coupling=0.7)
+
+
+def test_he_decode_is_graph_capturable(pkg, oracle, dev):
+    """The batched entry point neither allocates nor synchronises: a whole HE-AACv2 step can be
+    captured in a HIP graph and replayed."""
+    import torch
+    synth = _synth()
+    rng = np.random.default_rng(77)
+    hdr = synth.default_headers(pkg)
+    n = 48
+    cfg = pkg.CFG_HEV2
+    fr = next(synth.he_stream(rng, cfg, n, 1, hdr))
+    state0 = np.zeros((n, pkg.STATE_WORDS[cfg]), np.float32)
+    ref_pcm, ref_state = oracle.he_decode_batch(cfg, fr["coeffs"], fr["ics"], fr["sbr"], hdr, fr["ps"], state0, pkg.PCM_S16)
+    args = (torch.from_numpy(fr["coeffs"]).cuda(), pkg.to_device(fr["ics"]), pkg.to_device(fr["sbr"]),
+            pkg.to_device(hdr), pkg.to_device(fr["ps"]))
+    st_in = torch.zeros((n, pkg.STATE_WORDS[cfg]), device="cuda")
+    st_out = torch.empty_like(st_in)
+    pcm = torch.empty((n, 2048, 2), dtype=torch.int16, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        dev.he_decode(cfg, *args, st_in, state_out=st_out, pcm=pcm, pcm_format=pkg.PCM_S16)   # warm-up outside capture
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            dev.he_decode(cfg, *args, st_in, state_out=st_out, pcm=pcm, pcm_format=pkg.PCM_S16)
+    pcm.zero_(); st_out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(pcm.cpu().numpy(), ref_pcm)
+    nbad, where = _mismatch(st_out.cpu().numpy(), ref_state)
+    assert nbad == 0, where
