@@ -576,11 +576,15 @@ __device__ __forceinline__ void hf_channel(const HfWave &w, const float *g_noise
                 s_e = e == 1 ? s_m[1] : e == 2 ? s_m[2] : e == 3 ? s_m[3] : s_m[4];
                 plain = (e == c.e_a[0]) || (e == c.e_a[1]);
             }
+            // Lane-dependent conditions (band inside the SBR range, patch source present,
+            // sinusoid present) select values instead of branching: a divergent branch costs
+            // several scalar exec-mask instructions per slot, the selects one VALU each.
             v2f Y = v2f{0.0f, 0.0f};
-            const bool have_y = hf && i >= 2 * t0 && i < 2 * tL;
-            if (have_y) {
-                v2f xh = v2f{0.0f, 0.0f};
-                if (has_src) xh = xhigh3_pk(x2, x1, x0, kc);
+            const bool in_time = i >= 2 * t0 && i < 2 * tL;           // uniform
+            const bool have_y = hf && in_time;
+            if (in_time) {
+                v2f xh = xhigh3_pk(x2, x1, x0, kc);
+                xh = has_src ? xh : v2f{0.0f, 0.0f};
                 gq[(i + 4) % 5] = v2f{g_e, q_e};
                 // (g_filt, q_filt): this slot's values, or the 5-tap smoothing of both rows at once
                 v2f f = v2f{g_e, q_e};
@@ -596,12 +600,15 @@ __device__ __forceinline__ void hf_channel(const HfWave &w, const float *g_noise
                 const int phi_re = isine == 0 ? 1 : isine == 2 ? -1 : 0;
                 const int phi_im = isine == 1 ? 1 : isine == 3 ? -1 : 0;
                 const v2f ph = v2f{(float)phi_re, (float)(phi_im * phi_sign0)};
+                const v2f y_sine = Y + bc(s_e) * ph;
                 if (!plain) {
-                    if (s_e) Y = Y + bc(s_e) * ph;
-                    else     Y = Y + bc(f.y) * nq[i & 3];   // sbr_noise_table[(f_indexnoise + slot m_max + m + 1) & 0x1ff]
+                    // sbr_noise_table[(f_indexnoise + slot m_max + m + 1) & 0x1ff] where no sinusoid sits
+                    const v2f y_noise = Y + bc(f.y) * nq[i & 3];
+                    Y = s_e != 0.0f ? y_sine : y_noise;
                 } else {
-                    Y = Y + bc(s_e) * ph;
+                    Y = y_sine;
                 }
+                Y = hf ? Y : v2f{0.0f, 0.0f};
             }
             const float yr = Y.x, yi = Y.y;
             // ytail: Y[1][32..37]
@@ -611,19 +618,16 @@ __device__ __forceinline__ void hf_channel(const HfWave &w, const float *g_noise
                 else if (ytail_out != ytail_in) { ytail_out[o] = ytail_in[o]; ytail_out[o + 1] = ytail_in[o + 1]; }
             }
             // x_gen
-            float xo_r = 0.0f, xo_i = 0.0f;
+            float xo_r, xo_i;
             if (i < 6 && i < i_Temp) {
-                if (k < kx_old) {
-                    if (k < 32) { xo_r = xlin[i < 6 ? i : 0].x; xo_i = xlin[i < 6 ? i : 0].y; }
-                } else if (k < kx_old + m_old) {
-                    xo_r = ytin[i < 6 ? i : 0].x; xo_i = ytin[i < 6 ? i : 0].y;
-                }
+                const bool lo = k < kx_old, hi = !lo && k < kx_old + m_old;
+                xo_r = lo ? xlin[i < 6 ? i : 0].x : hi ? ytin[i < 6 ? i : 0].x : 0.0f;     // xlin is 0 for k >= 32
+                xo_i = lo ? xlin[i < 6 ? i : 0].y : hi ? ytin[i < 6 ? i : 0].y : 0.0f;
             } else {
-                if (k < kx) {
-                    if (k < 32) { xo_r = x0.x; xo_i = x0.y; }
-                } else if (k < kx + m_max && i < 32) {
-                    xo_r = yr; xo_i = yi;
-                }
+                const bool lo = k < kx, hi = !lo && k < kx + m_max && i < 32;
+                const bool lo32 = lo && k < 32;
+                xo_r = lo32 ? x0.x : hi ? yr : 0.0f;
+                xo_i = lo32 ? x0.y : hi ? yi : 0.0f;
             }
             emit(i, xo_r, xo_i);
             x2 = x1; x1 = x0;
