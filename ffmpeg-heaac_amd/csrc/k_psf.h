@@ -295,9 +295,13 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
         // current sample and delayed sample s[k][n - D]
         v2f sv, dv;
         if (HEAVY) {
-            const v2f subv = srow[n];                  // sub-subband lanes (others read row 0, unused)
+            // sub-subband lanes read their row (the others row 0, unused).  The reads are kept
+            // unconditional: as select operands the compiler would put each one under an
+            // exec-mask branch of its own.
+            v2f subv = srow[n];
+            v2f sub2 = srow[n >= 2 ? n - 2 : 0];                  // sub-subbands are all-pass bands: D = 2
+            asm volatile("" : "+v"(subv), "+v"(sub2));
             sv = is_sub ? subv : col[n];
-            const v2f sub2 = srow[n >= 2 ? n - 2 : 0];            // sub-subbands are all-pass bands: D = 2
             // state tail for the first slots (static register index per category)
             const v2f ap_d = n >= 2 ? (is_sub ? sub2 : col[n >= 2 ? n - 2 : 0]) : hst[12 + (n < 2 ? n : 0)];
             const v2f d14_d = n >= 14 ? col[n >= 14 ? n - 14 : 0] : hst[n < 14 ? n : 0];
