@@ -201,12 +201,18 @@ __device__ __forceinline__ void hybrid_fir(const float *in, const float *filt, f
 // ALIGNED8: every border is 8k - 1 (frame_class 0, aacps.c:203-205), so the H
 // interpolation can only restart at slots 0, 8, 16, 24 and the unrolled slot code in
 // between is one straight-line block.
-template <bool HEAVY, bool ALIGNED8, class W>
+// DUAL (baseline layout, with HEAVY): the lanes whose first role is a sub-subband (their X
+// store is discarded anyway) also carry the QMF band kh2 of their own column -- one of the
+// bands >= 64 with the one-slot delay -- so that every X row leaves as one full 256-byte
+// store and no separate pass over the slots is needed.  dual: this lane has a second role.
+template <bool HEAVY, bool ALIGNED8, bool DUAL, class W>
 __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, const signed char *kti,
                                         int is34, int kh, bool clear_state,
                                         const GBuf &SI, const GBuf &SO, const GBuf &X,
-                                        bool is_sub, int q, const v2f (&col)[32])
+                                        bool is_sub, int q, const v2f (&col)[32],
+                                        bool dual = false, int kh2 = 0, bool clear2 = false)
 {
+    static_assert(!DUAL || HEAVY, "the second role rides on the heavy pass");
     constexpr int dl_stride = 91 * 2, ap_stride = 50 * 2;
     constexpr int XP = 38 * 64;                       // X record: [L, R][re, im][38][64]
     const int nr_allpass = is34 ? 50 : 30, short_delay = is34 ? 62 : 42;
@@ -258,6 +264,15 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
         ph = v2f{phre, phim};
         phi = v2f{-phim, phre};                      // i * phi_fract
     }
+    // second role: delay tail, parameter band and H of band kh2
+    const int b2 = DUAL ? kti[dual ? kh2 : 64] : 0;
+    v2f hst2 = zero;
+    if (DUAL) {
+        const v2f t = SI.ldb2(opaque((dual ? kh2 : 64) * 8), HEAAC_PS_DELAY + 13 * dl_stride);
+        hst2 = clear2 ? zero : t;
+    }
+    const float *tgrow2 = w.pw[b2];
+    v2f hA2 = zero, hB2 = zero, hA2_step = zero, hB2_step = zero;
     const bool neg_im = (is34 && kh <= 13 && kh >= 9) || (!is34 && kh <= 1);
     const float *tgrow = w.pw[b];
     const v2f *srow = reinterpret_cast<const v2f *>(w.sub[is_sub ? kh : 0]);
@@ -284,6 +299,12 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
             hB = v2f{w.Hs[e][2 * R][b], w.Hs[e][3 * R][b]};
             hA_step = (v2f{w.Hs[e + 1][0][b], w.Hs[e + 1][R][b]} - hA) * bc(width);
             hB_step = (v2f{w.Hs[e + 1][2 * R][b], w.Hs[e + 1][3 * R][b]} - hB) * bc(width);
+            if constexpr (DUAL) {
+                hA2 = v2f{w.Hs[e][0][b2], w.Hs[e][R][b2]};
+                hB2 = v2f{w.Hs[e][2 * R][b2], w.Hs[e][3 * R][b2]};
+                hA2_step = (v2f{w.Hs[e + 1][0][b2], w.Hs[e + 1][R][b2]} - hA2) * bc(width);
+                hB2_step = (v2f{w.Hs[e + 1][2 * R][b2], w.Hs[e + 1][3 * R][b2]} - hB2) * bc(width);
+            }
             if constexpr (W::IS_GENERAL) if (enable_ipdopd) {
                 hAi = v2f{w.Hs[e][1][b], w.Hs[e][3][b]};
                 hBi = v2f{w.Hs[e][5][b], w.Hs[e][7][b]};
@@ -350,6 +371,16 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
             *reinterpret_cast<v2f *>(lrow + 2 * n) = lv;
             *reinterpret_cast<v2f *>(rrow + 2 * n) = rr;
         }
+        if constexpr (DUAL) {
+            // second role (aacps.c:738-752 with the one-slot delay, then :940-969)
+            const v2f d2 = n >= 1 ? col[n >= 1 ? n - 1 : 0] : hst2;
+            const v2f rv2 = bc(tgrow2[n]) * d2;
+            hA2 += hA2_step; hB2 += hB2_step;
+            const v2f lv2 = bc(hA2.x) * col[n] + bc(hB2.x) * rv2;
+            const v2f rr2 = bc(hA2.y) * col[n] + bc(hB2.y) * rv2;
+            lv = dual ? lv2 : lv;
+            rr = dual ? rr2 : rr;
+        }
         {
             const int qb = opaque(qs4);
             X.stb(lv.x, qb, n * 64);          X.stb(lv.y, qb, XP + n * 64);
@@ -369,6 +400,10 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
         }
         const int kv = opaque(kh * 8);
         SO.stb2(v, kv, HEAAC_PS_DELAY + j * dl_stride);
+    }
+    if (DUAL && dual) {
+#pragma unroll
+        for (int j = 0; j < 14; j++) SO.stb2(col[18 + j], opaque(kh2 * 8), HEAAC_PS_DELAY + j * dl_stride);
     }
     if (allpass) {
         // times 27..31 sit at ring positions (27 + j) % 5
@@ -768,22 +803,34 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
         // sub-subband lanes send their (discarded) X store to their own column: pass 2 or the
         // hybrid synthesis rewrites it afterwards
         const int qcol = GENERAL ? (is_sub ? 0 : kh - nsub + nlow) : lane;
-        if (aligned8)
-            ps_band<true, true>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X, is_sub, qcol, col);
-        else
-            ps_band<true, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X, is_sub, qcol, col);
+        if constexpr (GENERAL) {
+            if (aligned8)
+                ps_band<true, true, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X, is_sub, qcol, col);
+            else
+                ps_band<true, false, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X, is_sub, qcol, col);
+        } else {
+            // lanes 57..63 also carry the bands 64..70 of their own columns
+            const bool dual = lane >= 57;
+            const int kh2 = lane + 7;
+            if (aligned8)
+                ps_band<true, true, true>(w, g_tab, M.kti, is34, kh, kh >= top, SI, SO, X, is_sub, qcol, col,
+                                          dual, kh2, kh2 >= top);
+            else
+                ps_band<true, false, true>(w, g_tab, M.kti, is34, kh, kh >= top, SI, SO, X, is_sub, qcol, col,
+                                           dual, kh2, kh2 >= top);
+        }
     }
     STAMP(6);
     lane = opaque(lane);
     // ---- pass 2: hybrid bands 64.. (all use the one-slot delay) ----
-    if (GENERAL ? lane < nr_bands - 64 : lane >= 57) {
-        const int kh = GENERAL ? 64 + lane : lane + 7;
+    if constexpr (GENERAL) if (lane < nr_bands - 64) {
+        const int kh = 64 + lane;
         if (aligned8)
-            ps_band<false, true>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X,
-                                 false, kh - nsub + nlow, col);
+            ps_band<false, true, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X,
+                                        false, kh - nsub + nlow, col);
         else
-            ps_band<false, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X,
-                                 false, kh - nsub + nlow, col);
+            ps_band<false, false, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X,
+                                         false, kh - nsub + nlow, col);
     }
     STAMP(7);
     lane = opaque(lane);
