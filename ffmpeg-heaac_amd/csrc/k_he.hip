@@ -247,16 +247,18 @@ void k_hfadj(const float *__restrict__ g_tab,
 #define VB_STRIDE 129             // v slot row: 128 + 1 pad
 #define VB_ROWS   41              // 32 new slots (newest first) + 9 history slots
 
+#define SYN_WAVES_F32 7           // float PCM goes straight to HBM: no int16 staging, one more wave fits
 struct SynWave {
     float vb[VB_ROWS * VB_STRIDE];
-    uint16_t pcm0[2048];
 };
-struct SynLds {
+template <int NW>
+struct SynLdsT {
     float win[640];               // sbr_qmf_window_us
     float rot[64];                // SBR synthesis MDCT (scale 1/64): tcos[32], tsin[32]
     float c16[8], c32[12];
-    SynWave w[SYN_WAVES];
+    SynWave w[NW];
 };
+typedef SynLdsT<SYN_WAVES> SynLds;
 
 // swap with the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2]
 __device__ __forceinline__ float lane_xor1(float v)
@@ -268,8 +270,8 @@ __device__ __forceinline__ float lane_xor1(float v)
 //   X0/X1 : re / im planes [38][64] (slots 0..31 used)
 //   v_in/v_out : 1152-float ring state, newest slot first
 //   emit(i, n, value) receives out[64 i + n]
-template <class Emit>
-__device__ __forceinline__ void synth_channel(const SynLds &S, SynWave &w, const float *X0, const float *X1,
+template <class SL, class Emit>
+__device__ __forceinline__ void synth_channel(const SL &S, SynWave &w, const float *X0, const float *X1,
                                               const float *v_in, float *v_out,
                                               float scale, float bias, int lane, Emit emit)
 {
@@ -333,13 +335,15 @@ __device__ __forceinline__ void synth_channel(const SynLds &S, SynWave &w, const
 }
 
 template <int FMT>
-__global__ __launch_bounds__(SYN_WAVES * WAVE)
+__global__ __launch_bounds__((FMT == HEAAC_PCM_F32_PLANAR ? SYN_WAVES_F32 : SYN_WAVES) * WAVE)
 void k_synth(const float *__restrict__ g_tab, const float *g_X,
              const float *g_state_in, float *g_state_out, int state_words, int off_syn0,
              int nout, int copy_mono, void *__restrict__ g_pcm, float scale, float bias,
              unsigned long long n_frames, unsigned long long pcm_frame0)
 {
-    __shared__ SynLds S;
+    constexpr int NW = FMT == HEAAC_PCM_F32_PLANAR ? SYN_WAVES_F32 : SYN_WAVES;
+    __shared__ SynLdsT<NW> S;
+    __shared__ uint16_t s_pcm0[NW][FMT == HEAAC_PCM_F32_PLANAR ? 2 : 2048];   // left channel of an int16 pair
     for (int i = threadIdx.x; i < 640; i += blockDim.x) S.win[i] = g_tab[TB_QMF_US + i];
     if (threadIdx.x < 64) S.rot[threadIdx.x] = g_tab[TB_ROT128S + threadIdx.x];
     if (threadIdx.x < 5) S.c16[threadIdx.x] = g_tab[TB_COS16 + threadIdx.x];
@@ -347,8 +351,9 @@ void k_synth(const float *__restrict__ g_tab, const float *g_X,
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
     SynWave &w = S.w[wave];
-    for (unsigned long long f = (unsigned long long)blockIdx.x * SYN_WAVES + wave; f < n_frames;
-         f += (unsigned long long)gridDim.x * SYN_WAVES) {
+    uint16_t *pcm0 = s_pcm0[wave];
+    for (unsigned long long f = (unsigned long long)blockIdx.x * NW + wave; f < n_frames;
+         f += (unsigned long long)gridDim.x * NW) {
         const float *st_in = g_state_in + f * state_words + off_syn0;
         float *st_out = g_state_out + f * state_words + off_syn0;
         for (int ch = 0; ch < nout; ch++) {
@@ -368,12 +373,12 @@ void k_synth(const float *__restrict__ g_tab, const float *g_X,
                               [&](int i, int n, float v) { o[64 * i + n] = (int16_t)float_to_int16_one(v); });
             } else if (ch == 0) {
                 synth_channel(S, w, X0, X1, v_in, v_out, scale, bias, lane,
-                              [&](int i, int n, float v) { w.pcm0[64 * i + n] = (uint16_t)float_to_int16_one(v); });
+                              [&](int i, int n, float v) { pcm0[64 * i + n] = (uint16_t)float_to_int16_one(v); });
             } else {
                 uint32_t *o = reinterpret_cast<uint32_t *>(g_pcm) + (pcm_frame0 + f) * 2048;
                 synth_channel(S, w, X0, X1, v_in, v_out, scale, bias, lane,
                               [&](int i, int n, float v) {
-                                  o[64 * i + n] = (uint32_t)w.pcm0[64 * i + n] |
+                                  o[64 * i + n] = (uint32_t)pcm0[64 * i + n] |
                                                   ((uint32_t)(float_to_int16_one(v) & 0xffff) << 16);
                               });
             }
@@ -501,7 +506,8 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
     const float scale = -1024 * sf_scale, bias = HEAAC_ADD_BIAS;
     const dim3 g(he_grid(n, SYN_WAVES)), b(SYN_WAVES * WAVE);
     if (pcm_format == HEAAC_PCM_F32_PLANAR)
-        hipLaunchKernelGGL((k_synth<HEAAC_PCM_F32_PLANAR>), g, b, 0, s, d_tab, d_ws_X, d_state_in, d_state_out,
+        hipLaunchKernelGGL((k_synth<HEAAC_PCM_F32_PLANAR>), dim3(he_grid(n, SYN_WAVES_F32)),
+                           dim3(SYN_WAVES_F32 * WAVE), 0, s, d_tab, d_ws_X, d_state_in, d_state_out,
                            words, off_syn0, nout, copy_mono, d_pcm, scale, bias,
                            (unsigned long long)n, (unsigned long long)pcm_frame0);
     else if (pcm_format == HEAAC_PCM_S16_INTERLEAVED)
