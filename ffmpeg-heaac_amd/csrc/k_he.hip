@@ -247,7 +247,7 @@ void k_hfadj(const float *__restrict__ g_tab,
 #define VB_STRIDE 129             // v slot row: 128 + 1 pad
 #define VB_ROWS   41              // 32 new slots (newest first) + 9 history slots
 
-#define SYN_WAVES_F32 7           // float PCM goes straight to HBM: no int16 staging, one more wave fits
+#define SYN_WAVES_F32 7           // k_synth: the left int16 channel waits in registers, so 7 waves fit
 struct SynWave {
     float vb[VB_ROWS * VB_STRIDE];
 };
@@ -270,7 +270,8 @@ __device__ __forceinline__ float lane_xor1(float v)
 //   X0/X1 : re / im planes [38][64] (slots 0..31 used)
 //   v_in/v_out : 1152-float ring state, newest slot first
 //   emit(i, n, value) receives out[64 i + n]
-template <class SL, class Emit>
+// UNROLL: unroll count of the polyphase loop (16 = fully: emit() then sees compile-time slots)
+template <int UNROLL = 1, class SL, class Emit>
 __device__ __forceinline__ void synth_channel(const SL &S, SynWave &w, const float *X0, const float *X1,
                                               const float *v_in, float *v_out,
                                               float scale, float bias, int lane, Emit emit)
@@ -311,6 +312,7 @@ __device__ __forceinline__ void synth_channel(const SL &S, SynWave &w, const flo
         for (int j = 0; j < 10; j++) wt[j] = S.win[64 * j + n];
         const bool scale_and_bias = scale != 1.0f || bias != 0.0f;
         // two slots per packed multiply / add: (slot i, slot i + 1) share the window taps
+#pragma unroll UNROLL
         for (int i = 0; i < 32; i += 2) {
             const float *va = w.vb + (31 - i) * VB_STRIDE + n, *vb = va - VB_STRIDE;
             v2f acc = v2f{va[0], vb[0]} * bc(wt[0]) + v2f{0.0f, 0.0f};
@@ -335,15 +337,14 @@ __device__ __forceinline__ void synth_channel(const SL &S, SynWave &w, const flo
 }
 
 template <int FMT>
-__global__ __launch_bounds__((FMT == HEAAC_PCM_F32_PLANAR ? SYN_WAVES_F32 : SYN_WAVES) * WAVE)
+__global__ __launch_bounds__(SYN_WAVES_F32 * WAVE)
 void k_synth(const float *__restrict__ g_tab, const float *g_X,
              const float *g_state_in, float *g_state_out, int state_words, int off_syn0,
              int nout, int copy_mono, void *__restrict__ g_pcm, float scale, float bias,
              unsigned long long n_frames, unsigned long long pcm_frame0)
 {
-    constexpr int NW = FMT == HEAAC_PCM_F32_PLANAR ? SYN_WAVES_F32 : SYN_WAVES;
+    constexpr int NW = SYN_WAVES_F32;
     __shared__ SynLdsT<NW> S;
-    __shared__ uint16_t s_pcm0[NW][FMT == HEAAC_PCM_F32_PLANAR ? 2 : 2048];   // left channel of an int16 pair
     for (int i = threadIdx.x; i < 640; i += blockDim.x) S.win[i] = g_tab[TB_QMF_US + i];
     if (threadIdx.x < 64) S.rot[threadIdx.x] = g_tab[TB_ROT128S + threadIdx.x];
     if (threadIdx.x < 5) S.c16[threadIdx.x] = g_tab[TB_COS16 + threadIdx.x];
@@ -351,7 +352,7 @@ void k_synth(const float *__restrict__ g_tab, const float *g_X,
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
     SynWave &w = S.w[wave];
-    uint16_t *pcm0 = s_pcm0[wave];
+    uint32_t lpcm[16];          // left channel of an interleaved int16 pair: lane n, slots 2j | 2j + 1 << 16
     for (unsigned long long f = (unsigned long long)blockIdx.x * NW + wave; f < n_frames;
          f += (unsigned long long)gridDim.x * NW) {
         const float *st_in = g_state_in + f * state_words + off_syn0;
@@ -372,13 +373,17 @@ void k_synth(const float *__restrict__ g_tab, const float *g_X,
                 synth_channel(S, w, X0, X1, v_in, v_out, scale, bias, lane,
                               [&](int i, int n, float v) { o[64 * i + n] = (int16_t)float_to_int16_one(v); });
             } else if (ch == 0) {
-                synth_channel(S, w, X0, X1, v_in, v_out, scale, bias, lane,
-                              [&](int i, int n, float v) { pcm0[64 * i + n] = (uint16_t)float_to_int16_one(v); });
+                synth_channel<16>(S, w, X0, X1, v_in, v_out, scale, bias, lane,
+                              [&](int i, int n, float v) {
+                                  const uint32_t x = (uint32_t)float_to_int16_one(v) & 0xffff;
+                                  if (i & 1) lpcm[i >> 1] |= x << 16; else lpcm[i >> 1] = x;
+                              });
             } else {
                 uint32_t *o = reinterpret_cast<uint32_t *>(g_pcm) + (pcm_frame0 + f) * 2048;
-                synth_channel(S, w, X0, X1, v_in, v_out, scale, bias, lane,
+                synth_channel<16>(S, w, X0, X1, v_in, v_out, scale, bias, lane,
                               [&](int i, int n, float v) {
-                                  o[64 * i + n] = (uint32_t)pcm0[64 * i + n] |
+                                  // float_to_int16_interleave (dsputil.c:3989-4001)
+                                  o[64 * i + n] = ((lpcm[i >> 1] >> (16 * (i & 1))) & 0xffff) |
                                                   ((uint32_t)(float_to_int16_one(v) & 0xffff) << 16);
                               });
             }
@@ -504,10 +509,9 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
         }
     }
     const float scale = -1024 * sf_scale, bias = HEAAC_ADD_BIAS;
-    const dim3 g(he_grid(n, SYN_WAVES)), b(SYN_WAVES * WAVE);
+    const dim3 g(he_grid(n, SYN_WAVES_F32)), b(SYN_WAVES_F32 * WAVE);
     if (pcm_format == HEAAC_PCM_F32_PLANAR)
-        hipLaunchKernelGGL((k_synth<HEAAC_PCM_F32_PLANAR>), dim3(he_grid(n, SYN_WAVES_F32)),
-                           dim3(SYN_WAVES_F32 * WAVE), 0, s, d_tab, d_ws_X, d_state_in, d_state_out,
+        hipLaunchKernelGGL((k_synth<HEAAC_PCM_F32_PLANAR>), g, b, 0, s, d_tab, d_ws_X, d_state_in, d_state_out,
                            words, off_syn0, nout, copy_mono, d_pcm, scale, bias,
                            (unsigned long long)n, (unsigned long long)pcm_frame0);
     else if (pcm_format == HEAAC_PCM_S16_INTERLEAVED)
