@@ -25,7 +25,7 @@ struct LcWaveLds {
 // k_lc_decode: one wavefront = two channels at a time (the two channels of a CPE, or
 // two consecutive SCE frames), FFT in registers (k_core2.h).
 // ---------------------------------------------------------------------------
-#define LC2_WAVES 8
+#define LC2_WAVES 12
 
 struct Lc2Wave {
     cpx T[2][C2_TSTRIDE];         // per channel: coefficients, transposes, then buf[1024]
