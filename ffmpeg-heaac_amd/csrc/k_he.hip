@@ -85,14 +85,16 @@ __device__ __forceinline__ void qmf_analysis_wave(const float *qmf_ds, const flo
 // two consecutive mono frames).  Core IMDCT in registers (k_core2.h), then the analysis
 // filterbank with one 128-point IMDCT per lane: 2 x 32 slots fill the wave.
 // ---------------------------------------------------------------------------
-#define CA_WAVES 5
+#define CA_WAVES 6
 #define CA_U     2080             // fold rows u[32][65] of one channel
 
 struct CaWave {
     float tu[2 * 2 * C2_TSTRIDE]; // core: T[2][C2_TSTRIDE] complex; afterwards u of channel 0
-    float u1[CA_U];               // u of channel 1
-    float x[2][1312];             // analysis input: 288 history + 1024 new samples
+    float x1[1312];               // analysis input of channel 1: 288 history + 1024 new samples
+    float x0u1[CA_U];             // analysis input of channel 0 (first 1312 floats); once its fold is
+                                  // done, u of channel 1
 };
+static_assert(CA_U >= 1312, "x of channel 0 fits under u of channel 1");
 static_assert(CA_U <= 2 * 2 * C2_TSTRIDE, "u rows of channel 0 lie over the core's transpose regions");
 
 __global__ __launch_bounds__(CA_WAVES * WAVE)
@@ -144,7 +146,7 @@ void k_core_ana(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_
             float *st_out = g_state_out + f * state_words;
             const int off_saved = off_saved0 + ch * HEAAC_ST_SAVED;
             const int off_sbr = off_sbr0 + ch * HEAAC_ST_SBR;
-            float *x = w.x[c];
+            float *x = c ? w.x1 : w.x0u1;
             const float *xh_in = st_in + off_sbr + HEAAC_SBR_XHIST;
             float xh[5];
 #pragma unroll
@@ -170,8 +172,9 @@ void k_core_ana(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_
             const unsigned long long f = u / ncore;
             const int ch = (int)(u - f * ncore);
             float *xh_out = g_state_out + f * state_words + off_sbr0 + ch * HEAAC_ST_SBR + HEAAC_SBR_XHIST;
-            const float *x = w.x[c];
-            float *uu = c ? w.u1 : w.tu;
+            // (channel 1's u overwrites channel 0's x: every read of it was issued by then)
+            const float *x = c ? w.x1 : w.x0u1;
+            float *uu = c ? w.x0u1 : w.tu;
 #pragma unroll
             for (int t = 0; t < 5; t++) if (64 * t + lane < 288) xh_out[64 * t + lane] = x[1024 + 64 * t + lane];
             const int k = lane;
@@ -188,7 +191,7 @@ void k_core_ana(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_
         // in[2k] = -f[64-k] (k = 1..31); in[63] = f[32];  then ff_imdct_half (N = 128),
         // lane = (channel, slot)
         {
-            float *row = (lane >> 5 ? w.u1 : w.tu) + (lane & 31) * 65;
+            float *row = (lane >> 5 ? w.x0u1 : w.tu) + (lane & 31) * 65;
             const float *f = row;
             float o[64];
             imdct128_reg([&](int j) -> float {
@@ -208,7 +211,7 @@ void k_core_ana(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             if (c == 1 && !have1) break;
-            const float *uu = c ? w.u1 : w.tu;
+            const float *uu = c ? w.x0u1 : w.tu;
             float *Wo = g_W + (c ? u1 : u0) * 2048;
             for (int t = lane; t < 2048; t += WAVE) Wo[t] = uu[(t >> 6) * 65 + (t & 63)];
         }
