@@ -42,7 +42,7 @@ __device__ __forceinline__ float exp2_half(int twice)
 // and per envelope (mapped scalefactors, estimated envelope, gains) lives in that
 // lane's registers; the only cross-lane steps are the limiter-band sums of
 // sbr_gain_calc, which go through small LDS arrays in the reference's order.
-#define HF_WAVES 8
+#define HF_WAVES 10
 #define XL_STRIDE 81              // X_low row: 40 slots * (re,im) + 1 pad (bank spread)
 #define MAXM 48                   // e_origmapped[7][48] etc. in the reference (sbr.h:165-177)
 #define MAXE 5
