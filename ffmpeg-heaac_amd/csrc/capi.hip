@@ -43,7 +43,7 @@ extern "C" const char *heaac_strerror(int err)
 // size (persistent-kernel tails amortise); keeping the workspace inside the
 // 256 MiB Infinity Cache (chunk <= 4096) costs more in tails than it saves in
 // HBM traffic while the kernels are latency-bound.
-#define HE_CHUNK_FRAMES 65536
+#define HE_CHUNK_FRAMES 131072
 #define WS_W_FLOATS (2 * 2048)
 #define WS_X_FLOATS (2 * 2 * 38 * 64)
 
