@@ -15,6 +15,7 @@ struct HeaacDevice {
     float *d_tab;
     uint16_t *d_rev;
     void *d_work;
+    unsigned *d_queue;      // frame-queue heads of the kernels that draw frames dynamically
     size_t work_bytes;
     size_t max_frames;
     size_t chunk;
@@ -82,6 +83,7 @@ extern "C" int heaac_device_create(HeaacDevice **out, size_t max_frames)
     int rc = HEAAC_OK;
     if (hipMalloc((void **)&d->d_tab, sizeof(t->f)) != hipSuccess ||
         hipMalloc((void **)&d->d_rev, sizeof(t->rev)) != hipSuccess ||
+        hipMalloc((void **)&d->d_queue, 64) != hipSuccess ||
         (d->work_bytes && hipMalloc(&d->d_work, d->work_bytes) != hipSuccess))
         rc = HEAAC_ERR_NOMEM;
     if (rc == HEAAC_OK &&
@@ -103,6 +105,7 @@ extern "C" void heaac_device_destroy(HeaacDevice *d)
     if (d->d_tab) (void)hipFree(d->d_tab);
     if (d->d_rev) (void)hipFree(d->d_rev);
     if (d->d_work) (void)hipFree(d->d_work);
+    if (d->d_queue) (void)hipFree(d->d_queue);
     free(d);
 }
 
@@ -179,7 +182,7 @@ extern "C" int heaac_he_decode_batch(HeaacDevice *dev, int cfg,
                                  d_sbr + f0, d_hdr, d_ps ? d_ps + f0 : NULL,
                                  d_state_in + f0 * words, d_state_out + f0 * words,
                                  (char *)d_pcm + f0 * pcm_bytes, pcm_format,
-                                 ws_W, ws_X, nc, 0, (hipStream_t)stream);
+                                 ws_W, ws_X, dev->d_queue, nc, 0, (hipStream_t)stream);
         if (rc != HEAAC_OK)
             return rc;
     }

@@ -471,7 +471,7 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
                                const HeaacPsFrame *d_ps,
                                const float *d_state_in, float *d_state_out,
                                void *d_pcm, int pcm_format,
-                               float *d_ws_W, float *d_ws_X,
+                               float *d_ws_W, float *d_ws_X, unsigned *d_queue,
                                size_t n, size_t pcm_frame0, hipStream_t s)
 {
     const int ncore = cfg == HEAAC_CFG_HEV1 ? 2 : 1;
@@ -497,7 +497,7 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
         // frames with another PS layout (it skips the rest)
         const int off_ps = off_syn0 + 2 * HEAAC_ST_SYNTH;
         int rc = heaac_launch_hfps(d_tab, d_sbr, d_hdr, d_ps, d_ws_W, d_state_in, d_state_out, words,
-                                   off_sbr0, off_ps, d_ws_X, n, s);
+                                   off_sbr0, off_ps, d_ws_X, n, d_queue, s);
         if (rc != HEAAC_OK) return rc;
         rc = heaac_launch_ps(d_tab, d_ps, d_sbr, d_hdr, d_state_in, d_state_out, words, off_ps, d_ws_X, n, 2, s);
         if (rc != HEAAC_OK) return rc;

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(HFPS_WAVES * WAVE)
 void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g_sbr,
             const HeaacSbrHeader *__restrict__ g_hdr, const HeaacPsFrame *__restrict__ g_ps,
             const float *g_W, const float *g_state_in, float *g_state_out, int state_words,
-            int off_sbr, int off_ps, float *g_X, unsigned long long n)
+            int off_sbr, int off_ps, float *g_X, unsigned long long n, unsigned *g_queue)
 {
     using WT = PsWaveT<false>;
     static_assert(WT::SCR <= HF_XLOW_WORDS, "|s|^2 / subL / subR lie over X_low");
@@ -95,8 +95,13 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
              reinterpret_cast<float (*)[SUB_STRIDE]>(s_a[wave] + (WT::NSUB + 1) * SUB_STRIDE),
              reinterpret_cast<float (*)[33]>(s_c[wave]), s_Hs[wave], s_idx[wave][0], s_idx[wave][1],
              s_idx[wave][0], s_idx[wave][0] };
-    for (unsigned long long f = (unsigned long long)blockIdx.x * HFPS_WAVES + wave; f < n;
-         f += (unsigned long long)gridDim.x * HFPS_WAVES) {
+    // Frames cost between ~0.8x and ~1.3x the mean (envelope counts, smoothing, patches), so the
+    // waves draw them from a queue instead of a fixed stride: the first one is the wave's own index,
+    // each next one is fetched (one atomic, in flight during the frame) from g_queue.
+    unsigned long long f = (unsigned long long)blockIdx.x * HFPS_WAVES + wave;
+    while (f < n) {
+        unsigned nxt = 0;
+        if (lane == 0) nxt = atomicAdd(g_queue, 1u) + gridDim.x * HFPS_WAVES;     // queue starts behind the static ones
         const bool base = __builtin_amdgcn_readfirstlane(!ps_frame_is_general(&g_ps[f]));
         float *Xf = g_X + (f * 2) * (2 * 38 * 64);
         const float *st_in = g_state_in + f * state_words;
@@ -118,11 +123,13 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
         if (!base) {
 #pragma unroll
             for (int i = 0; i < 32; i++) { Xf[i * 64 + lane] = col[i].x; Xf[38 * 64 + i * 64 + lane] = col[i].y; }
+            f = (unsigned long long)__builtin_amdgcn_readfirstlane(nxt);
             continue;
         }
         const HeaacSbrHeader &h = g_hdr[g_sbr[f].hdr];
         const int top = h.kx + h.m;                 // ff_ps_apply(..., sbr->kx[1] + sbr->m[1])
         ps_frame<false, true>(W, g_tab, &g_ps[f], top, st_in + off_ps, st_out + off_ps, Xf, lane, wave, col);
+        f = (unsigned long long)__builtin_amdgcn_readfirstlane(nxt);
     }
 }
 
@@ -155,14 +162,16 @@ extern "C" int heaac_launch_ps(const float *d_tab, const HeaacPsFrame *d_ps, con
 extern "C" int heaac_launch_hfps(const float *d_tab, const HeaacSbrFrame *d_sbr, const HeaacSbrHeader *d_hdr,
                                  const HeaacPsFrame *d_ps, const float *d_ws_W,
                                  const float *d_state_in, float *d_state_out, int state_words,
-                                 int off_sbr, int off_ps, float *d_ws_X, size_t n, hipStream_t s)
+                                 int off_sbr, int off_ps, float *d_ws_X, size_t n, unsigned *d_queue,
+                                 hipStream_t s)
 {
     if (!n) return HEAAC_OK;
     unsigned long long g = (n + HFPS_WAVES - 1) / HFPS_WAVES;
     if (g > 256) g = 256;
+    if (hipMemsetAsync(d_queue, 0, sizeof(unsigned), s) != hipSuccess) return HEAAC_ERR_HIP;
     hipLaunchKernelGGL(k_hfps, dim3((unsigned)g), dim3(HFPS_WAVES * WAVE), 0, s, d_tab, d_sbr, d_hdr, d_ps,
                        d_ws_W, d_state_in, d_state_out, state_words, off_sbr, off_ps, d_ws_X,
-                       (unsigned long long)n);
+                       (unsigned long long)n, d_queue);
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
 }
 

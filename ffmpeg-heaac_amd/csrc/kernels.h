@@ -23,7 +23,7 @@ int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cfg,
                     const HeaacPsFrame *d_ps,
                     const float *d_state_in, float *d_state_out,
                     void *d_pcm, int pcm_format,
-                    float *d_ws_W, float *d_ws_X,
+                    float *d_ws_W, float *d_ws_X, unsigned *d_queue,
                     size_t n, size_t pcm_frame0, hipStream_t s);
 
 int heaac_launch_ps(const float *d_tab, const HeaacPsFrame *d_ps, const HeaacSbrFrame *d_sbr,
@@ -33,7 +33,7 @@ int heaac_launch_ps(const float *d_tab, const HeaacPsFrame *d_ps, const HeaacSbr
 int heaac_launch_hfps(const float *d_tab, const HeaacSbrFrame *d_sbr, const HeaacSbrHeader *d_hdr,
                       const HeaacPsFrame *d_ps, const float *d_ws_W,
                       const float *d_state_in, float *d_state_out, int state_words,
-                      int off_sbr, int off_ps, float *d_ws_X, size_t n, hipStream_t s);
+                      int off_sbr, int off_ps, float *d_ws_X, size_t n, unsigned *d_queue, hipStream_t s);
 
 int heaac_launch_qmf_analysis(const float *d_tab, const float *d_in, const float *d_xh_in,
                               float *d_xh_out, float *d_W, float scale, size_t n, hipStream_t s);
