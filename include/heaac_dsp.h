@@ -216,7 +216,10 @@ typedef struct HeaacPsFrame {
 
 /* Opaque device-side context: immutable tables (twiddles, windows, QMF
  * prototype, noise table, PS filters) resident in HBM for one device, plus a
- * scratch workspace sized for `max_frames`.  One per GPU/process. */
+ * scratch workspace sized for `max_frames`.  One per GPU/process.  The HE
+ * calls pass intermediates (and a frame queue) through that workspace, so the
+ * calls on one HeaacDevice must be ordered on one stream (or serialised by the
+ * caller); concurrent streams take one HeaacDevice each. */
 typedef struct HeaacDevice HeaacDevice;
 
 /* Create the context on the current HIP device.  Returns 0 on success,
