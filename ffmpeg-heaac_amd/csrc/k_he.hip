@@ -344,7 +344,7 @@ __global__ __launch_bounds__(SYN_WAVES_F32 * WAVE)
 void k_synth(const float *__restrict__ g_tab, const float *g_X,
              const float *g_state_in, float *g_state_out, int state_words, int off_syn0,
              int nout, int copy_mono, void *__restrict__ g_pcm, float scale, float bias,
-             unsigned long long n_frames, unsigned long long pcm_frame0)
+             unsigned long long n_frames, unsigned long long pcm_frame0, unsigned *g_queue)
 {
     constexpr int NW = SYN_WAVES_F32;
     __shared__ SynLdsT<NW> S;
@@ -356,8 +356,12 @@ void k_synth(const float *__restrict__ g_tab, const float *g_X,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
     SynWave &w = S.w[wave];
     uint32_t lpcm[16];          // left channel of an interleaved int16 pair: lane n, slots 2j | 2j + 1 << 16
-    for (unsigned long long f = (unsigned long long)blockIdx.x * NW + wave; f < n_frames;
-         f += (unsigned long long)gridDim.x * NW) {
+    // frames are drawn from a queue (first one: the wave's own index; the next index is fetched
+    // while the current frame is processed), which evens out the waves' finishing times
+    unsigned long long f = (unsigned long long)blockIdx.x * NW + wave;
+    while (f < n_frames) {
+        unsigned nxt = 0;
+        if (lane == 0) nxt = atomicAdd(g_queue, 1u) + gridDim.x * NW;
         const float *st_in = g_state_in + f * state_words + off_syn0;
         float *st_out = g_state_out + f * state_words + off_syn0;
         for (int ch = 0; ch < nout; ch++) {
@@ -391,6 +395,7 @@ void k_synth(const float *__restrict__ g_tab, const float *g_X,
                               });
             }
         }
+        f = (unsigned long long)__builtin_amdgcn_readfirstlane(nxt);
     }
 }
 
@@ -513,14 +518,15 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
     }
     const float scale = -1024 * sf_scale, bias = HEAAC_ADD_BIAS;
     const dim3 g(he_grid(n, SYN_WAVES_F32)), b(SYN_WAVES_F32 * WAVE);
+    if (hipMemsetAsync(d_queue + 2, 0, sizeof(unsigned), s) != hipSuccess) return HEAAC_ERR_HIP;
     if (pcm_format == HEAAC_PCM_F32_PLANAR)
         hipLaunchKernelGGL((k_synth<HEAAC_PCM_F32_PLANAR>), g, b, 0, s, d_tab, d_ws_X, d_state_in, d_state_out,
                            words, off_syn0, nout, copy_mono, d_pcm, scale, bias,
-                           (unsigned long long)n, (unsigned long long)pcm_frame0);
+                           (unsigned long long)n, (unsigned long long)pcm_frame0, d_queue + 2);
     else if (pcm_format == HEAAC_PCM_S16_INTERLEAVED)
         hipLaunchKernelGGL((k_synth<HEAAC_PCM_S16_INTERLEAVED>), g, b, 0, s, d_tab, d_ws_X, d_state_in, d_state_out,
                            words, off_syn0, nout, copy_mono, d_pcm, scale, bias,
-                           (unsigned long long)n, (unsigned long long)pcm_frame0);
+                           (unsigned long long)n, (unsigned long long)pcm_frame0, d_queue + 2);
     else
         return HEAAC_ERR_ARG;
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
