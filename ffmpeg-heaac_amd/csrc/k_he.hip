@@ -493,6 +493,9 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
     const unsigned long long units = (unsigned long long)n * ncore;
     const float sf_scale = HEAAC_SF_SCALE;
 
+    // queue heads of the kernels that draw frames dynamically (k_hfps: [0], k_synth: [2]); the static
+    // stride stays where it measured faster (k_core_ana, k_hfadj: neighbouring waves share lines)
+    if (hipMemsetAsync(d_queue, 0, 64, s) != hipSuccess) return HEAAC_ERR_HIP;
     hipLaunchKernelGGL(k_core_ana, dim3(he_grid((units + 1) / 2, CA_WAVES)), dim3(CA_WAVES * WAVE), 0, s,
                        d_tab, d_rev, d_coeffs, d_ics, d_state_in, d_state_out, words, ncore,
                        off_saved0, off_sbr0, d_ws_W, 1 / (-1024 * sf_scale), units);
@@ -518,7 +521,6 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
     }
     const float scale = -1024 * sf_scale, bias = HEAAC_ADD_BIAS;
     const dim3 g(he_grid(n, SYN_WAVES_F32)), b(SYN_WAVES_F32 * WAVE);
-    if (hipMemsetAsync(d_queue + 2, 0, sizeof(unsigned), s) != hipSuccess) return HEAAC_ERR_HIP;
     if (pcm_format == HEAAC_PCM_F32_PLANAR)
         hipLaunchKernelGGL((k_synth<HEAAC_PCM_F32_PLANAR>), g, b, 0, s, d_tab, d_ws_X, d_state_in, d_state_out,
                            words, off_syn0, nout, copy_mono, d_pcm, scale, bias,

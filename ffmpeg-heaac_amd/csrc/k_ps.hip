@@ -168,7 +168,6 @@ extern "C" int heaac_launch_hfps(const float *d_tab, const HeaacSbrFrame *d_sbr,
     if (!n) return HEAAC_OK;
     unsigned long long g = (n + HFPS_WAVES - 1) / HFPS_WAVES;
     if (g > 256) g = 256;
-    if (hipMemsetAsync(d_queue, 0, sizeof(unsigned), s) != hipSuccess) return HEAAC_ERR_HIP;
     hipLaunchKernelGGL(k_hfps, dim3((unsigned)g), dim3(HFPS_WAVES * WAVE), 0, s, d_tab, d_sbr, d_hdr, d_ps,
                        d_ws_W, d_state_in, d_state_out, state_words, off_sbr, off_ps, d_ws_X,
                        (unsigned long long)n, d_queue);
