@@ -223,7 +223,7 @@ __global__ __launch_bounds__(HF_WAVES * WAVE)
 void k_hfadj(const float *__restrict__ g_tab,
              const HeaacSbrFrame *__restrict__ g_sbr, const HeaacSbrHeader *__restrict__ g_hdr,
              const float *g_W, const float *g_state_in, float *g_state_out, int state_words,
-             int ncore, int off_sbr0, float *g_X, unsigned long long n_units)
+             int ncore, int off_sbr0, float *g_X, unsigned long long n_units, unsigned *g_queue)
 {
     __shared__ float s_xlow[HF_WAVES][HF_XLOW_WORDS], s_aux[HF_WAVES][HF_AUX_WORDS], s_rec[HF_WAVES][HF_REC_WORDS];
     __shared__ float s_noise[1024];              // sbr_noise_table, staged once per workgroup
@@ -231,8 +231,15 @@ void k_hfadj(const float *__restrict__ g_tab,
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
     const HfWave S = hf_wave_view(s_xlow[wave], s_aux[wave], s_rec[wave]);
-    for (unsigned long long u = (unsigned long long)blockIdx.x * HF_WAVES + wave; u < n_units;
-         u += (unsigned long long)gridDim.x * HF_WAVES) {
+    // Units are drawn from a queue two at a time (for a CPE: the two channels of one frame, which
+    // share the frame's side info; one hot address serves < 100 M atomics/s): the first pair is the
+    // wave's own index, the next one is fetched while the current one is processed.
+    unsigned long long ub = ((unsigned long long)blockIdx.x * HF_WAVES + wave) * 2;
+    while (ub < n_units) {
+        unsigned nxt = 0;
+        if (lane == 0) nxt = atomicAdd(g_queue, 2u) + gridDim.x * HF_WAVES * 2;
+      for (int qi = 0; qi < 2 && ub + qi < n_units; qi++) {
+        const unsigned long long u = ub + qi;
         const unsigned long long f = u / ncore;
         const int ch = (int)(u - f * ncore);
         const int off = off_sbr0 + ch * HEAAC_ST_SBR;
@@ -240,6 +247,8 @@ void k_hfadj(const float *__restrict__ g_tab,
         hf_channel(S, s_noise, &g_sbr[f], g_hdr, ch, g_W + u * 2048,
                    g_state_in + f * state_words + off, g_state_out + f * state_words + off, lane,
                    [&](int i, float re, float im) { X0[i * 64 + lane] = re; X1[i * 64 + lane] = im; });
+      }
+        ub = (unsigned long long)__builtin_amdgcn_readfirstlane(nxt);
     }
 }
 
@@ -510,9 +519,9 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
         rc = heaac_launch_ps(d_tab, d_ps, d_sbr, d_hdr, d_state_in, d_state_out, words, off_ps, d_ws_X, n, 2, s);
         if (rc != HEAAC_OK) return rc;
     } else {
-        hipLaunchKernelGGL(k_hfadj, dim3(he_grid(units, HF_WAVES)), dim3(HF_WAVES * WAVE), 0, s,
+        hipLaunchKernelGGL(k_hfadj, dim3(he_grid((units + 1) / 2, HF_WAVES)), dim3(HF_WAVES * WAVE), 0, s,
                            d_tab, d_sbr, d_hdr, d_ws_W, d_state_in, d_state_out, words, ncore, off_sbr0,
-                           d_ws_X, units);
+                           d_ws_X, units, d_queue + 1);
         if (cfg == HEAAC_CFG_HEV2) {
             int rc = heaac_launch_ps(d_tab, d_ps, d_sbr, d_hdr, d_state_in, d_state_out, words,
                                      off_syn0 + 2 * HEAAC_ST_SYNTH, d_ws_X, n, 3, s);
