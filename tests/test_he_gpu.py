@@ -217,3 +217,32 @@ def test_he_decode_is_graph_capturable(pkg, oracle, dev):
     assert np.array_equal(pcm.cpu().numpy(), ref_pcm)
     nbad, where = _mismatch(st_out.cpu().numpy(), ref_state)
     assert nbad == 0, where
+
+
+def _random_headers(pkg, rng, count):
+    """`count` valid SBR headers drawn over the whole parameter space (and three SBR rates)."""
+    hs = []
+    while len(hs) < count:
+        try:
+            hs.append(pkg.sbr_make_header(
+                sample_rate=int(rng.choice([48000, 44100, 32000])),
+                start_freq=int(rng.integers(0, 16)), stop_freq=int(rng.integers(0, 14)),
+                xover=int(rng.integers(0, 4)), freq_scale=int(rng.integers(0, 4)),
+                alter_scale=int(rng.integers(0, 2)), noise_bands=int(rng.integers(0, 4)),
+                limiter_bands=int(rng.integers(0, 4)), limiter_gains=int(rng.integers(0, 4)),
+                interpol_freq=int(rng.integers(0, 2)), smoothing_mode=int(rng.integers(0, 2)),
+                amp_res=int(rng.integers(0, 2))))
+        except ValueError:
+            pass                                    # the reference rejects this combination too
+    return np.concatenate(hs)
+
+
+@pytest.mark.parametrize("cfg_name", ["CFG_HEV1", "CFG_HEV2"])
+def test_random_sbr_headers(pkg, oracle, dev, cfg_name):
+    """48 random valid headers (band layouts, patch counts, limiter / smoothing / interpolation
+    modes), one stream each, four chained frames."""
+    rng = np.random.default_rng(4242)
+    hdr = _random_headers(pkg, rng, 48)
+    n = 2 * len(hdr)
+    _run_chain(pkg, oracle, dev, getattr(pkg, cfg_name), n, 4, 71, hdr, hdr_choice=np.arange(n) % len(hdr),
+               ps_mode="mix")
