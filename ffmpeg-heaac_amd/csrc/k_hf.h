@@ -547,6 +547,15 @@ __device__ __forceinline__ void hf_channel(const HfWave &w, const float *g_noise
             }
         }
         const unsigned noise0 = idxnoise + (unsigned)(m + 1) - (unsigned)(2 * t0) * (unsigned)m_max;
+        // sinusoid phase of the first slot with output (i = 2 t0: slot 0), and the step to the next
+        v2f ph_cur;
+        {
+            const int isine = idxsine & 3;
+            const int phi_re = isine == 0 ? 1 : isine == 2 ? -1 : 0;
+            const int phi_im = isine == 1 ? 1 : isine == 3 ? -1 : 0;
+            ph_cur = v2f{(float)phi_re, (float)(phi_im * phi_sign0)};
+        }
+        const v2f ph_rot = v2f{(float)-phi_sign0, (float)phi_sign0};     // (re, s im) -> (-s (s im), s re)
         v2f xq[4], nq[4];
 #pragma unroll
         for (int i = 0; i < 38; i++) {
@@ -595,11 +604,10 @@ __device__ __forceinline__ void hf_channel(const HfWave &w, const float *g_noise
                     f = a;
                 }
                 Y = xh * bc(f.x);
-                const int slot = i - 2 * t0;
-                const int isine = (idxsine + slot) & 3;
-                const int phi_re = isine == 0 ? 1 : isine == 2 ? -1 : 0;
-                const int phi_im = isine == 1 ? 1 : isine == 3 ? -1 : 0;
-                const v2f ph = v2f{(float)phi_re, (float)(phi_im * phi_sign0)};
+                // phi[f_indexsine + slot] (:1676-1698): (1,0) (0,1) (-1,0) (0,-1), the imaginary part
+                // signed by phi_sign0 -- each slot's pair is the previous one times i (exact: +-1, 0)
+                const v2f ph = ph_cur;
+                ph_cur = ph_rot * swp(ph_cur) + v2f{0.0f, 0.0f};      // (+ 0: the zero stays +0 as (float)0 is)
                 const v2f y_sine = Y + bc(s_e) * ph;
                 if (!plain) {
                     // sbr_noise_table[(f_indexnoise + slot m_max + m + 1) & 0x1ff] where no sinusoid sits
