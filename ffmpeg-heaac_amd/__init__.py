@@ -96,6 +96,7 @@ EXPORTED = [
     "heaac_device_create", "heaac_device_destroy", "heaac_device_workspace_bytes",
     "heaac_strerror", "heaac_imdct_half_batch", "heaac_lc_decode_batch",
     "heaac_he_decode_batch", "heaac_qmf_analysis_batch", "heaac_qmf_synthesis_batch",
+    "heaac_qmf_synthesis_ds_batch",
     "heaac_sbr_make_header", "heaac_build_info", "heaac_spectral_tools_batch",
     # heaac_fft.h
     "ff_fft_init", "ff_fft_end", "ff_fft_permute", "ff_fft_calc",
@@ -283,4 +284,15 @@ class Device:
         _check(lib().heaac_qmf_synthesis_batch(self._h, _ptr(X), _ptr(v), _ptr(vo), _ptr(out),
                                                C.c_float(scale), C.c_float(bias), C.c_size_t(n), _stream()),
                "heaac_qmf_synthesis_batch")
+        return out, vo
+
+    def qmf_synthesis_ds(self, X, v, scale=2.0 ** -15, bias=385.0):
+        """Downsampled synthesis bank (div = 1): X [n][2][32][64], v [n][576] -> out [n][1024]."""
+        import torch
+        n = X.shape[0]
+        out = torch.empty((n, 1024), dtype=torch.float32, device=X.device)
+        vo = torch.empty_like(v)
+        _check(lib().heaac_qmf_synthesis_ds_batch(self._h, _ptr(X), _ptr(v), _ptr(vo), _ptr(out),
+                                                  C.c_float(scale), C.c_float(bias), C.c_size_t(n), _stream()),
+               "heaac_qmf_synthesis_ds_batch")
         return out, vo

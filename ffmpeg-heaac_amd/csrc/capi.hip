@@ -212,6 +212,18 @@ extern "C" int heaac_qmf_synthesis_batch(HeaacDevice *dev, const float *d_X,
                                       (hipStream_t)stream);
 }
 
+extern "C" int heaac_qmf_synthesis_ds_batch(HeaacDevice *dev, const float *d_X,
+                                            const float *d_v_in, float *d_v_out,
+                                            float *d_out, float scale, float bias,
+                                            size_t n, void *stream)
+{
+    if (!dev) return HEAAC_ERR_ARG;
+    if (n == 0) return HEAAC_OK;
+    if (!d_X || !d_v_in || !d_v_out || !d_out) return HEAAC_ERR_ARG;
+    return heaac_launch_qmf_synthesis_ds(dev->d_tab, d_X, d_v_in, d_v_out, d_out, scale, bias, n,
+                                         (hipStream_t)stream);
+}
+
 // Debug/test hook: device pointers of the stage workspace of the LAST chunk
 // (W[chunk][2][32][32][2], X[chunk][2][2][38][64]).  Not part of include/*.h.
 extern "C" int heaac_debug_workspace(HeaacDevice *dev, float **d_W, float **d_X, size_t *chunk)

@@ -461,6 +461,64 @@ void k_qmf_synthesis(const float *__restrict__ g_tab, const float *__restrict__ 
     }
 }
 
+// Downsampled synthesis bank (div = 1, aacsbr.c:1175-1230): one wave per channel.  Lanes 0..31 run
+// the slots' 128-point IMDCTs (one per slot), then every lane forms two output samples per pass:
+// lane = (slot parity, n).
+#define DS_STRIDE 65
+__global__ __launch_bounds__(SYN_WAVES * WAVE)
+void k_qmf_synthesis_ds(const float *__restrict__ g_tab, const float *__restrict__ g_X /* [n][2][32][64] */,
+                        const float *g_v_in, float *g_v_out, float *__restrict__ g_out,
+                        float scale, float bias, unsigned long long n)
+{
+    __shared__ float s_win[320];
+    __shared__ float s_rot[64], s_c16[8], s_c32[12];
+    __shared__ float s_vb[SYN_WAVES][41 * DS_STRIDE];
+    for (int i = threadIdx.x; i < 320; i += blockDim.x) s_win[i] = g_tab[TB_QMF_DS + i];
+    if (threadIdx.x < 64) s_rot[threadIdx.x] = g_tab[TB_ROT128S + threadIdx.x];
+    if (threadIdx.x < 5) s_c16[threadIdx.x] = g_tab[TB_COS16 + threadIdx.x];
+    if (threadIdx.x < 9) s_c32[threadIdx.x] = g_tab[TB_COS32 + threadIdx.x];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
+    float *vb = s_vb[wave];
+    for (unsigned long long u = (unsigned long long)blockIdx.x * SYN_WAVES + wave; u < n;
+         u += (unsigned long long)gridDim.x * SYN_WAVES) {
+        const float *X0 = g_X + u * 4096, *X1 = X0 + 2048;
+        // history: 9 slots of 64 behind the 32 new ones
+        for (int t = lane; t < 576; t += WAVE) vb[(32 + (t >> 6)) * DS_STRIDE + (t & 63)] = g_v_in[u * 576 + t];
+        if (lane < 32) {
+            const int i = lane;
+            const float *r0 = X0 + i * 64, *r1 = X1 + i * 64;
+            float o[64];
+            // X[0][i][n] = -X[0][i][n]; X[0][i][32+n] = X[1][i][31-n]
+            imdct128_reg([&](int j) -> float { return j < 32 ? -r0[j] : r1[63 - j]; }, o, s_rot, s_c16, s_c32);
+            float *v = vb + (31 - i) * DS_STRIDE;
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                v[k]      =  o[63 - 2 * k];
+                v[63 - k] = -o[62 - 2 * k];
+            }
+        }
+        wave_sync();
+        {
+            const int nn = lane & 31, par = lane >> 5;
+            float wt[10];
+#pragma unroll
+            for (int j = 0; j < 10; j++) wt[j] = s_win[32 * j + nn];
+            const bool scale_and_bias = scale != 1.0f || bias != 0.0f;
+            for (int i = par; i < 32; i += 2) {
+                const float *v = vb + (31 - i) * DS_STRIDE + nn;
+                float acc = v[0] * wt[0] + 0.0f;
+#pragma unroll
+                for (int j = 1; j < 10; j++) acc = v[j * DS_STRIDE + ((j & 1) ? 32 : 0)] * wt[j] + acc;
+                if (scale_and_bias) acc = acc * scale + bias;
+                g_out[u * 1024 + 32 * i + nn] = acc;
+            }
+        }
+        for (int t = lane; t < 576; t += WAVE) g_v_out[u * 576 + t] = vb[(t >> 6) * DS_STRIDE + (t & 63)];
+        wave_sync();
+    }
+}
+
 // ===========================================================================
 // host side: launch the HE pipeline over one chunk of frames
 // ===========================================================================
@@ -558,6 +616,16 @@ extern "C" int heaac_launch_qmf_synthesis(const float *d_tab, const float *d_X, 
 {
     if (!n) return HEAAC_OK;
     hipLaunchKernelGGL(k_qmf_synthesis, dim3(he_grid(n, SYN_WAVES)), dim3(SYN_WAVES * WAVE), 0, s,
+                       d_tab, d_X, d_v_in, d_v_out, d_out, scale, bias, (unsigned long long)n);
+    return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
+}
+
+extern "C" int heaac_launch_qmf_synthesis_ds(const float *d_tab, const float *d_X, const float *d_v_in,
+                                            float *d_v_out, float *d_out, float scale, float bias,
+                                            size_t n, hipStream_t s)
+{
+    if (n == 0) return HEAAC_OK;
+    hipLaunchKernelGGL(k_qmf_synthesis_ds, dim3(he_grid(n, SYN_WAVES)), dim3(SYN_WAVES * WAVE), 0, s,
                        d_tab, d_X, d_v_in, d_v_out, d_out, scale, bias, (unsigned long long)n);
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
 }

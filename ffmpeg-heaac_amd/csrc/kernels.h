@@ -41,6 +41,10 @@ int heaac_launch_qmf_analysis(const float *d_tab, const float *d_in, const float
 int heaac_launch_qmf_synthesis(const float *d_tab, const float *d_X, const float *d_v_in,
                                float *d_v_out, float *d_out, float scale, float bias,
                                size_t n, hipStream_t s);
+
+int heaac_launch_qmf_synthesis_ds(const float *d_tab, const float *d_X, const float *d_v_in,
+                                  float *d_v_out, float *d_out, float scale, float bias,
+                                  size_t n, hipStream_t s);
 }
 
 extern "C" {

@@ -303,6 +303,16 @@ int heaac_qmf_synthesis_batch(HeaacDevice *dev, const float *d_X,
                               float *d_out, float scale, float bias,
                               size_t n, void *stream);
 
+/* Downsampled synthesis bank: sbr_qmf_synthesis with div = 1 (aacsbr.c:1175-1230), what
+ * ff_sbr_apply selects when the output runs at the core rate (aacsbr.c:1719):
+ *   d_X [n][2][32][64] as above (bands 0..31 of each row are used),
+ *   d_v_in/out [n][576], d_out [n][1024]; out = acc*scale + bias.
+ * The fused heaac_he_decode_batch implements the dual-rate bank (div = 0). */
+int heaac_qmf_synthesis_ds_batch(HeaacDevice *dev, const float *d_X,
+                                 const float *d_v_in, float *d_v_out,
+                                 float *d_out, float scale, float bias,
+                                 size_t n, void *stream);
+
 /* ------------------------------------------------------------------------
  * Spectral tools that run on the dequantised spectrum before the IMDCT
  * (SURVEY s8f N1): apply_mid_side_stereo (aacdec.c:1390-1411),

@@ -192,6 +192,43 @@ void oracle_qmf_synthesis(const float *Xin, float *v, float *out, float scale, f
     qmf_synthesis(out, X, v, bias, scale);
 }
 
+/* Downsampled synthesis QMF bank: sbr_qmf_synthesis with div = 1 (aacsbr.c:1175-1230): 32 output
+ * samples per slot from one 128-point IMDCT, window sbr_qmf_window_ds, ring slots of 64 values.
+ * Same linear restatement as above: slot i at vb + (31-i)*64, 576 history values behind. */
+void oracle_qmf_synthesis_ds(const float *Xin, float *vstate, float *out, float scale, float bias)
+{
+    const or_tables *t = oracle_tables();
+    static const int voff[10] = { 0, 96, 128, 224, 256, 352, 384, 480, 512, 608 };
+    float vb[41 * 64];
+    float mdct_buf[64], in[64];
+    int i, n, j;
+    int scale_and_bias = scale != 1.0f || bias != 0.0f;
+    memcpy(vb + 32 * 64, vstate, 576 * sizeof(float));
+    for (i = 0; i < 32; i++) {
+        const float *X0 = Xin + i * 64, *X1 = Xin + (32 + i) * 64;
+        float *v = vb + (31 - i) * 64;
+        for (n = 0; n < 32; n++) {
+            in[n]      = -X0[n];
+            in[32 + n] =  X1[31 - n];
+        }
+        oracle_imdct_half(2, mdct_buf, in);
+        for (n = 0; n < 32; n++) {
+            v[     n] =  mdct_buf[63 - 2 * n];
+            v[63 - n] = -mdct_buf[62 - 2 * n];
+        }
+        for (n = 0; n < 32; n++)
+            out[n] = v[n] * t->qmf_ds[n] + 0.0f;
+        for (j = 1; j < 10; j++)
+            for (n = 0; n < 32; n++)
+                out[n] = v[voff[j] + n] * t->qmf_ds[32 * j + n] + out[n];
+        if (scale_and_bias)
+            for (n = 0; n < 32; n++)
+                out[n] = out[n] * scale + bias;
+        out += 32;
+    }
+    memcpy(vstate, vb, 576 * sizeof(float));
+}
+
 /* ------------------------------------------------------------------ */
 /* a13 autocorrelate / inverse filter / chirp, aacsbr.c:1232-1334       */
 /* ------------------------------------------------------------------ */

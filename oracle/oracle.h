@@ -80,6 +80,8 @@ int  oracle_float_to_int16_one(float f);                           /* dsputil.c:
 /* ---- SBR stages on plain arrays (a11, a20), for stage tests ---- */
 void oracle_qmf_analysis(const float *in /*1024*/, float *xhist /*288 in/out*/,
                          float *W /*[32][32][2]*/, float scale);    /* aacsbr.c:1136 */
+/* div = 1 (downsampled bank): X [2][32][64] (bands 0..31 used), v 576 in/out, out 1024 */
+void oracle_qmf_synthesis_ds(const float *X, float *v, float *out, float scale, float bias);
 void oracle_qmf_synthesis(const float *X /*[2][32][64]*/, float *v /*1152 in/out*/,
                           float *out /*2048*/, float scale, float bias); /* aacsbr.c:1175 */
 

@@ -157,6 +157,14 @@ def qmf_synthesis(X, v, scale=2.0 ** -15, bias=385.0):
     return out, v
 
 
+def qmf_synthesis_ds(X, v, scale=2.0 ** -15, bias=385.0):
+    X = _f32(X)
+    v = _f32(v).copy()
+    out = np.zeros(1024, np.float32)
+    lib().oracle_qmf_synthesis_ds(_p(X), _p(v), _p(out), C.c_float(scale), C.c_float(bias))
+    return out, v
+
+
 def float_to_int16(a):
     a = _f32(a)
     f = lib().oracle_float_to_int16_one

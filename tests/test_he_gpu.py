@@ -49,6 +49,25 @@ def test_qmf_synthesis_batch(pkg, oracle, dev, n):
         assert np.array_equal(_bits(vo[i]), _bits(rv)), i
 
 
+@pytest.mark.parametrize("n", [1, 7, 100])
+def test_qmf_synthesis_downsampled_batch(pkg, oracle, dev, n):
+    """sbr_qmf_synthesis with div = 1 (aacsbr.c:1175-1230), chained over two frames."""
+    import torch
+    rng = np.random.default_rng(150 + n)
+    v = (rng.standard_normal((n, 576)) * 5).astype(np.float32)
+    d_v = torch.from_numpy(v).cuda()
+    for step in range(2):
+        X = (rng.standard_normal((n, 2, 32, 64)) * 40).astype(np.float32)
+        out, d_v = dev.qmf_synthesis_ds(torch.from_numpy(X).cuda(), d_v, scale=1.0 if step else 2.0 ** -15,
+                                        bias=0.0 if step else 385.0)
+        out, vo = out.cpu().numpy(), d_v.cpu().numpy()
+        for i in range(n):
+            r, v[i] = oracle.qmf_synthesis_ds(X[i], v[i], scale=1.0 if step else 2.0 ** -15,
+                                              bias=0.0 if step else 385.0)
+            assert np.array_equal(_bits(out[i]), _bits(r)), (step, i)
+        assert np.array_equal(_bits(vo), _bits(v)), step
+
+
 def _run_chain(pkg, oracle, dev, cfg, n, steps, seed, hdr, ps_mode="20", hdr_choice=None, fmt=None,
                check_state=True, coupling=0.0):
     import torch

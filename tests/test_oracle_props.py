@@ -146,3 +146,25 @@ def test_float_to_int16_bias_trick(oracle):
     got = oracle.float_to_int16(vals)
     want = np.clip(np.round((vals.astype(np.float64) - 385.0) * 32768.0), -32768, 32767).astype(np.int16)
     assert np.array_equal(got, want), (got, want)
+
+
+def test_downsampled_synthesis_is_the_decimated_bank(oracle):
+    """div = 1 reconstructs a 32-band analysis (the low half of the spectrum) at the core rate:
+    analysis (32 bands) -> downsampled synthesis returns the delayed input."""
+    rng = np.random.default_rng(9)
+    x = np.zeros(8 * 1024, np.float32)
+    t = np.arange(x.size)
+    x[:] = (np.sin(2 * np.pi * 0.01 * t) + 0.5 * np.sin(2 * np.pi * 0.11 * t + 1.0)) * 1000
+    xhist = np.zeros(288, np.float32); v = np.zeros(576, np.float32)
+    outs = []
+    for f in range(8):
+        W, xhist = oracle.qmf_analysis(x[f * 1024:(f + 1) * 1024], xhist, scale=1.0)
+        X = np.zeros((2, 32, 64), np.float32)
+        X[0, :, :32] = W[:, :, 0]; X[1, :, :32] = W[:, :, 1]
+        o, v = oracle.qmf_synthesis_ds(X, v, scale=1.0, bias=0.0)
+        outs.append(o)
+    y = np.concatenate(outs)
+    best = max(range(200, 400), key=lambda d: abs(np.dot(x[2048:6000], y[2048 + d:6000 + d])))
+    a, b = x[2048:6000], y[2048 + best:6000 + best]
+    corr = np.dot(a, b) / np.sqrt(np.dot(a, a) * np.dot(b, b))
+    assert abs(corr) > 0.9999, (best, corr)
