@@ -81,12 +81,17 @@ TNS_DT = np.dtype([
     ("present", "u1"), ("n_filt", "u1", (8,)), ("length", "u1", (8, 4)), ("direction", "u1", (8, 4)),
     ("order", "u1", (8, 4)), ("pad", "u1", (3,)), ("coef", "<f4", (8, 4, 20)),
 ])
-TOOLS_CH_DT = np.dtype([("ics", TOOLS_ICS_DT), ("band_type", "u1", (128,)), ("sf", "<f4", (128,)), ("tns", TNS_DT)])
+PRED_DT = np.dtype([("predictor_present", "u1"), ("predictor_reset_group", "u1"), ("pred_sfb_max", "u1"),
+                    ("pad", "u1"), ("prediction_used", "u1", (44,))])
+PRED_STATE_DT = np.dtype([("cor0", "<f4"), ("cor1", "<f4"), ("var0", "<f4"), ("var1", "<f4"), ("r0", "<f4"), ("r1", "<f4")])
+MAX_PREDICTORS = 672
+TOOLS_CH_DT = np.dtype([("ics", TOOLS_ICS_DT), ("band_type", "u1", (128,)), ("sf", "<f4", (128,)), ("tns", TNS_DT),
+                        ("pred", PRED_DT)])
 TOOLS_FRAME_DT = np.dtype([
     ("common_window", "u1"), ("ms_present", "u1"), ("pad", "u1", (2,)), ("ms_mask", "u1", (128,)),
     ("ch", TOOLS_CH_DT, (2,)),
 ])
-assert TOOLS_ICS_DT.itemsize == 144 and TNS_DT.itemsize == 2668 and TOOLS_FRAME_DT.itemsize == 7036
+assert TOOLS_ICS_DT.itemsize == 144 and TNS_DT.itemsize == 2668 and TOOLS_FRAME_DT.itemsize == 7132
 assert SBR_HDR_DT.itemsize == 532 and SBR_CH_DT.itemsize == 336
 assert SBR_FRAME_DT.itemsize == 680 and PS_FRAME_DT.itemsize == 532
 
@@ -233,16 +238,20 @@ class Device:
         return pcm, state_out
 
     # -- spectral tools before the IMDCT (M/S, intensity stereo, TNS), in place --
-    def spectral_tools(self, channels, coeffs, tools, rng=None):
-        """rng: int32 [n] generator states (updated in place) -> noise substitution runs too."""
+    def spectral_tools(self, channels, coeffs, tools, rng=None, pred=None):
+        """rng: int32 [n] generator states (updated in place) -> noise substitution runs too.
+        pred: float32 [n][channels][672][6] predictor states (in place) -> AAC-Main prediction too."""
         import torch
         n = coeffs.shape[0]
         assert coeffs.dtype == torch.float32 and coeffs.numel() == n * channels * 1024
         assert tools.dtype == torch.uint8 and tools.numel() == n * TOOLS_FRAME_DT.itemsize
         assert rng is None or (rng.dtype == torch.int32 and rng.numel() == n)
+        assert pred is None or (pred.dtype == torch.float32 and pred.numel() == n * channels * MAX_PREDICTORS * 6)
         _check(lib().heaac_spectral_tools_batch(self._h, channels, _ptr(coeffs), _ptr(tools),
                                                 _ptr(rng) if rng is not None else None,
                                                 _ptr(rng) if rng is not None else None,
+                                                _ptr(pred) if pred is not None else None,
+                                                _ptr(pred) if pred is not None else None,
                                                 C.c_size_t(n), _stream()), "heaac_spectral_tools_batch")
         return coeffs
 

@@ -140,15 +140,17 @@ extern "C" int heaac_lc_decode_batch(HeaacDevice *dev, int channels,
 extern "C" int heaac_spectral_tools_batch(HeaacDevice *dev, int channels, float *d_coeffs,
                                           const HeaacToolsFrame *d_tools,
                                           const int32_t *d_rng_in, int32_t *d_rng_out,
+                                          const HeaacPredictorState *d_pred_in, HeaacPredictorState *d_pred_out,
                                           size_t n, void *stream)
 {
-    if (!dev || channels < 1 || channels > 2 || (d_rng_in && !d_rng_out))
+    if (!dev || channels < 1 || channels > 2 || (d_rng_in && !d_rng_out) || (d_pred_in && !d_pred_out))
         return HEAAC_ERR_ARG;
     if (n == 0)
         return HEAAC_OK;
     if (!d_coeffs || !d_tools)
         return HEAAC_ERR_ARG;
-    return heaac_launch_spectral_tools(channels, d_coeffs, d_tools, d_rng_in, d_rng_out, n, (hipStream_t)stream);
+    return heaac_launch_spectral_tools(channels, d_coeffs, d_tools, d_rng_in, d_rng_out, d_pred_in, d_pred_out, n,
+                                       (hipStream_t)stream);
 }
 
 extern "C" int heaac_he_decode_batch(HeaacDevice *dev, int cfg,

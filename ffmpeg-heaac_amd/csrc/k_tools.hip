@@ -104,6 +104,68 @@ __device__ __forceinline__ void tools_intensity(ToolsWave &w, int lane)
     }
 }
 
+// flt16_round / flt16_even / flt16_trunc, aacdec.c:1247-1269 (flt16_even's `& 0x00010000U >> 16`
+// parses as `& 1`: kept)
+__device__ __forceinline__ float flt16_round(float pf)
+{
+    return __uint_as_float((__float_as_uint(pf) + 0x00008000u) & 0xFFFF0000u);
+}
+__device__ __forceinline__ float flt16_even(float pf)
+{
+    const unsigned i = __float_as_uint(pf);
+    return __uint_as_float((i + 0x00007FFFu + (i & 1u)) & 0xFFFF0000u);
+}
+__device__ __forceinline__ float flt16_trunc(float pf)
+{
+    return __uint_as_float(__float_as_uint(pf) & 0xFFFF0000u);
+}
+
+// apply_prediction (aacdec.c:1302-1322) for one channel: the 672 predictors are independent, one
+// per lane and pass.  predict() (:1271-1297) is restated with its mixed precision: the two
+// variance updates add a float product to 0.5 * (double) -- the literal is a double there.
+__device__ __forceinline__ void tools_prediction(ToolsWave &w, int ch, const HeaacPredictorState *g_in,
+                                                 HeaacPredictorState *g_out, int lane)
+{
+    const HeaacToolsIcs &ics = w.t.ch[ch].ics;
+    const HeaacPrediction &pr = w.t.ch[ch].pred;
+    const bool eight = ics.num_windows == 8;
+    const int limit = eight ? 0 : ics.swb_offset[pr.pred_sfb_max];        // lines [0, limit) are predicted
+    const int group = pr.predictor_reset_group;
+    const float sf_scale = HEAAC_SF_SCALE;
+    const float a = 0.953125f, alpha = 0.90625f;
+    for (int k = lane; k < HEAAC_MAX_PREDICTORS; k += WAVE) {
+        HeaacPredictorState ps = g_in[k];
+        if (k < limit) {
+            // scalefactor band of line k (bands are at most 96 wide: walk from a coarse guess)
+            int sfb = 0;
+            while (ics.swb_offset[sfb + 1] <= k) sfb++;
+            const bool output_enable = pr.predictor_present && pr.prediction_used[sfb];
+            float coef = w.coef[ch][k];
+            const float k1 = ps.var0 > 1 ? ps.cor0 * flt16_even(a / ps.var0) : 0.0f;
+            const float k2 = ps.var1 > 1 ? ps.cor1 * flt16_even(a / ps.var1) : 0.0f;
+            const float pv = flt16_round(k1 * ps.r0 + k2 * ps.r1);
+            if (output_enable) coef += pv * sf_scale;
+            const float e0 = coef / sf_scale;
+            const float e1 = e0 - k1 * ps.r0;
+            const float c1 = flt16_trunc(alpha * ps.cor1 + ps.r1 * e1);
+            const float v1 = flt16_trunc((float)((double)(alpha * ps.var1) + 0.5 * (double)(ps.r1 * ps.r1 + e1 * e1)));
+            const float c0 = flt16_trunc(alpha * ps.cor0 + ps.r0 * e0);
+            const float v0 = flt16_trunc((float)((double)(alpha * ps.var0) + 0.5 * (double)(ps.r0 * ps.r0 + e0 * e0)));
+            const float r1 = flt16_trunc(a * (ps.r0 - k1 * e0));
+            const float r0 = flt16_trunc(a * e0);
+            ps.cor0 = c0; ps.cor1 = c1; ps.var0 = v0; ps.var1 = v1; ps.r0 = r0; ps.r1 = r1;
+            w.coef[ch][k] = coef;
+        }
+        // reset_predictor_group (:524-529) / reset_all_predictors for eight short windows
+        if (eight || (group && k % 30 == group - 1)) {
+            ps.cor0 = ps.cor1 = ps.r0 = ps.r1 = 0.0f;
+            ps.var0 = ps.var1 = 1.0f;
+        }
+        g_out[k] = ps;
+    }
+    wave_sync();
+}
+
 // one lane = window `win` of channel `ch`
 __device__ __forceinline__ void tools_tns_window(ToolsWave &w, int ch, int win, float *lpc)
 {
@@ -148,7 +210,8 @@ __device__ __forceinline__ void tools_tns_window(ToolsWave &w, int ch, int win, 
 template <int CH>
 __global__ __launch_bounds__(TL_WAVES * WAVE)
 void k_spectral_tools(float *g_coeffs, const HeaacToolsFrame *__restrict__ g_tools,
-                      const int *g_rng_in, int *g_rng_out, unsigned long long n)
+                      const int *g_rng_in, int *g_rng_out,
+                      const HeaacPredictorState *g_pred_in, HeaacPredictorState *g_pred_out, unsigned long long n)
 {
     __shared__ ToolsWave S[TL_WAVES];
     __shared__ LcgSkip K;
@@ -182,8 +245,20 @@ void k_spectral_tools(float *g_coeffs, const HeaacToolsFrame *__restrict__ g_too
             for (int c = 0; c < CH; c++) rs = tools_pns(w, K, c, rs, lane);
             if (lane == 0) g_rng_out[f] = (int)rs;
         }
+        const bool common = CH == 2 && w.t.common_window;
+        if (g_pred_in && !common) {             // decode_ics, aacdec.c:1381-1382
+#pragma unroll
+            for (int c = 0; c < CH; c++)
+                tools_prediction(w, c, g_pred_in + (f * CH + c) * HEAAC_MAX_PREDICTORS,
+                                 g_pred_out + (f * CH + c) * HEAAC_MAX_PREDICTORS, lane);
+        }
         if (CH == 2) {
             if (w.t.common_window && w.t.ms_present) { tools_mid_side(w, lane); wave_sync(); }
+            if (g_pred_in && common) {          // decode_cpe, aacdec.c:1486-1489
+                for (int c = 0; c < 2; c++)
+                    tools_prediction(w, c, g_pred_in + (f * 2 + c) * HEAAC_MAX_PREDICTORS,
+                                     g_pred_out + (f * 2 + c) * HEAAC_MAX_PREDICTORS, lane);
+            }
             tools_intensity(w, lane);
             wave_sync();
         }
@@ -205,17 +280,19 @@ void k_spectral_tools(float *g_coeffs, const HeaacToolsFrame *__restrict__ g_too
 }
 
 extern "C" int heaac_launch_spectral_tools(int channels, float *d_coeffs, const HeaacToolsFrame *d_tools,
-                                           const int *d_rng_in, int *d_rng_out, size_t n, hipStream_t s)
+                                           const int *d_rng_in, int *d_rng_out,
+                                           const HeaacPredictorState *d_pred_in, HeaacPredictorState *d_pred_out,
+                                           size_t n, hipStream_t s)
 {
     if (n == 0) return HEAAC_OK;
     unsigned long long g = (n + TL_WAVES - 1) / TL_WAVES;
     if (g > 256) g = 256;
     if (channels == 2)
         hipLaunchKernelGGL(k_spectral_tools<2>, dim3((unsigned)g), dim3(TL_WAVES * WAVE), 0, s, d_coeffs, d_tools,
-                           d_rng_in, d_rng_out, (unsigned long long)n);
+                           d_rng_in, d_rng_out, d_pred_in, d_pred_out, (unsigned long long)n);
     else if (channels == 1)
         hipLaunchKernelGGL(k_spectral_tools<1>, dim3((unsigned)g), dim3(TL_WAVES * WAVE), 0, s, d_coeffs, d_tools,
-                           d_rng_in, d_rng_out, (unsigned long long)n);
+                           d_rng_in, d_rng_out, d_pred_in, d_pred_out, (unsigned long long)n);
     else
         return HEAAC_ERR_ARG;
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;

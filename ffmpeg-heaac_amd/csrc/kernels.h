@@ -49,7 +49,9 @@ int heaac_launch_qmf_synthesis_ds(const float *d_tab, const float *d_X, const fl
 
 extern "C" {
 int heaac_launch_spectral_tools(int channels, float *d_coeffs, const HeaacToolsFrame *d_tools,
-                                const int *d_rng_in, int *d_rng_out, size_t n, hipStream_t s);
+                                const int *d_rng_in, int *d_rng_out,
+                                const HeaacPredictorState *d_pred_in, HeaacPredictorState *d_pred_out,
+                                size_t n, hipStream_t s);
 int heaac_launch_fft_calc(const float *d_tab, int nbits, float *d_z, size_t n, hipStream_t s);
 int heaac_launch_imdct_mirror(float *d_out, int n, size_t count, hipStream_t s);
 }

@@ -342,6 +342,11 @@ def tools_frames(rng, pkg, n, channels=2):
             ch["band_type"] = bt
             ch["band_type"][nb:] = 0
             ch["sf"] = np.exp2(rng.integers(-12, 8, 128) / 4.0).astype(np.float32)
+            pr = ch["pred"]
+            pr["pred_sfb_max"] = 40                       # ff_aac_pred_sfb_max[3] (48 kHz), aactab.c:47-49
+            pr["predictor_present"] = rng.random() < 0.7
+            pr["prediction_used"][:41] = rng.random(41) < 0.6
+            pr["predictor_reset_group"] = rng.integers(1, 31) if rng.random() < 0.15 else 0
             tns = ch["tns"]
             tns["present"] = rng.random() < 0.5
             nw = int(ch["ics"]["num_windows"])

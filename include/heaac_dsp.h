@@ -346,6 +346,19 @@ typedef struct HeaacTns {
     float   coef[8][4][HEAAC_TNS_MAX_ORDER];
 } HeaacTns;                           /* 2668 B */
 
+/* AAC-Main backward-adaptive prediction side info (aac.h:146-149) */
+typedef struct HeaacPrediction {
+    uint8_t predictor_present;
+    uint8_t predictor_reset_group;    /* 0: none, else 1..30 */
+    uint8_t pred_sfb_max;             /* ff_aac_pred_sfb_max[sampling_index] (aactab.c:47-49) */
+    uint8_t pad;
+    uint8_t prediction_used[44];      /* [41] in the reference */
+} HeaacPrediction;                    /* 48 B */
+
+/* PredictorState (aac.h:114-122): one per spectral line below the prediction limit */
+#define HEAAC_MAX_PREDICTORS 672
+typedef struct HeaacPredictorState { float cor0, cor1, var0, var1, r0, r1; } HeaacPredictorState;
+
 typedef struct HeaacToolsChannel {
     HeaacToolsIcs ics;
     uint8_t  band_type[128];          /* sce->band_type[idx], idx = g * max_sfb + sfb.  The runs the
@@ -353,7 +366,8 @@ typedef struct HeaacToolsChannel {
                                          run share one type, so testing every band is the same walk. */
     float    sf[128];                 /* sce->sf[idx] (first 120 used) */
     HeaacTns tns;
-} HeaacToolsChannel;                  /* 3452 B */
+    HeaacPrediction pred;
+} HeaacToolsChannel;                  /* 3500 B */
 
 typedef struct HeaacToolsFrame {
     uint8_t  common_window;           /* CPE only: both channels share ch[0].ics */
@@ -361,7 +375,7 @@ typedef struct HeaacToolsFrame {
     uint8_t  pad[2];
     uint8_t  ms_mask[128];            /* cpe->ms_mask[idx] */
     HeaacToolsChannel ch[2];
-} HeaacToolsFrame;                    /* 7036 B */
+} HeaacToolsFrame;                    /* 7132 B */
 
 /* In place on d_coeffs [n][channels][1024].  channels == 2: M/S (if common_window and
  * ms_present), intensity stereo, then TNS per channel -- the order of decode_cpe
@@ -373,10 +387,16 @@ typedef struct HeaacToolsFrame {
  * 0x1f2e3d4c, :567) in parse order -- channel 0 then channel 1, bands in (group, sfb) order, the
  * windows of a group, ascending k -- and scaled to sf[idx] / sqrtf(energy).  d_rng_in[n] is the
  * state before the frame, d_rng_out[n] the state after it (may alias).  With d_rng_in == NULL
- * noise bands are taken as given. */
+ * noise bands are taken as given.
+ * AAC-Main prediction (apply_prediction / predict, aacdec.c:1247-1322) runs when d_pred_in is not
+ * NULL: d_pred_in/out [n][channels][672] predictor states (may alias; a stream starts from
+ * reset_all_predictors: cor = r = 0, var = 1, aacdec.c:507-522).  Order as in the reference:
+ * after noise substitution for channels without common_window (decode_ics, :1381-1382), after
+ * M/S and before intensity stereo for a common-window pair (decode_cpe, :1483-1489). */
 int heaac_spectral_tools_batch(HeaacDevice *dev, int channels, float *d_coeffs,
                                const HeaacToolsFrame *d_tools,
                                const int32_t *d_rng_in, int32_t *d_rng_out,
+                               const HeaacPredictorState *d_pred_in, HeaacPredictorState *d_pred_out,
                                size_t n, void *stream);
 
 /* Host-side helper (no GPU): derive the frequency-band tables of one SBR

@@ -153,11 +153,85 @@ static int or_pns(const HeaacToolsChannel *ch, float *coef, int random_state)
     return random_state;
 }
 
+/* flt16_round / flt16_even / flt16_trunc, aacdec.c:1247-1269 (flt16_even's `& 0x00010000U >> 16`
+ * parses as `& 1`: kept) */
+static float flt16_round(float pf)
+{
+    union { float f; uint32_t i; } t; t.f = pf;
+    t.i = (t.i + 0x00008000U) & 0xFFFF0000U;
+    return t.f;
+}
+static float flt16_even(float pf)
+{
+    union { float f; uint32_t i; } t; t.f = pf;
+    t.i = (t.i + 0x00007FFFU + (t.i & 0x00010000U >> 16)) & 0xFFFF0000U;
+    return t.f;
+}
+static float flt16_trunc(float pf)
+{
+    union { float f; uint32_t i; } t; t.f = pf;
+    t.i &= 0xFFFF0000U;
+    return t.f;
+}
+
+/* predict, aacdec.c:1271-1297 (0.5 is a double literal there: the var updates are summed in double) */
+static void or_predict(HeaacPredictorState *ps, float *coef, int output_enable)
+{
+    const float sf_scale = HEAAC_SF_SCALE;
+    const float a     = 0.953125; // 61.0 / 64
+    const float alpha = 0.90625;  // 29.0 / 32
+    float e0, e1;
+    float pv;
+    float k1, k2;
+
+    k1 = ps->var0 > 1 ? ps->cor0 * flt16_even(a / ps->var0) : 0;
+    k2 = ps->var1 > 1 ? ps->cor1 * flt16_even(a / ps->var1) : 0;
+
+    pv = flt16_round(k1 * ps->r0 + k2 * ps->r1);
+    if (output_enable)
+        *coef += pv * sf_scale;
+
+    e0 = *coef / sf_scale;
+    e1 = e0 - k1 * ps->r0;
+
+    ps->cor1 = flt16_trunc(alpha * ps->cor1 + ps->r1 * e1);
+    ps->var1 = flt16_trunc(alpha * ps->var1 + 0.5 * (ps->r1 * ps->r1 + e1 * e1));
+    ps->cor0 = flt16_trunc(alpha * ps->cor0 + ps->r0 * e0);
+    ps->var0 = flt16_trunc(alpha * ps->var0 + 0.5 * (ps->r0 * ps->r0 + e0 * e0));
+
+    ps->r1 = flt16_trunc(a * (ps->r0 - k1 * e0));
+    ps->r0 = flt16_trunc(a * e0);
+}
+
+static void or_reset_predict_state(HeaacPredictorState *ps)
+{
+    ps->r0 = 0.0f; ps->r1 = 0.0f; ps->cor0 = 0.0f; ps->cor1 = 0.0f; ps->var0 = 1.0f; ps->var1 = 1.0f;
+}
+
+/* apply_prediction, aacdec.c:1302-1322 (predictor_initialized: the caller's initial state) */
+static void or_prediction(const HeaacToolsChannel *ch, float *coef, HeaacPredictorState *st)
+{
+    if (ch->ics.num_windows != 8) {
+        for (int sfb = 0; sfb < ch->pred.pred_sfb_max; sfb++)
+            for (int k = ch->ics.swb_offset[sfb]; k < ch->ics.swb_offset[sfb + 1]; k++)
+                or_predict(&st[k], &coef[k], ch->pred.predictor_present && ch->pred.prediction_used[sfb]);
+        if (ch->pred.predictor_reset_group)
+            for (int i = ch->pred.predictor_reset_group - 1; i < HEAAC_MAX_PREDICTORS; i += 30)
+                or_reset_predict_state(&st[i]);
+    } else {
+        for (int i = 0; i < HEAAC_MAX_PREDICTORS; i++)
+            or_reset_predict_state(&st[i]);
+    }
+}
+
 /* decode_cpe's tail (aacdec.c:1483-1492) + spectral_to_sample's TNS calls (:1913-1916);
  * rng_in != NULL: noise substitution first, channel 0 then channel 1 (decode_ics order) */
 void oracle_spectral_tools_batch(int channels, float *coeffs, const HeaacToolsFrame *tools,
-                                 const int32_t *rng_in, int32_t *rng_out, size_t n)
+                                 const int32_t *rng_in, int32_t *rng_out,
+                                 const HeaacPredictorState *pred_in, HeaacPredictorState *pred_out, size_t n)
 {
+    if (pred_in && pred_out != pred_in)
+        memcpy(pred_out, pred_in, n * (size_t)channels * HEAAC_MAX_PREDICTORS * sizeof(*pred_in));
     for (size_t f = 0; f < n; f++) {
         const HeaacToolsFrame *t = &tools[f];
         float *c0 = coeffs + f * (size_t)channels * 1024, *c1 = c0 + 1024;
@@ -167,9 +241,20 @@ void oracle_spectral_tools_batch(int channels, float *coeffs, const HeaacToolsFr
                 rs = or_pns(&t->ch[c], c ? c1 : c0, rs);
             rng_out[f] = rs;
         }
+        HeaacPredictorState *p0 = pred_in ? pred_out + f * (size_t)channels * HEAAC_MAX_PREDICTORS : NULL;
+        HeaacPredictorState *p1 = p0 ? p0 + HEAAC_MAX_PREDICTORS : NULL;
+        const int common = channels == 2 && t->common_window;
+        if (p0 && !common) {                       /* decode_ics, aacdec.c:1381-1382 */
+            or_prediction(&t->ch[0], c0, p0);
+            if (channels == 2) or_prediction(&t->ch[1], c1, p1);
+        }
         if (channels == 2) {
             if (t->common_window && t->ms_present)
                 or_mid_side(t, c0, c1);
+            if (p0 && common) {                    /* decode_cpe, aacdec.c:1486-1489 */
+                or_prediction(&t->ch[0], c0, p0);
+                or_prediction(&t->ch[1], c1, p1);
+            }
             or_intensity(t, c0, c1);
         }
         if (t->ch[0].tns.present)

@@ -90,10 +90,11 @@ int oracle_lc_decode_batch(int channels, const float *coeffs, const HeaacIcs *ic
                            const float *state_in, float *state_out,
                            void *pcm, int pcm_format, size_t n);
 
-/* (PNS if rng_in,) M/S, intensity stereo and TNS in place on coeffs [n][channels][1024]
+/* (PNS if rng_in, AAC-Main prediction if pred_in,) M/S, intensity stereo and TNS in place on coeffs [n][channels][1024]
  * (aacdec.c:1390-1451, 1698-1736; order of decode_cpe + spectral_to_sample). */
 void oracle_spectral_tools_batch(int channels, float *coeffs, const HeaacToolsFrame *tools,
-                                 const int32_t *rng_in, int32_t *rng_out, size_t n);
+                                 const int32_t *rng_in, int32_t *rng_out,
+                                 const HeaacPredictorState *pred_in, HeaacPredictorState *pred_out, size_t n);
 
 int oracle_he_decode_batch(int cfg, const float *coeffs, const HeaacIcs *ics,
                            const HeaacSbrFrame *sbr, const HeaacSbrHeader *hdr, size_t n_hdr,

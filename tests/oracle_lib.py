@@ -188,18 +188,20 @@ def lc_decode_batch(channels, coeffs, ics, state_in, pcm_format=PCM_F32):
     return pcm, state_out
 
 
-def spectral_tools_batch(channels, coeffs, tools, rng=None):
-    """(PNS if rng is given,) M/S + intensity + TNS on a copy of coeffs [n][channels][1024].
-    Returns coeffs, or (coeffs, rng_out)."""
+def spectral_tools_batch(channels, coeffs, tools, rng=None, pred=None):
+    """(PNS if rng, AAC-Main prediction if pred,) M/S + intensity + TNS on a copy of coeffs.
+    Returns coeffs, followed by rng_out and / or pred_out when those were given."""
     out = np.ascontiguousarray(coeffs, np.float32).copy()
     tools = np.ascontiguousarray(tools)
-    if rng is None:
-        lib().oracle_spectral_tools_batch(C.c_int(channels), _p(out), _p(tools), None, None, C.c_size_t(out.shape[0]))
-        return out
-    rin = np.ascontiguousarray(rng, np.int32)
-    rout = np.empty_like(rin)
-    lib().oracle_spectral_tools_batch(C.c_int(channels), _p(out), _p(tools), _p(rin), _p(rout), C.c_size_t(out.shape[0]))
-    return out, rout
+    rin = rout = pin = pout = None
+    if rng is not None:
+        rin = np.ascontiguousarray(rng, np.int32); rout = np.empty_like(rin)
+    if pred is not None:
+        pin = np.ascontiguousarray(pred, np.float32); pout = np.empty_like(pin)
+    lib().oracle_spectral_tools_batch(C.c_int(channels), _p(out), _p(tools), _p(rin), _p(rout), _p(pin), _p(pout),
+                                      C.c_size_t(out.shape[0]))
+    res = (out,) + ((rout,) if rng is not None else ()) + ((pout,) if pred is not None else ())
+    return res[0] if len(res) == 1 else res
 
 
 def he_decode_batch(cfg, coeffs, ics, sbr, hdr, ps, state_in, pcm_format=PCM_F32):

@@ -112,3 +112,33 @@ def test_noise_bands_carry_the_scalefactor_energy(pkg, oracle):
     # everything else untouched
     keep = np.ones((2, 1024), bool); keep[0, off[20]:off[21]] = False; keep[1, off[5]:off[6]] = False
     assert not out[0][keep].any()
+
+
+def test_main_prediction_tracks_a_stationary_line(pkg, oracle):
+    """A spectral line that repeats frame after frame becomes predictable: with output enabled and a
+    zero residual the reconstructed value approaches the line (backward-adaptive LMS)."""
+    t = _long_frame(pkg)
+    for c in range(2):
+        pr = t["ch"][0][c]["pred"]
+        pr["pred_sfb_max"] = 40; pr["predictor_present"] = 1; pr["prediction_used"][:41] = 1
+    pred = np.zeros((1, 2, pkg.MAX_PREDICTORS), pkg.PRED_STATE_DT)
+    pred["var0"] = 1.0; pred["var1"] = 1.0
+    pred = pred.view(np.float32).reshape(1, 2, pkg.MAX_PREDICTORS, 6)
+    sf = 1.0 / (1024.0 * 32768.0)
+    line = np.zeros((1, 2, 1024), np.float32); line[0, :, 10] = 2000 * sf
+    # phase 1: the encoder sends the full line (prediction off) for a while -> predictors adapt
+    t["ch"][0][0]["pred"]["predictor_present"] = 0; t["ch"][0][1]["pred"]["predictor_present"] = 0
+    for _ in range(30):
+        out, pred = oracle.spectral_tools_batch(2, line, t, None, pred)
+        assert np.array_equal(out, line)                         # output_enable = 0: spectrum untouched
+    assert pred[0, 0, 10, 2] > 1 and pred[0, 0, 11, 2] < 1       # var0 grows where energy is, decays elsewhere
+    # phase 2: residual zero, prediction on -> the decoder output is the prediction itself
+    t["ch"][0][0]["pred"]["predictor_present"] = 1
+    out, pred2 = oracle.spectral_tools_batch(2, np.zeros_like(line), t, None, pred)
+    assert abs(out[0, 0, 10] / line[0, 0, 10] - 1) < 0.2         # within 20 % of the stationary line
+    assert out[0, 1, 10] == 0                                    # channel 1 still has prediction off
+    # reset group 11 (lines 10, 40, 70 ...) returns those predictors to the initial state
+    t["ch"][0][0]["pred"]["predictor_reset_group"] = 11
+    _, pred3 = oracle.spectral_tools_batch(2, line, t, None, pred)
+    assert tuple(pred3[0, 0, 10]) == (0, 0, 1, 1, 0, 0) and tuple(pred3[0, 0, 40]) == (0, 0, 1, 1, 0, 0)
+    assert pred3[0, 0, 9, 2] < 1                                 # neighbours keep adapting

@@ -50,6 +50,33 @@ def test_spectral_tools_with_noise_substitution(pkg, oracle, dev, channels):
         assert np.array_equal(d_state.cpu().numpy(), state), "step %d" % step
 
 
+@pytest.mark.parametrize("channels", [1, 2])
+def test_spectral_tools_with_main_prediction(pkg, oracle, dev, channels):
+    """AAC-Main backward-adaptive prediction (with PNS ahead of it), predictor state chained
+    over five frames from reset_all_predictors."""
+    import torch
+    n = 60
+    rng = np.random.default_rng(60 + channels)
+    rs = np.full(n, 0x1f2e3d4c, np.int32)
+    pred = np.zeros((n, channels, pkg.MAX_PREDICTORS), pkg.PRED_STATE_DT)
+    pred["var0"] = 1.0; pred["var1"] = 1.0
+    pred = pred.view(np.float32).reshape(n, channels, pkg.MAX_PREDICTORS, 6)
+    d_rs = torch.from_numpy(rs.copy()).cuda()
+    d_pred = torch.from_numpy(pred.copy()).cuda()
+    active = False
+    for step in range(5):
+        tools = _synth().tools_frames(rng, pkg, n, channels)
+        coeffs = (rng.standard_normal((n, channels, 1024)) * 1e-4).astype(np.float32)
+        ref, rs, pred = oracle.spectral_tools_batch(channels, coeffs, tools, rs, pred)
+        d = torch.from_numpy(coeffs).cuda()
+        dev.spectral_tools(channels, d, pkg.to_device(tools), rng=d_rs, pred=d_pred)
+        assert np.array_equal(_bits(d.cpu().numpy()), _bits(ref)), "step %d" % step
+        assert np.array_equal(d_rs.cpu().numpy(), rs), "step %d" % step
+        assert np.array_equal(_bits(d_pred.cpu().numpy()), _bits(pred)), "step %d" % step
+        active = active or bool((pred[..., 2] > 1).any())          # var0 > 1: predictors have adapted
+    assert active
+
+
 def test_spectral_tools_then_lc_decode(pkg, oracle, dev):
     """tools -> imdct_and_windowing: the prefix of spectral_to_sample (aacdec.c:1903-1925)."""
     import torch
@@ -74,4 +101,5 @@ def test_spectral_tools_empty_and_bad_args(pkg, dev):
     z = torch.zeros((0, 2, 1024), device="cuda")
     dev.spectral_tools(2, z, torch.zeros(0, dtype=torch.uint8, device="cuda"))
     with pytest.raises(pkg.HeaacError):
-        pkg._check(pkg.lib().heaac_spectral_tools_batch(dev._h, 3, None, None, None, None, 1, None), "bad channels")
+        pkg._check(pkg.lib().heaac_spectral_tools_batch(dev._h, 3, None, None, None, None, None, None, 1, None),
+                   "bad channels")
