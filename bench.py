@@ -29,10 +29,14 @@ WORKLOADS = {
     "lc_stereo": ("CFG_LC_STEREO", 64 * 1024, "AAC-LC stereo 48 kHz, 64 k-frame batch"),
     "hev1": ("CFG_HEV1", 64 * 1024, "HE-AACv1 stereo 48 kHz, 64 k-frame batch"),
     "hev2": ("CFG_HEV2", 256 * 1024, "HE-AACv2 stereo 48 kHz, 256 k-frame batch"),
+    # secondary run of SURVEY s8d: 34-band PS with IPD/OPD (the general PS kernel finishes every frame)
+    "hev2_34": ("CFG_HEV2", 64 * 1024, "HE-AACv2 stereo 48 kHz, 34-band PS + IPD/OPD, 64 k-frame batch"),
 }
+PS_MODE = {"hev2_34": "34"}
+ALGO_BYTES_OVERRIDE = {"hev2_34": 95788}       # PS state 17 996 B instead of 12 744 B
 
 
-def make_inputs(pkg, synth, torch, cfg, n, seed, pool=4096):
+def make_inputs(pkg, synth, torch, cfg, n, seed, pool=4096, ps_mode="20"):
     """Synthetic per-frame inputs on the GPU.  Parameters for `pool` independent
     streams are generated on the host for 3 consecutive frames (2 warm-up frames
     build a realistic state, the third is the timed one) and tiled to n frames;
@@ -49,7 +53,7 @@ def make_inputs(pkg, synth, torch, cfg, n, seed, pool=4096):
         hdr = None
     else:
         hdr = synth.default_headers(pkg)
-        for fr in synth.he_stream(rng, cfg, pool, 3, hdr):
+        for fr in synth.he_stream(rng, cfg, pool, 3, hdr, ps_mode=ps_mode):
             d = dict(ics=pkg.to_device(fr["ics"]).repeat(reps)[: n * pkg.CORE_CH[cfg] * 4].contiguous(),
                      sbr=pkg.to_device(fr["sbr"]).repeat(reps)[: n * 680].contiguous(),
                      ps=None)
@@ -156,7 +160,8 @@ def main():
     torch.cuda.set_device(local)
 
     dev = pkg.Device(n)
-    steps_in, coeffs, hdr = make_inputs(pkg, synth, torch, cfg, n, seed=1234 + rank)
+    steps_in, coeffs, hdr = make_inputs(pkg, synth, torch, cfg, n, seed=1234 + rank,
+                                        ps_mode=PS_MODE.get(workload, "20"))
     fmt = pkg.PCM_F32 if args.pcm == "f32" else pkg.PCM_S16
     words = pkg.STATE_WORDS[cfg]
     # state is updated in place (st_in == st_out), as a decoder does frame after frame
@@ -212,7 +217,7 @@ def main():
     if rank == 0:
         total_frames = n * world * args.steps
         value = total_frames / elapsed
-        bytes_per_frame = pkg.ALGO_BYTES[cfg]
+        bytes_per_frame = ALGO_BYTES_OVERRIDE.get(workload, pkg.ALGO_BYTES[cfg])
         if fmt == pkg.PCM_S16:      # int16 PCM out instead of f32: 2 bytes/sample less
             bytes_per_frame -= pkg.OUT_CH[cfg] * pkg.OUT_LEN[cfg] * 2
         achieved = bytes_per_frame * n / (kern_ms * 1e-3) / 1e9
