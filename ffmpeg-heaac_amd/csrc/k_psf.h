@@ -177,16 +177,19 @@ __device__ __forceinline__ float remap_val(const float *par, int to34, int b)
 // in: 13 consecutive complex slots, filt: [7][2]
 __device__ __forceinline__ void hybrid_fir(const float *in, const float *filt, float &o_re, float &o_im)
 {
-    float sum_re = filt[12] * in[12], sum_im = filt[12] * in[13];
+    // (re, im) pairs: sum += f0 * (in0 + in1) + (-f1, f1) * swap(in0 - in1), the reference's terms
+    // two per packed instruction
+    const v2f *x = reinterpret_cast<const v2f *>(in);
+    v2f sum = bc(filt[12]) * x[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-        const float in0_re = in[2 * j], in0_im = in[2 * j + 1];
-        const float in1_re = in[2 * (12 - j)], in1_im = in[2 * (12 - j) + 1];
-        sum_re += filt[2 * j] * (in0_re + in1_re) - filt[2 * j + 1] * (in0_im - in1_im);
-        sum_im += filt[2 * j] * (in0_im + in1_im) + filt[2 * j + 1] * (in0_re - in1_re);
+        const v2f in0 = x[j], in1 = x[12 - j];
+        const v2f sm = in0 + in1, df = in0 - in1;
+        const float f0 = filt[2 * j], f1 = filt[2 * j + 1];
+        sum = sum + (bc(f0) * sm + v2f{-f1, f1} * __builtin_shufflevector(df, df, 1, 0));
     }
-    o_re = sum_re;
-    o_im = sum_im;
+    o_re = sum.x;
+    o_im = sum.y;
 }
 
 // One band, all 32 slots: decorrelation (aacps.c:696-753) fused with the mixing
