@@ -1,17 +1,15 @@
-// k_he.hip -- HE-AAC (SBR + Parametric Stereo) batched kernels for gfx950.
+// k_he.hip -- HE-AAC (SBR) batched kernels for gfx950 and the HE pipeline driver.
 //
-//   k_core_ana  : imdct_and_windowing (bias 0) + sbr_qmf_analysis      (a8, a11)
-//   k_hfadj     : lf_gen, inverse filter, chirp, hf_gen, mapping,
-//                 env_estimate, gain_calc, hf_assemble, x_gen          (a10, a12-a19)
-//   k_ps        : hybrid analysis, decorrelation, stereo_processing,
-//                 hybrid synthesis                                     (a22-a26)
-//   k_synth     : sbr_qmf_synthesis + float_to_int16_interleave        (a20, a27)
+//   k_core_ana  : imdct_and_windowing (bias 0) + sbr_qmf_analysis, two channels per wave   (a8, a11)
+//   k_hfadj     : lf_gen, inverse filter, chirp, hf_gen, mapping, env_estimate, gain_calc,
+//                 hf_assemble, x_gen (k_hf.h) for HE-AACv1; for HE-AACv2 the same stage runs
+//                 fused with Parametric Stereo in k_hfps (k_ps.hip)                        (a10, a12-a19)
+//   k_synth     : sbr_qmf_synthesis + float_to_int16_interleave                            (a20, a27)
+//   k_qmf_analysis / k_qmf_synthesis / k_qmf_synthesis_ds : the stage-level batched filterbanks
 //
-// One wavefront owns one unit (an SBR channel, a PS frame, an output channel);
-// workgroups are persistent and keep the immutable tables in LDS.  Stages hand
-// W[32][32][2] and X[2][38][64] to each other through a workspace that the
-// host sizes to stay inside the 256 MiB Infinity Cache (frames are processed in
-// chunks), so the intermediates do not travel to HBM.
+// One wavefront owns one unit (an SBR channel or a pair, an output frame); workgroups are
+// persistent and keep the immutable tables in LDS.  Stages hand W[32][32][2] and X[2][2][38][64]
+// to each other through a workspace, one chunk of frames at a time (capi.hip).
 //
 // Reference line numbers are libavcodec/aacsbr.c and aacps.c.
 #include <stdlib.h>

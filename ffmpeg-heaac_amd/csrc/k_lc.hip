@@ -4,10 +4,11 @@
 // imdct_and_windowing() per channel with bias 385, then (optionally)
 // float_to_int16_interleave (dsputil.c:3989-4001).
 //
-// Persistent workgroups of 4 wavefronts; each wavefront owns one frame at a
-// time (all its channels), tables live in LDS for the life of the workgroup.
-// HBM traffic per frame is exactly the algorithmic minimum: coefficients and
-// overlap read once with 16-byte loads, PCM and overlap written once.
+// Persistent workgroups of 12 wavefronts; each wavefront owns two channels at a time (one per
+// half-wave, FFT in registers: k_core2.h), tables live in LDS for the life of the workgroup.
+// HBM traffic per frame is the algorithmic minimum: coefficients and overlap read once, PCM and
+// overlap written once.  The LDS-FFT kernels further down serve the stage-level
+// heaac_imdct_half_batch and the FFTContext shim.
 #include "k_core.h"
 #include "k_core2.h"
 #include "kernels.h"

@@ -1,13 +1,15 @@
-// k_ps.hip -- Parametric Stereo for gfx950: ff_ps_apply() (aacps.c:973-992) =
-// hybrid_analysis (:359-395), decorrelation (:645-754), stereo_processing
-// (:794-971), hybrid_synthesis (:397-445), one wavefront per frame.
+// k_ps.hip -- Parametric Stereo kernels for gfx950: ff_ps_apply() (aacps.c:973-992) =
+// hybrid_analysis (:359-395), decorrelation (:645-754), stereo_processing (:794-971),
+// hybrid_synthesis (:397-445), one wavefront per frame (device code: k_psf.h).
 //
-// Lane = frequency band.  Every recursion of the reference (transient smoother,
-// all-pass chain, H-matrix interpolation) runs over time inside one lane, so
-// the reference's operation order is kept and parallelism comes from the
-// 71/91 hybrid bands.  Two passes: pass A handles the bands that are plain QMF
-// bands (read and written as coalesced rows of X), pass B the hybrid
-// sub-subbands of the lowest 3/5 QMF bands (kept in LDS).
+//   k_hfps         HF adjustment (k_hf.h) fused with baseline PS: the HE-AACv2 hot path
+//   k_ps<false,8>  baseline PS alone (20 bands, no IPD/OPD) -- the unfused A/B path
+//   k_ps<true,4>   every other layout: 34 bands, IPD/OPD, 20 <-> 34 switches, PS off
+//
+// Lane = frequency band.  Every recursion of the reference (transient smoother, all-pass chain,
+// H-matrix interpolation) runs over time inside one lane, so the reference's operation order is
+// kept and parallelism comes from the 71 / 91 hybrid bands.  Plain QMF bands are columns held in
+// registers; the hybrid sub-subbands of the lowest 3 / 5 QMF bands are kept in LDS.
 #include "k_common.h"
 #include "kernels.h"
 
