@@ -178,9 +178,14 @@ void k_core_ana(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_
             const int k = lane;
             const float w0 = s_qmf_ds[k], w1 = s_qmf_ds[k + 64], w2 = s_qmf_ds[k + 128],
                         w3 = s_qmf_ds[k + 192], w4 = s_qmf_ds[k + 256];
-            for (int i = 0; i < 32; i++) {
-                const float *xs = x + 32 * i + 319 - k;
-                uu[i * 65 + k] = w0 * xs[0] + w1 * xs[-64] + w2 * xs[-128] + w3 * xs[-192] + w4 * xs[-256];
+            // two slots per packed multiply / add
+            for (int i = 0; i < 32; i += 2) {
+                const float *xa = x + 32 * i + 319 - k, *xb = xa + 32;
+                const v2f f = bc(w0) * v2f{xa[0], xb[0]} + bc(w1) * v2f{xa[-64], xb[-64]} +
+                              bc(w2) * v2f{xa[-128], xb[-128]} + bc(w3) * v2f{xa[-192], xb[-192]} +
+                              bc(w4) * v2f{xa[-256], xb[-256]};
+                uu[i * 65 + k] = f.x;
+                uu[(i + 1) * 65 + k] = f.y;
             }
         }
         wave_sync();
