@@ -65,3 +65,36 @@ def test_two_rank_shard_and_gather(tmp_path):
     for p in procs:
         assert p.wait(timeout=300) == 0
     assert np.load(out)[0] == 1
+
+
+def _bench(*extra, env=None):
+    e = dict(os.environ, OMP_NUM_THREADS="1")
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None); e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *extra], env=e,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher on the command line (the driver's shape):
+    bench.py starts the ranks itself; rank 0's single JSON line comes back on stdout.
+    --dry-run replaces the GPU work by a sleep, everything around it is the real code."""
+    import json
+    p = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--frames", "1000",
+               "--backend", "gloo", "--gather")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["dry_run"]
+    assert abs(out["per_gpu_value"] * 2 - out["value"]) < 1e-6 * out["value"]
+    assert out["config"]["frames_per_gpu"] == 1000 and "pcm_gather_ms" in out
+    assert {"achieved", "peak", "frac", "gflops"} <= set(out["roofline"])
+
+
+def test_bench_rank_failure_is_not_swallowed():
+    """A rank that dies makes the launcher exit non-zero and print no JSON line."""
+    p = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--frames", "64", "--backend", "gloo")
+    # no --dry-run: without a GPU every rank fails loudly in Device()
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
