@@ -83,6 +83,30 @@ __device__ __forceinline__ int opaque(int v)
     return v;
 }
 
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// ---------------------------------------------------------------------------
+// L2 prefetch of a record the wave will read a frame later: every lane loads one dword of a
+// different 128-byte line (sc1: past the CU's vector L1, allocated in the XCD's L2), the data is
+// thrown away.  `sink` is the one VGPR all these loads write; it must stay live (loop-carried) until
+// the l2_touch_drain() after the unit loop, so that a load returning late never lands in a register
+// the compiler has given to something else.  The compiler's own vmcnt bookkeeping stays correct:
+// these loads are older than anything it waits for afterwards (vmcnt retires in order).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void l2_touch(const void *base, unsigned bytes, int lane, unsigned &sink)
+{
+    for (unsigned o = 0; o < bytes; o += WAVE * 128) {
+        unsigned off = o + (unsigned)lane * 128;
+        off = off < bytes ? off : bytes - 4;                 // surplus lanes re-touch the last line
+        const char *p = reinterpret_cast<const char *>(base) + off;
+        asm volatile("global_load_dword %0, %1, off sc1" : "+v"(sink) : "v"(p) : "memory");
+    }
+}
+__device__ __forceinline__ void l2_touch_drain(unsigned &sink)
+{
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) :: "memory");
+}
+
 // ---------------------------------------------------------------------------
 // Split-radix schedule.  The reference FFT (libavcodec/fft.c:283-351) is the
 // recursion  fft(n, o) = fft(n/2, o); fft(n/4, o+n/2); fft(n/4, o+3n/4);

@@ -13,6 +13,7 @@
 //
 // Reference line numbers are libavcodec/aacsbr.c and aacps.c.
 #include <stdlib.h>
+#include <type_traits>
 #include "k_core.h"
 #include "k_core2.h"
 #include "kernels.h"
@@ -264,7 +265,7 @@ void k_hfadj(const float *__restrict__ g_tab,
 
 #define SYN_WAVES_F32 7           // k_synth: the left int16 channel waits in registers, so 7 waves fit
 struct SynWave {
-    float vb[VB_ROWS * VB_STRIDE];
+    __attribute__((aligned(16))) float vb[VB_ROWS * VB_STRIDE + 3];
 };
 template <int NW>
 struct SynLdsT {
@@ -275,82 +276,155 @@ struct SynLdsT {
 };
 typedef SynLdsT<SYN_WAVES> SynLds;
 
+#ifdef HF_STAMPS
+#define SSTAMP(i) TL_STAMP(i, (i) == 0)
+#else
+#define SSTAMP(i) do {} while (0)
+#endif
+
 // swap with the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2]
 __device__ __forceinline__ float lane_xor1(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
 }
 
-// sbr_qmf_synthesis (aacsbr.c:1175-1230), div = 0, for one channel.
-//   X0/X1 : re / im planes [38][64] (slots 0..31 used)
-//   v_in/v_out : 1152-float ring state, newest slot first
-//   emit(i, n, value) receives out[64 i + n]
-// UNROLL: unroll count of the polyphase loop (16 = fully: emit() then sees compile-time slots)
+// sbr_qmf_synthesis (aacsbr.c:1175-1230), div = 0, for one channel, in four pieces so that a kernel
+// can have the NEXT channel's loads in flight while the current one runs its polyphase sum:
+//   syn_load     X rows (lane = (slot, re/im plane): 64 floats) and the ring state (18 floats / lane)
+//   syn_rows     ring state -> v rows 32..40; 64 IMDCTs (N = 128), butterfly -> v rows 0..31
+//   syn_poly     10-tap polyphase sum, lane = output column; emit(i, n, value) receives out[64 i + n]
+//   syn_hist_out new ring state = v rows 0..8
+struct SynIn {
+    float x[64];                  // X[part][slot][0..63] of this lane's (slot, part)
+    float h[18];                  // v_in[lane + 64 r]
+};
+
+// The X rows are loaded coalesced -- every instruction takes 1 KiB of consecutive memory (four rows),
+// each 128-byte line is fetched once -- and reach the lane that runs the row's IMDCT through a staging
+// image in the wave's v-row memory (free between two channels): syn_rows starts with that transpose.
+// (A lane reading its own 256-byte row in 16-byte pieces pulls every line through the vector L1 eight
+// times; with 7 waves per CU the L1 keeps none of them.)
+#define SYN_STAGE_STRIDE 68       // floats per staged row: 64 + 4 (b128 reads of 64 different rows spread over all banks)
+__device__ __forceinline__ void syn_load(const float *X0, const float *X1, const float *v_in, int lane, SynIn &d)
+{
+    const float4 *p0 = reinterpret_cast<const float4 *>(X0), *p1 = reinterpret_cast<const float4 *>(X1);
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const float4 t = q < 8 ? p0[q * 64 + lane] : p1[(q - 8) * 64 + lane];
+        d.x[4 * q] = t.x; d.x[4 * q + 1] = t.y; d.x[4 * q + 2] = t.z; d.x[4 * q + 3] = t.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 18; r++) d.h[r] = v_in[lane + 64 * r];
+}
+
+template <class SL>
+__device__ __forceinline__ void syn_rows(const SL &S, SynWave &w, const SynIn &d, int lane)
+{
+    // staged image: row (plane, slot) at (plane * 32 + slot) * SYN_STAGE_STRIDE; piece q of the loads holds
+    // floats 4 (lane & 15) .. of row 4 (q & 7) + (lane >> 4) of plane q >> 3
+    float x[64];
+    {
+        float4 *st = reinterpret_cast<float4 *>(w.vb);
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int row = (q >> 3) * 32 + 4 * (q & 7) + (lane >> 4);
+            st[(row * SYN_STAGE_STRIDE >> 2) + (lane & 15)] = make_float4(d.x[4 * q], d.x[4 * q + 1], d.x[4 * q + 2], d.x[4 * q + 3]);
+        }
+        wave_sync();
+        const int mine = (lane & 1) * 32 + (lane >> 1);
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const float4 t = st[(mine * SYN_STAGE_STRIDE >> 2) + q];
+            x[4 * q] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+        }
+        wave_sync();
+    }
+    SSTAMP(1);
+    // history: 9 slots behind the 32 new ones
+#pragma unroll
+    for (int r = 0; r < 18; r++)
+        w.vb[(32 + (r >> 1)) * VB_STRIDE + (r & 1) * 64 + lane] = d.h[r];
+    // 64 IMDCTs (N = 128): lane = (slot, re/im plane).  X[1][i][n] = -X[1][i][n] for odd n (:1201-1203):
+    // the odd lanes flip the sign bit of their odd inputs, so that all lanes run ONE instruction stream.
+    const int i = lane >> 1, part = lane & 1;
+    const unsigned flip = (unsigned)part << 31;
+    float o[64];
+    imdct128_reg([&](int j) -> float {
+                     return (j & 1) ? __uint_as_float(__float_as_uint(x[j]) ^ flip) : x[j];
+                 }, o, S.rot, S.c16, S.c32);
+    SSTAMP(2);
+    // v[n] = -buf0[63-n] + buf1[n];  v[127-n] = buf0[63-n] + buf1[n]   (:1206-1209)
+    // The even lane holds buf0 and forms v[n], the odd lane holds buf1 and forms v[64 + n] =
+    // buf0[n] + buf1[63 - n]: at step n both send o[n] to the partner and add their own o[63 - n]
+    // (negated in the even lane), and both store at column n of their half of the row.
+    float *vs = w.vb + (31 - i) * VB_STRIDE + 64 * part;
+    const unsigned neg = (unsigned)(part ^ 1) << 31;
+#pragma unroll
+    for (int n = 0; n < 64; n++) {
+        const float mine = __uint_as_float(__float_as_uint(o[63 - n]) ^ neg);
+        vs[n] = lane_xor1(o[n]) + mine;
+    }
+}
+
+template <int UNROLL = 1, class SL, class Emit>
+__device__ __forceinline__ void syn_poly(const SL &S, const SynWave &w, float scale, float bias, int lane, Emit emit)
+{
+    SSTAMP(3);
+    // 10-tap polyphase sum (:1210-1219), lane = n
+    const int n = lane;
+    float wt[10];
+#pragma unroll
+    for (int j = 0; j < 10; j++) wt[j] = S.win[64 * j + n];
+    const bool scale_and_bias = scale != 1.0f || bias != 0.0f;
+    // two slots per packed multiply / add: (slot i, slot i + 1) share the window taps
+#pragma unroll UNROLL
+    for (int i = 0; i < 32; i += 2) {
+        const float *va = w.vb + (31 - i) * VB_STRIDE + n, *vb = va - VB_STRIDE;
+        v2f acc = v2f{va[0], vb[0]} * bc(wt[0]) + v2f{0.0f, 0.0f};
+        acc = v2f{va[1 * VB_STRIDE + 64], vb[1 * VB_STRIDE + 64]} * bc(wt[1]) + acc;
+        acc = v2f{va[2 * VB_STRIDE],      vb[2 * VB_STRIDE]}      * bc(wt[2]) + acc;
+        acc = v2f{va[3 * VB_STRIDE + 64], vb[3 * VB_STRIDE + 64]} * bc(wt[3]) + acc;
+        acc = v2f{va[4 * VB_STRIDE],      vb[4 * VB_STRIDE]}      * bc(wt[4]) + acc;
+        acc = v2f{va[5 * VB_STRIDE + 64], vb[5 * VB_STRIDE + 64]} * bc(wt[5]) + acc;
+        acc = v2f{va[6 * VB_STRIDE],      vb[6 * VB_STRIDE]}      * bc(wt[6]) + acc;
+        acc = v2f{va[7 * VB_STRIDE + 64], vb[7 * VB_STRIDE + 64]} * bc(wt[7]) + acc;
+        acc = v2f{va[8 * VB_STRIDE],      vb[8 * VB_STRIDE]}      * bc(wt[8]) + acc;
+        acc = v2f{va[9 * VB_STRIDE + 64], vb[9 * VB_STRIDE + 64]} * bc(wt[9]) + acc;
+        if (scale_and_bias) acc = acc * bc(scale) + bc(bias);
+        emit(i, n, acc.x);
+        emit(i + 1, n, acc.y);
+    }
+    SSTAMP(4);
+}
+
+__device__ __forceinline__ void syn_hist_out(const SynWave &w, float *v_out, int lane)
+{
+    // new ring state: slots 31..23
+#pragma unroll
+    for (int r = 0; r < 18; r++)
+        v_out[lane + 64 * r] = w.vb[(r >> 1) * VB_STRIDE + (r & 1) * 64 + lane];
+}
+
+// The four pieces in sequence (stage-level kernel).
 template <int UNROLL = 1, class SL, class Emit>
 __device__ __forceinline__ void synth_channel(const SL &S, SynWave &w, const float *X0, const float *X1,
                                               const float *v_in, float *v_out,
                                               float scale, float bias, int lane, Emit emit)
 {
-    // history: 9 slots behind the 32 new ones
-    for (int t = lane; t < 1152; t += WAVE)
-        w.vb[(32 + (t >> 7)) * VB_STRIDE + (t & 127)] = v_in[t];
-    // 64 IMDCTs (N = 128): lane = (slot, re/im plane)
-    {
-        const int i = lane >> 1, part = lane & 1;
-        const float *row = (part ? X1 : X0) + i * 64;
-        float o[64];
-        if (part) {
-            // X[1][i][n] = -X[1][i][n] for odd n (:1201-1203)
-            imdct128_reg([&](int j) -> float { return (j & 1) ? -row[j] : row[j]; }, o, S.rot, S.c16, S.c32);
-        } else {
-            imdct128_reg([&](int j) -> float { return row[j]; }, o, S.rot, S.c16, S.c32);
-        }
-        // v[n] = -buf0[63-n] + buf1[n];  v[127-n] = buf0[63-n] + buf1[n]   (:1206-1209)
-        // even lane holds buf0 and produces v[0..63], odd lane holds buf1 and
-        // produces v[64..127].
-        float *vs = w.vb + (31 - i) * VB_STRIDE;
-#pragma unroll
-        for (int n = 0; n < 64; n++) {
-            // both lanes exchange the element the partner needs for index n
-            const float mine = part ? o[n] : o[63 - n];        // buf1[n] | buf0[63-n]
-            const float other = lane_xor1(mine);               // buf0[63-n] | buf1[n]
-            if (part) vs[127 - n] = other + mine;              //  buf0[63-n] + buf1[n]
-            else      vs[n] = -mine + other;                   // -buf0[63-n] + buf1[n]
-        }
-    }
+    SSTAMP(0);
+    SynIn d;
+    syn_load(X0, X1, v_in, lane, d);
+    syn_rows(S, w, d, lane);
     wave_sync();
-    // 10-tap polyphase sum (:1210-1219), lane = n
-    {
-        const int n = lane;
-        float wt[10];
-#pragma unroll
-        for (int j = 0; j < 10; j++) wt[j] = S.win[64 * j + n];
-        const bool scale_and_bias = scale != 1.0f || bias != 0.0f;
-        // two slots per packed multiply / add: (slot i, slot i + 1) share the window taps
-#pragma unroll UNROLL
-        for (int i = 0; i < 32; i += 2) {
-            const float *va = w.vb + (31 - i) * VB_STRIDE + n, *vb = va - VB_STRIDE;
-            v2f acc = v2f{va[0], vb[0]} * bc(wt[0]) + v2f{0.0f, 0.0f};
-            acc = v2f{va[1 * VB_STRIDE + 64], vb[1 * VB_STRIDE + 64]} * bc(wt[1]) + acc;
-            acc = v2f{va[2 * VB_STRIDE],      vb[2 * VB_STRIDE]}      * bc(wt[2]) + acc;
-            acc = v2f{va[3 * VB_STRIDE + 64], vb[3 * VB_STRIDE + 64]} * bc(wt[3]) + acc;
-            acc = v2f{va[4 * VB_STRIDE],      vb[4 * VB_STRIDE]}      * bc(wt[4]) + acc;
-            acc = v2f{va[5 * VB_STRIDE + 64], vb[5 * VB_STRIDE + 64]} * bc(wt[5]) + acc;
-            acc = v2f{va[6 * VB_STRIDE],      vb[6 * VB_STRIDE]}      * bc(wt[6]) + acc;
-            acc = v2f{va[7 * VB_STRIDE + 64], vb[7 * VB_STRIDE + 64]} * bc(wt[7]) + acc;
-            acc = v2f{va[8 * VB_STRIDE],      vb[8 * VB_STRIDE]}      * bc(wt[8]) + acc;
-            acc = v2f{va[9 * VB_STRIDE + 64], vb[9 * VB_STRIDE + 64]} * bc(wt[9]) + acc;
-            if (scale_and_bias) acc = acc * bc(scale) + bc(bias);
-            emit(i, n, acc.x);
-            emit(i + 1, n, acc.y);
-        }
-    }
-    // new ring state: slots 31..23
-    for (int t = lane; t < 1152; t += WAVE)
-        v_out[t] = w.vb[(t >> 7) * VB_STRIDE + (t & 127)];
+    syn_poly<UNROLL>(S, w, scale, bias, lane, emit);
+    syn_hist_out(w, v_out, lane);
     wave_sync();
+    SSTAMP(5);
 }
 
+// k_synth: one wave per frame.  While a channel runs its polyphase sum, the X rows and ring state of
+// the next unit -- the frame's other channel, or the first channel of the wave's next frame (the queue
+// hands indices out one frame ahead) -- are already on their way into registers.
 template <int FMT>
 __global__ __launch_bounds__(SYN_WAVES_F32 * WAVE)
 void k_synth(const float *__restrict__ g_tab, const float *g_X,
@@ -368,46 +442,67 @@ void k_synth(const float *__restrict__ g_tab, const float *g_X,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
     SynWave &w = S.w[wave];
     uint32_t lpcm[16];          // left channel of an interleaved int16 pair: lane n, slots 2j | 2j + 1 << 16
-    // frames are drawn from a queue (first one: the wave's own index; the next index is fetched
-    // while the current frame is processed), which evens out the waves' finishing times
+    auto load_unit = [&](unsigned long long f, int ch, SynIn &d) {
+        const float *X0 = g_X + (f * 2 + ch) * (2 * 38 * 64);
+        syn_load(X0, X0 + 38 * 64, g_state_in + f * state_words + off_syn0 + ch * HEAAC_ST_SYNTH, lane, d);
+    };
+    // two tickets: the frame in work and the next one (first one: the wave's own index)
     unsigned long long f = (unsigned long long)blockIdx.x * NW + wave;
+    unsigned tk = 0;
+    if (lane == 0) tk = atomicAdd(g_queue, 1u) + gridDim.x * NW;
+    unsigned long long f1 = (unsigned long long)__builtin_amdgcn_readfirstlane(tk);
+    SynIn cur;
+    if (f < n_frames) load_unit(f, 0, cur);
     while (f < n_frames) {
         unsigned nxt = 0;
         if (lane == 0) nxt = atomicAdd(g_queue, 1u) + gridDim.x * NW;
-        const float *st_in = g_state_in + f * state_words + off_syn0;
         float *st_out = g_state_out + f * state_words + off_syn0;
-        for (int ch = 0; ch < nout; ch++) {
-            // copy_mono: ps->start == 0 handled by the caller pointing both
-            // channels at plane set 0 (aacsbr.c:1755)
-            const float *X0 = g_X + (f * 2 + (copy_mono ? 0 : ch)) * (2 * 38 * 64);
-            const float *X1 = X0 + 38 * 64;
-            const float *v_in = st_in + ch * HEAAC_ST_SYNTH;
-            float *v_out = st_out + ch * HEAAC_ST_SYNTH;
-            if (FMT == HEAAC_PCM_F32_PLANAR) {
-                float *o = reinterpret_cast<float *>(g_pcm) + ((pcm_frame0 + f) * nout + ch) * 2048;
-                synth_channel(S, w, X0, X1, v_in, v_out, scale, bias, lane,
-                              [&](int i, int n, float v) { o[64 * i + n] = v; });
-            } else if (nout == 1) {
-                int16_t *o = reinterpret_cast<int16_t *>(g_pcm) + (pcm_frame0 + f) * 2048;
-                synth_channel(S, w, X0, X1, v_in, v_out, scale, bias, lane,
-                              [&](int i, int n, float v) { o[64 * i + n] = (int16_t)float_to_int16_one(v); });
-            } else if (ch == 0) {
-                synth_channel<16>(S, w, X0, X1, v_in, v_out, scale, bias, lane,
-                              [&](int i, int n, float v) {
-                                  const uint32_t x = (uint32_t)float_to_int16_one(v) & 0xffff;
-                                  if (i & 1) lpcm[i >> 1] |= x << 16; else lpcm[i >> 1] = x;
-                              });
-            } else {
-                uint32_t *o = reinterpret_cast<uint32_t *>(g_pcm) + (pcm_frame0 + f) * 2048;
-                synth_channel<16>(S, w, X0, X1, v_in, v_out, scale, bias, lane,
-                              [&](int i, int n, float v) {
-                                  // float_to_int16_interleave (dsputil.c:3989-4001)
-                                  o[64 * i + n] = ((lpcm[i >> 1] >> (16 * (i & 1))) & 0xffff) |
-                                                  ((uint32_t)(float_to_int16_one(v) & 0xffff) << 16);
-                              });
+        // one channel: rows from `cur`, then the next unit's loads, then the polyphase sum
+        // (the int16 stereo path keeps its packed left channel in registers through a fully unrolled
+        // sum and has no room for loads in flight: it fetches the next unit afterwards)
+        auto channel = [&](int ch, auto unroll, auto emit) {
+            constexpr bool early = decltype(unroll)::value == 1;
+            SSTAMP(0);
+            syn_rows(S, w, cur, lane);
+            wave_sync();
+            const bool more = ch + 1 < nout;
+            if (early) {
+                if (more) load_unit(f, ch + 1, cur);
+                else if (f1 < n_frames) load_unit(f1, 0, cur);
             }
+            syn_poly<decltype(unroll)::value>(S, w, scale, bias, lane, emit);
+            syn_hist_out(w, st_out + ch * HEAAC_ST_SYNTH, lane);
+            wave_sync();
+            if (!early) {
+                if (more) load_unit(f, ch + 1, cur);
+                else if (f1 < n_frames) load_unit(f1, 0, cur);
+            }
+            SSTAMP(5);
+        };
+        typedef std::integral_constant<int, 1> U1;
+        typedef std::integral_constant<int, 16> U16;
+        if (FMT == HEAAC_PCM_F32_PLANAR) {
+            for (int ch = 0; ch < nout; ch++) {
+                float *o = reinterpret_cast<float *>(g_pcm) + ((pcm_frame0 + f) * nout + ch) * 2048;
+                channel(ch, U1(), [&](int i, int n, float v) { o[64 * i + n] = v; });
+            }
+        } else if (nout == 1) {
+            int16_t *o = reinterpret_cast<int16_t *>(g_pcm) + (pcm_frame0 + f) * 2048;
+            channel(0, U1(), [&](int i, int n, float v) { o[64 * i + n] = (int16_t)float_to_int16_one(v); });
+        } else {
+            channel(0, U16(), [&](int i, int n, float v) {
+                const uint32_t x = (uint32_t)float_to_int16_one(v) & 0xffff;
+                if (i & 1) lpcm[i >> 1] |= x << 16; else lpcm[i >> 1] = x;
+            });
+            uint32_t *o = reinterpret_cast<uint32_t *>(g_pcm) + (pcm_frame0 + f) * 2048;
+            channel(1, U16(), [&](int i, int n, float v) {
+                // float_to_int16_interleave (dsputil.c:3989-4001)
+                o[64 * i + n] = ((lpcm[i >> 1] >> (16 * (i & 1))) & 0xffff) |
+                                ((uint32_t)(float_to_int16_one(v) & 0xffff) << 16);
+            });
         }
-        f = (unsigned long long)__builtin_amdgcn_readfirstlane(nxt);
+        f = f1;
+        f1 = (unsigned long long)__builtin_amdgcn_readfirstlane(nxt);
     }
 }
 
@@ -633,9 +728,12 @@ extern "C" int heaac_launch_qmf_synthesis_ds(const float *d_tab, const float *d_
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
 }
 
+
 #ifdef HF_STAMPS
-extern "C" int heaac_debug_hf_stamps(unsigned long long *out)
+// accumulated phase timeline of this translation unit's kernels (k_synth): out[0..31] cycles, out[32] units
+extern "C" int heaac_debug_timeline_he(unsigned long long *out)
 {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hf_stamps), sizeof(g_hf_stamps)) == hipSuccess ? 0 : -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tl_acc), sizeof(g_tl_acc)) != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out + 32, HIP_SYMBOL(g_tl_cnt), sizeof(g_tl_cnt)) == hipSuccess ? 0 : -1;
 }
 #endif

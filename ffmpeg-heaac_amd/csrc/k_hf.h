@@ -7,9 +7,17 @@
 
 #define ENV_ADJ 2          // ENVELOPE_ADJUSTMENT_OFFSET, aacsbr.c:39
 
-#ifdef HF_STAMPS
-static __device__ unsigned long long g_hf_stamps[16];     // one copy per translation unit
-#define HSTAMP(i) do { wave_sync(); if (lane == 0 && blockIdx.x == 7 && threadIdx.x < 64) g_hf_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#if defined(HF_STAMPS) || defined(PS_STAMPS)
+// Phase timeline (diagnostic builds only): wave 0 of every 8th workgroup accumulates the cycles
+// between consecutive stamps over all the frames it processes; slot 31 = time between frames.
+static __device__ unsigned long long g_tl_acc[32], g_tl_last[256], g_tl_cnt;
+#define TL_STAMP(i, is_first) do { wave_sync(); \
+    if (lane == 0 && (blockIdx.x & 7) == 7 && threadIdx.x < 64) { \
+        const unsigned long long t_ = __builtin_readcyclecounter(), l_ = g_tl_last[blockIdx.x]; \
+        if (is_first) { if (l_) atomicAdd(&g_tl_acc[31], t_ - l_); atomicAdd(&g_tl_cnt, 1ull); } \
+        else atomicAdd(&g_tl_acc[i], t_ - l_); \
+        g_tl_last[blockIdx.x] = t_; } } while (0)
+#define HSTAMP(i) TL_STAMP(i, (i) == 0)
 #else
 #define HSTAMP(i) do {} while (0)
 #endif
@@ -132,11 +140,14 @@ __device__ __forceinline__ v2f xhigh3_pk(v2f x2, v2f x1, v2f x0, const float *a)
 
 // emit(i, re, im) receives X[.][i][k] of this lane's band k = lane for the slots i = 0..37
 // (i is a compile-time constant at every call).
-template <class Emit>
+// after_params(): called once the stage's parameter loads have arrived (a fused kernel stores what it
+// loaded for its later stages beside them, in the same wait).
+template <class Emit, class Hook = NoHook>
 __device__ __forceinline__ void hf_channel(const HfWave &w, const float *g_noise /* LDS */,
                                            const HeaacSbrFrame *g_fr, const HeaacSbrHeader *g_hdr,
                                            int ch, const float *g_W,
-                                           const float *st_in, float *st_out, int lane_in, Emit emit)
+                                           const float *st_in, float *st_out, int lane_in, Emit emit,
+                                           Hook after_params = Hook())
 {
     // redefined opaquely so that lane-derived values are not hoisted out of the unit loop
     // (where they would sit in registers for the whole kernel and get spilled)
@@ -182,6 +193,7 @@ __device__ __forceinline__ void hf_channel(const HfWave &w, const float *g_noise
             if (lane + 64 * r < 133) hd[lane + 64 * r] = hreg[r];
         }
     }
+    after_params();
     wave_sync();
     const HeaacSbrHeader &h = w.h;
     const HeaacSbrChannel &c = w.c[ch];
@@ -361,14 +373,20 @@ __device__ __forceinline__ void hf_channel(const HfWave &w, const float *g_noise
                         const int ilb = c.t_env[e] * 2 + ENV_ADJ, iub = c.t_env[e + 1] * 2 + ENV_ADJ;
                         float sum = 0.0f;
                         if (has_src) {
-                            float2 x2 = make_float2(xrow[2 * (ilb - 2)], xrow[2 * (ilb - 2) + 1]);
-                            float2 x1 = make_float2(xrow[2 * (ilb - 1)], xrow[2 * (ilb - 1) + 1]);
-                            for (int i = ilb; i < iub; i++) {
-                                const float2 x0 = make_float2(xrow[2 * i], xrow[2 * i + 1]);
-                                float re, im;
-                                xhigh3(x2, x1, x0, kc, re, im);
-                                sum += re * re + im * im;
-                                x2 = x1; x1 = x0;
+                            v2f x2 = v2f{xrow[2 * (ilb - 2)], xrow[2 * (ilb - 2) + 1]};
+                            v2f x1 = v2f{xrow[2 * (ilb - 1)], xrow[2 * (ilb - 1) + 1]};
+                            // the next sample is read one step ahead of its use (an envelope spans an
+                            // even number of slots: two steps per trip)
+                            v2f xa = v2f{xrow[2 * ilb], xrow[2 * ilb + 1]};
+                            v2f xb = v2f{xrow[2 * ilb + 2], xrow[2 * ilb + 3]};
+                            for (int i = ilb; i < iub; i += 2) {
+                                const v2f na = v2f{xrow[2 * i + 4], xrow[2 * i + 5]};
+                                const v2f nb = v2f{xrow[2 * i + 6], xrow[2 * i + 7]};
+                                const v2f h0 = xhigh3_pk(x2, x1, xa, kc);
+                                sum += h0.x * h0.x + h0.y * h0.y;
+                                const v2f h1 = xhigh3_pk(x1, xa, xb, kc);
+                                sum += h1.x * h1.x + h1.y * h1.y;
+                                x2 = xa; x1 = xb; xa = na; xb = nb;
                             }
                         } else {
                             for (int i = ilb; i < iub; i++) sum += 0.0f * 0.0f + 0.0f * 0.0f;

@@ -37,7 +37,8 @@ void k_ps(const float *__restrict__ g_tab, const HeaacPsFrame *__restrict__ g_ps
              reinterpret_cast<float (*)[SUB_STRIDE]>(s_scr[wave]),
              reinterpret_cast<float (*)[SUB_STRIDE]>(s_scr[wave] + (WT::NSUB + 1) * SUB_STRIDE),
              s_pw[wave], s_Hs[wave], s_idx[wave][0], s_idx[wave][1],
-             s_idx[wave][GENERAL ? 2 : 0], s_idx[wave][GENERAL ? 3 : 0] };
+             s_idx[wave][GENERAL ? 2 : 0], s_idx[wave][GENERAL ? 3 : 0],
+             g_tab + TB_F20_0_8, g_tab + TB_G1_Q2 };
     const v2f no_cols[32] = {};
     // Frames are dealt round-robin to the waves of the grid; a wave checks the ownership of its
     // next 64 frames at once (one per lane), so a launch that owns few frames costs microseconds.
@@ -88,7 +89,10 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
     __shared__ float s_Hs[HFPS_WAVES][6][WT::NH][WT::NPAR];
     __shared__ signed char s_idx[HFPS_WAVES][2][5][WT::NPAR];
     __shared__ float s_noise[1024];                       // sbr_noise_table, staged once per workgroup
+    __shared__ float s_hyb[8 * 14 + 8];                   // 20-band hybrid filters: f20_0_8, g1_Q2
     wg_copy_f4(s_noise, g_tab + TB_NOISE, 1024);
+    if (threadIdx.x < 112) s_hyb[threadIdx.x] = g_tab[TB_F20_0_8 + threadIdx.x];
+    if (threadIdx.x < 8) s_hyb[112 + threadIdx.x] = g_tab[TB_G1_Q2 + threadIdx.x];
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
     const HfWave H = hf_wave_view(s_a[wave], s_b[wave], s_c[wave]);
@@ -96,20 +100,54 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
              reinterpret_cast<float (*)[SUB_STRIDE]>(s_a[wave]),
              reinterpret_cast<float (*)[SUB_STRIDE]>(s_a[wave] + (WT::NSUB + 1) * SUB_STRIDE),
              reinterpret_cast<float (*)[33]>(s_c[wave]), s_Hs[wave], s_idx[wave][0], s_idx[wave][1],
-             s_idx[wave][0], s_idx[wave][0] };
+             s_idx[wave][0], s_idx[wave][0], s_hyb, s_hyb + 112 };
     // Frames cost between ~0.8x and ~1.3x the mean (envelope counts, smoothing, patches), so the
     // waves draw them from a queue instead of a fixed stride: the first one is the wave's own index,
     // each next one is fetched (one atomic, in flight during the frame) from g_queue.
+    // Two tickets are held: the frame being processed and the next one, whose records are touched
+    // into L2 while the current frame computes (the queue hands the next index out a frame early).
+#ifndef HFPS_PREFETCH
+#define HFPS_PREFETCH 2
+#endif
+    unsigned sink = 0;
     unsigned long long f = (unsigned long long)blockIdx.x * HFPS_WAVES + wave;
+    unsigned tk = 0;
+    if (lane == 0) tk = atomicAdd(g_queue, 1u) + gridDim.x * HFPS_WAVES;          // queue starts behind the static ones
+    unsigned long long f1 = (unsigned long long)__builtin_amdgcn_readfirstlane(tk);
     while (f < n) {
         unsigned nxt = 0;
-        if (lane == 0) nxt = atomicAdd(g_queue, 1u) + gridDim.x * HFPS_WAVES;     // queue starts behind the static ones
+        if (lane == 0) nxt = atomicAdd(g_queue, 1u) + gridDim.x * HFPS_WAVES;
+        auto prefetch_next = [&]() {
+            if (HFPS_PREFETCH >= 1 && f1 < n) {
+                l2_touch(&g_sbr[f1], sizeof(HeaacSbrFrame), lane, sink);
+                l2_touch(&g_ps[f1], sizeof(HeaacPsFrame), lane, sink);
+                if (HFPS_PREFETCH >= 2) {
+                    l2_touch(g_W + f1 * 2048, 2048 * 4, lane, sink);
+                    l2_touch(g_state_in + f1 * state_words + off_sbr, HEAAC_ST_SBR * 4, lane, sink);
+                }
+                if (HFPS_PREFETCH >= 3)
+                    l2_touch(g_state_in + f1 * state_words + off_ps, HEAAC_ST_PS * 4, lane, sink);
+            }
+        };
         const bool base = __builtin_amdgcn_readfirstlane(!ps_frame_is_general(&g_ps[f]));
         float *Xf = g_X + (f * 2) * (2 * 38 * 64);
         const float *st_in = g_state_in + f * state_words;
         float *st_out = g_state_out + f * state_words;
         v2f col[32];
         float (*inb)[44][2] = s_inb[wave];
+        // the PS record and the hybrid filters' history are loaded here, beside the HF stage's
+        // parameters, and stored to LDS in the same wait
+        uint32_t preg[3];
+        float hist_re = 0.0f, hist_im = 0.0f;
+        {
+            const uint32_t *ps_ = reinterpret_cast<const uint32_t *>(&g_ps[f]);
+#pragma unroll
+            for (int r = 0; r < 3; r++) preg[r] = lane + 64 * r < (int)(sizeof(HeaacPsFrame) / 4) ? ps_[lane + 64 * r] : 0;
+            if (lane < WT::NLOW * 6) {
+                hist_re = st_in[off_ps + HEAAC_PS_INBUF + 2 * lane];
+                hist_im = st_in[off_ps + HEAAC_PS_INBUF + 2 * lane + 1];
+            }
+        }
         hf_channel(H, s_noise, &g_sbr[f], g_hdr, 0, g_W + f * 2048, st_in + off_sbr, st_out + off_sbr, lane,
                    [&](int i, float re, float im) {
                        if (i < 32) {
@@ -121,18 +159,27 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
                            Xf[i * 64 + lane] = re;
                            Xf[38 * 64 + i * 64 + lane] = im;
                        }
+                   },
+                   [&]() {
+                       uint32_t *pd = reinterpret_cast<uint32_t *>(&s_p[wave]);
+#pragma unroll
+                       for (int r = 0; r < 3; r++)
+                           if (lane + 64 * r < (int)(sizeof(HeaacPsFrame) / 4)) pd[lane + 64 * r] = preg[r];
+                       if (lane < WT::NLOW * 6) { inb[lane / 6][lane % 6][0] = hist_re; inb[lane / 6][lane % 6][1] = hist_im; }
                    });
         if (!base) {
 #pragma unroll
             for (int i = 0; i < 32; i++) { Xf[i * 64 + lane] = col[i].x; Xf[38 * 64 + i * 64 + lane] = col[i].y; }
-            f = (unsigned long long)__builtin_amdgcn_readfirstlane(nxt);
-            continue;
+        } else {
+            // ff_ps_apply(..., sbr->kx[1] + sbr->m[1]): the header is still in the HF stage's LDS
+            const int top = __builtin_amdgcn_readfirstlane(H.h.kx + H.h.m);
+            ps_frame<false, true>(W, g_tab, &g_ps[f], top, st_in + off_ps, st_out + off_ps, Xf, lane, wave, col,
+                                  prefetch_next);
         }
-        const HeaacSbrHeader &h = g_hdr[g_sbr[f].hdr];
-        const int top = h.kx + h.m;                 // ff_ps_apply(..., sbr->kx[1] + sbr->m[1])
-        ps_frame<false, true>(W, g_tab, &g_ps[f], top, st_in + off_ps, st_out + off_ps, Xf, lane, wave, col);
-        f = (unsigned long long)__builtin_amdgcn_readfirstlane(nxt);
+        f = f1;
+        f1 = (unsigned long long)__builtin_amdgcn_readfirstlane(nxt);
     }
+    l2_touch_drain(sink);
 }
 
 #define PS_WAVES_20 8
@@ -176,17 +223,11 @@ extern "C" int heaac_launch_hfps(const float *d_tab, const HeaacSbrFrame *d_sbr,
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
 }
 
-#ifdef HF_STAMPS
-// stamps of the HF stage inside the fused kernel
-extern "C" int heaac_debug_hfps_stamps(unsigned long long *out)
+#if defined(HF_STAMPS) || defined(PS_STAMPS)
+// accumulated phase timeline of the fused kernel: out[0..31] cycles per phase, out[32] frames
+extern "C" int heaac_debug_timeline(unsigned long long *out)
 {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hf_stamps), sizeof(g_hf_stamps)) == hipSuccess ? 0 : -1;
-}
-#endif
-
-#ifdef PS_STAMPS
-extern "C" int heaac_debug_ps_stamps(unsigned long long *out)
-{
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ps_stamps), sizeof(g_ps_stamps)) == hipSuccess ? 0 : -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tl_acc), sizeof(g_tl_acc)) != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out + 32, HIP_SYMBOL(g_tl_cnt), sizeof(g_tl_cnt)) == hipSuccess ? 0 : -1;
 }
 #endif

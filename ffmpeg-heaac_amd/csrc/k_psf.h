@@ -3,10 +3,10 @@
 #pragma once
 #include "k_common.h"
 #include "heaac_dsp.h"
+#include "k_hf.h"
 
 #ifdef PS_STAMPS
-__device__ unsigned long long g_ps_stamps[16];
-#define STAMP(i) do { wave_sync(); if (lane == 0 && blockIdx.x == 7 && wave == 0) g_ps_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#define STAMP(i) TL_STAMP(16 + (i), false)
 #else
 #define STAMP(i) do {} while (0)
 #endif
@@ -81,6 +81,7 @@ struct PsWaveT {
     float (*pw)[33];                   // [NPAR] band power, then transient gain
     float (*Hs)[NH][NPAR];             // [6]    H11,H12,H21,H22 (re[,im]) rows per envelope border
     signed char (*iid_m)[NPAR], (*icc_m)[NPAR], (*ipd_m)[NPAR], (*opd_m)[NPAR];   // [5]
+    const float *hybF, *hybG;          // 20-band hybrid filters f20_0_8[8][7][2] and g1_Q2[7]: LDS copies or the table blob
 };
 
 // map_idx_* (aacps.c:461-643) as a gather: mapped value of band b.
@@ -208,12 +209,15 @@ __device__ __forceinline__ void hybrid_fir(const float *in, const float *filt, f
 // store is discarded anyway) also carry the QMF band kh2 of their own column -- one of the
 // bands >= 64 with the one-slot delay -- so that every X row leaves as one full 256-byte
 // store and no separate pass over the slots is needed.  dual: this lane has a second role.
-template <bool HEAVY, bool ALIGNED8, bool DUAL, class W>
+// hook(): called once, two thirds into the slot loop (the fused kernel touches the next frame's
+// records into L2 there: early enough to be back before they are needed, late enough to survive
+// in L2 until then).
+template <bool HEAVY, bool ALIGNED8, bool DUAL, class W, class Hook = NoHook>
 __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, const signed char *kti,
                                         int is34, int kh, bool clear_state,
                                         const GBuf &SI, const GBuf &SO, const GBuf &X,
                                         bool is_sub, int q, const v2f (&col)[32],
-                                        bool dual = false, int kh2 = 0, bool clear2 = false)
+                                        bool dual = false, int kh2 = 0, bool clear2 = false, Hook hook = Hook())
 {
     static_assert(!DUAL || HEAVY, "the second role rides on the heavy pass");
     constexpr int dl_stride = 91 * 2, ap_stride = 50 * 2;
@@ -291,6 +295,7 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
     // Fully unrolled over the 32 slots: ring positions and column indices are static.
 #pragma unroll
     for (int n = 0; n < 32; n++) {
+        if (n == 20) hook();
         if ((!ALIGNED8 || (n & 7) == 0) && n > stop) {
             // next envelope (aacps.c:900-938)
             e++;
@@ -462,12 +467,15 @@ __device__ __forceinline__ bool ps_frame_is_general(const HeaacPsFrame *g_p)
 // FUSED: the mono QMF signal arrives in registers from the HF stage of the same wave
 // (hfcol[n] = X[.][n][k] of band k = lane; the look-ahead slots 32..37 of the hybrid bands
 // are already in w.inb) instead of being read from Xrec.
-template <bool GENERAL, bool FUSED = false>
+// FUSED also means: the caller has already copied the frame's PS record into w.p and the hybrid
+// filters' history (in_buf state) into w.inb[.][0..5] (k_hfps issues those loads at the start of the
+// frame, beside the HF stage's own).
+template <bool GENERAL, bool FUSED = false, class Hook = NoHook>
 __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__restrict__ g_tab,
                                          const HeaacPsFrame *g_p, int top_qmf,
                                          const float *st_in, float *st_out,
                                          float *Xrec /* [2][2][38][64]: in: mono in [0], out: left, right */,
-                                         int lane_in, int wave, const v2f (&hfcol)[32])
+                                         int lane_in, int wave, const v2f (&hfcol)[32], Hook hook = Hook())
 {
     static_assert(!(GENERAL && FUSED), "the fused path is the baseline layout only");
     // `lane` is redefined opaquely at every phase: values derived from it (LDS addresses,
@@ -477,7 +485,7 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     using WT = PsWaveT<GENERAL>;
     constexpr int XP = 38 * 64;
     const GBuf SI(st_in), SO(st_out), X(Xrec);
-    {
+    if constexpr (!FUSED) {
         const uint32_t *s = reinterpret_cast<const uint32_t *>(g_p);
         uint32_t *d = reinterpret_cast<uint32_t *>(&w.p);   // w.p is a reference into LDS
         for (int i = lane; i < (int)(sizeof(HeaacPsFrame) / 4); i += WAVE) d[i] = s[i];
@@ -536,15 +544,14 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
             for (int n = 0; n < 32; n++) { w.inb[q_own][n + 6][0] = col[n].x; w.inb[q_own][n + 6][1] = col[n].y; }
         }
     }
+    if constexpr (!FUSED)
     for (int t = lane; t < nlow * 6; t += WAVE) {
         const int i = t / 6, j = t % 6;
         w.inb[i][j][0] = SI.ld(t * 2, HEAAC_PS_INBUF);
         w.inb[i][j][1] = SI.ld(t * 2, HEAAC_PS_INBUF + 1);
         // lookahead slots 32..37
-        if constexpr (!FUSED) {
-            w.inb[i][38 + j][0] = X.ld((32 + j) * 64 + i);
-            w.inb[i][38 + j][1] = X.ld((32 + j) * 64 + i, XP);
-        }
+        w.inb[i][38 + j][0] = X.ld((32 + j) * 64 + i);
+        w.inb[i][38 + j][1] = X.ld((32 + j) * 64 + i, XP);
     }
     wave_sync();
     STAMP(1);
@@ -618,47 +625,61 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- hybrid filters -> sub[ks][n] ----
-    for (int t = lane; t < nsub * 32; t += WAVE) {
-        const int ks = t >> 5, n = t & 31;
-        float re, im;
-        if (is34) {
+    auto hybrid_put = [&](int ks, int n, float re, float im) {
+        w.sub[ks][2 * n] = re;
+        w.sub[ks][2 * n + 1] = im;
+        w.pn[n * WT::PNS + ks] = re * re + im * im;
+    };
+    if (!is34) {
+        // 20-band layout: 10 sub-subbands x 32 slots = five passes of the wave; pass `it` forms the
+        // sub-subbands 2 it and 2 it + 1 (one per half-wave), so which filter a pass applies is known
+        // at compile time and the LDS reads of all passes are in flight together.
+        const int h = lane >> 5, n = lane & 31;
+        const float *F = w.hybF, *G = w.hybG;
+#pragma unroll
+        for (int it = 0; it < 5; it++) {
+            const int ks = 2 * it + h;
+            float re, im;
+            if (it < 3) {
+                // hybrid6_cx (:303-336): out = temp[fa] (+ temp[fb]); order 6,7,0,1,2+5,3+4
+                const float *in = &w.inb[0][n][0];
+                const int fa = it == 0 ? 6 + h : it == 1 ? h : 2 + h;
+                hybrid_fir(in, F + fa * 14, re, im);
+                if (it == 2) {
+                    float br, bi;
+                    hybrid_fir(in, F + (5 - h) * 14, br, bi);
+                    re = re + br;
+                    im = im + bi;
+                }
+            } else {
+                // hybrid2_re (:283-301): band 1 reversed, band 2 not; half-wave h forms out[h]
+                const int reverse = it == 3 ? 1 : 0;
+                const float *in = &w.inb[it - 2][n][0];
+                const float re_in = G[6] * in[12], im_in = G[6] * in[13];
+                float re_op = 0.0f, im_op = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 6; j += 2) {
+                    re_op += G[j + 1] * (in[2 * (j + 1)] + in[2 * (12 - j - 1)]);
+                    im_op += G[j + 1] * (in[2 * (j + 1) + 1] + in[2 * (12 - j - 1) + 1]);
+                }
+                // out[reverse] = in + op, out[!reverse] = in - op: a - b is a + (-b) exactly
+                const bool plus = h == reverse;
+                re = re_in + (plus ? re_op : -re_op);
+                im = im_in + (plus ? im_op : -im_op);
+            }
+            hybrid_put(ks, n, re, im);
+        }
+    } else if constexpr (GENERAL) {
+        for (int t = lane; t < 32 * 32; t += WAVE) {
+            const int ks = t >> 5, n = t & 31;
+            float re, im;
             int qb, f, off;
             if (ks < 12)      { qb = 0; f = ks;      off = TB_F34_0_12; }
             else if (ks < 20) { qb = 1; f = ks - 12; off = TB_F34_1_8; }
             else              { qb = 2 + ((ks - 20) >> 2); f = (ks - 20) & 3; off = TB_F34_2_4; }
             hybrid_fir(&w.inb[qb][n][0], g_tab + off + f * 14, re, im);
-        } else if (ks < 6) {
-            // hybrid6_cx (:303-336): out = temp[fa] (+ temp[fb]); order 6,7,0,1,2+5,3+4
-            const float *in = &w.inb[0][n][0];
-            const float *F = g_tab + TB_F20_0_8;
-            const int fa = ks == 0 ? 6 : ks == 1 ? 7 : ks == 2 ? 0 : ks == 3 ? 1 : ks == 4 ? 2 : 3;
-            hybrid_fir(in, F + fa * 14, re, im);
-            if (ks >= 4) {
-                float br, bi;
-                hybrid_fir(in, F + (ks == 4 ? 5 : 4) * 14, br, bi);
-                re = re + br;
-                im = im + bi;
-            }
-        } else {
-            // hybrid2_re (:283-301): band 1 reversed, band 2 not
-            const int qb = ks < 8 ? 1 : 2, reverse = ks < 8 ? 1 : 0;
-            const int which = (ks - (qb == 1 ? 6 : 8));       // 0 -> out[0], 1 -> out[1]
-            const float *in = &w.inb[qb][n][0];
-            const float *f = g_tab + TB_G1_Q2;
-            const float re_in = f[6] * in[12], im_in = f[6] * in[13];
-            float re_op = 0.0f, im_op = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 6; j += 2) {
-                re_op += f[j + 1] * (in[2 * (j + 1)] + in[2 * (12 - j - 1)]);
-                im_op += f[j + 1] * (in[2 * (j + 1) + 1] + in[2 * (12 - j - 1) + 1]);
-            }
-            // out[reverse] = in + op, out[!reverse] = in - op
-            if (which == reverse) { re = re_in + re_op; im = im_in + im_op; }
-            else                  { re = re_in - re_op; im = im_in - im_op; }
+            hybrid_put(ks, n, re, im);
         }
-        w.sub[ks][2 * n] = re;
-        w.sub[ks][2 * n + 1] = im;
-        w.pn[n * WT::PNS + ks] = re * re + im * im;
     }
     wave_sync();
 
@@ -817,10 +838,10 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
             const int kh2 = lane + 7;
             if (aligned8)
                 ps_band<true, true, true>(w, g_tab, M.kti, is34, kh, kh >= top, SI, SO, X, is_sub, qcol, col,
-                                          dual, kh2, kh2 >= top);
+                                          dual, kh2, kh2 >= top, hook);
             else
                 ps_band<true, false, true>(w, g_tab, M.kti, is34, kh, kh >= top, SI, SO, X, is_sub, qcol, col,
-                                           dual, kh2, kh2 >= top);
+                                           dual, kh2, kh2 >= top, hook);
         }
     }
     STAMP(6);
