@@ -10,16 +10,32 @@
 #include "tables.h"
 #include "kernels.h"
 
+#define HE_MAX_LANES 4
 struct HeaacDevice {
     int device;
     float *d_tab;
     uint16_t *d_rev;
     void *d_work;
-    unsigned *d_queue;      // frame-queue heads of the kernels that draw frames dynamically
+    unsigned *d_queue;      // frame-queue heads of the kernels that draw frames dynamically (one set per lane)
     size_t work_bytes;
     size_t max_frames;
     size_t chunk;
+    int sets;               // workspace sets allocated: 1 (batches of one chunk) or HE_LANES
+    // Chunks of one HE call alternate between two internal streams ("lanes"), each with its own
+    // workspace half and queue heads: the persistent kernels of one chunk drain while the next
+    // chunk's kernels fill the freed CUs, so a chunk can be small enough for its W / X workspace to
+    // live in the 256 MiB Infinity Cache between the kernel that writes it and the one that reads it.
+    hipStream_t lane[HE_MAX_LANES];
+    hipEvent_t fork, join[HE_MAX_LANES];
+    int lanes;
 };
+static int he_lanes()
+{
+    const char *env = getenv("HEAAC_LANES");                 /* tuning knob */
+    int l = env ? atoi(env) : 2;
+    return l < 1 ? 1 : l > HE_MAX_LANES ? HE_MAX_LANES : l;
+}
+#define HE_LANES he_lanes()
 
 extern "C" const char *heaac_build_info(void)
 {
@@ -38,24 +54,32 @@ extern "C" const char *heaac_strerror(int err)
     return "unknown error";
 }
 
-// HE pipeline stages exchange W[ncore][32][32][2] and X[2][2][38][64] per frame
-// through this workspace, one chunk of frames at a time.  Measured on MI355X
-// (profiles/r01_chunk_sweep.txt): throughput rises monotonically with the chunk
-// size (persistent-kernel tails amortise); keeping the workspace inside the
-// 256 MiB Infinity Cache (chunk <= 4096) costs more in tails than it saves in
-// HBM traffic while the kernels are latency-bound.
-#define HE_CHUNK_FRAMES 131072
+// HE pipeline stages exchange W[ncore][32][32][2] and X[2][2][38][64] per frame through this
+// workspace, one chunk of frames at a time.  Measured on MI355X (profiles/r01_chunk_sweep.txt,
+// profiles/r02_chunk_lanes.txt): throughput rises with the chunk size (the tails of the persistent
+// kernels amortise) up to the whole 256 k-frame batch; chunks small enough to keep the workspace
+// in the 256 MiB Infinity Cache lose more in tails than they save, also when consecutive chunks
+// overlap on two streams.  Batches beyond one chunk alternate between two lanes (below).
+#define HE_CHUNK_FRAMES 262144
 #define WS_W_FLOATS (2 * 2048)
 #define WS_X_FLOATS (2 * 2 * 38 * 64)
 
-extern "C" size_t heaac_device_workspace_bytes(size_t max_frames)
+static size_t he_chunk_frames(size_t max_frames)
 {
     size_t cap = HE_CHUNK_FRAMES;
     const char *env = getenv("HEAAC_CHUNK_FRAMES");          /* tuning knob */
     if (env && atol(env) >= 64) cap = (size_t)atol(env);
     size_t chunk = max_frames < cap ? max_frames : cap;
-    if (chunk < 64) chunk = 64;
-    return chunk * (WS_W_FLOATS + WS_X_FLOATS) * sizeof(float);
+    return chunk < 64 ? 64 : chunk;
+}
+
+extern "C" size_t heaac_device_workspace_bytes(size_t max_frames)
+{
+    // one workspace set per lane; a batch that fits one chunk runs on the caller's stream alone
+    const size_t chunk = he_chunk_frames(max_frames);
+    size_t sets = max_frames > chunk ? (size_t)HE_LANES : 1;
+    if (sets > 1 && (max_frames + chunk - 1) / chunk < sets) sets = (max_frames + chunk - 1) / chunk;
+    return sets * chunk * (WS_W_FLOATS + WS_X_FLOATS) * sizeof(float);
 }
 
 extern "C" int heaac_device_create(HeaacDevice **out, size_t max_frames)
@@ -79,11 +103,14 @@ extern "C" int heaac_device_create(HeaacDevice **out, size_t max_frames)
     heaac_build_tables(t);
     d->max_frames = max_frames;
     d->work_bytes = heaac_device_workspace_bytes(max_frames);
-    d->chunk = d->work_bytes / ((WS_W_FLOATS + WS_X_FLOATS) * sizeof(float));
+    d->chunk = he_chunk_frames(max_frames);
+    d->sets = max_frames > d->chunk ? HE_LANES : 1;
+    if (d->sets > 1 && (max_frames + d->chunk - 1) / d->chunk < (size_t)d->sets)
+        d->sets = (int)((max_frames + d->chunk - 1) / d->chunk);
     int rc = HEAAC_OK;
     if (hipMalloc((void **)&d->d_tab, sizeof(t->f)) != hipSuccess ||
         hipMalloc((void **)&d->d_rev, sizeof(t->rev)) != hipSuccess ||
-        hipMalloc((void **)&d->d_queue, 64) != hipSuccess ||
+        hipMalloc((void **)&d->d_queue, 64 * HE_MAX_LANES) != hipSuccess ||
         (d->work_bytes && hipMalloc(&d->d_work, d->work_bytes) != hipSuccess))
         rc = HEAAC_ERR_NOMEM;
     if (rc == HEAAC_OK &&
@@ -91,6 +118,13 @@ extern "C" int heaac_device_create(HeaacDevice **out, size_t max_frames)
          hipMemcpy(d->d_rev, t->rev, sizeof(t->rev), hipMemcpyHostToDevice) != hipSuccess))
         rc = HEAAC_ERR_HIP;
     free(t);
+    d->lanes = HE_LANES;
+    if (rc == HEAAC_OK && hipEventCreateWithFlags(&d->fork, hipEventDisableTiming) != hipSuccess)
+        rc = HEAAC_ERR_HIP;
+    for (int k = 0; k < d->lanes && rc == HEAAC_OK; k++)
+        if (hipEventCreateWithFlags(&d->join[k], hipEventDisableTiming) != hipSuccess ||
+            hipStreamCreateWithFlags(&d->lane[k], hipStreamNonBlocking) != hipSuccess)
+            rc = HEAAC_ERR_HIP;
     if (rc != HEAAC_OK) {
         heaac_device_destroy(d);
         return rc;
@@ -106,6 +140,11 @@ extern "C" void heaac_device_destroy(HeaacDevice *d)
     if (d->d_rev) (void)hipFree(d->d_rev);
     if (d->d_work) (void)hipFree(d->d_work);
     if (d->d_queue) (void)hipFree(d->d_queue);
+    for (int k = 0; k < HE_MAX_LANES; k++) {
+        if (d->lane[k]) (void)hipStreamDestroy(d->lane[k]);
+        if (d->join[k]) (void)hipEventDestroy(d->join[k]);
+    }
+    if (d->fork) (void)hipEventDestroy(d->fork);
     free(d);
 }
 
@@ -175,20 +214,39 @@ extern "C" int heaac_he_decode_batch(HeaacDevice *dev, int cfg,
     const size_t words = cfg == HEAAC_CFG_HEV1 ? HEAAC_STATE_WORDS_HEV1 :
                          cfg == HEAAC_CFG_HEV2 ? HEAAC_STATE_WORDS_HEV2 : HEAAC_STATE_WORDS_HEV1_MONO;
     const size_t pcm_bytes = (size_t)nout * 2048 * (pcm_format == HEAAC_PCM_F32_PLANAR ? 4 : 2);
-    float *ws_W = (float *)dev->d_work;
-    float *ws_X = ws_W + dev->chunk * WS_W_FLOATS;
-    for (size_t f0 = 0; f0 < n; f0 += dev->chunk) {
-        const size_t nc = n - f0 < dev->chunk ? n - f0 : dev->chunk;
-        int rc = heaac_launch_he(dev->d_tab, dev->d_rev, cfg,
-                                 d_coeffs + f0 * ncore * 1024, d_ics + f0 * ncore,
-                                 d_sbr + f0, d_hdr, d_ps ? d_ps + f0 : NULL,
-                                 d_state_in + f0 * words, d_state_out + f0 * words,
-                                 (char *)d_pcm + f0 * pcm_bytes, pcm_format,
-                                 ws_W, ws_X, dev->d_queue, nc, 0, (hipStream_t)stream);
-        if (rc != HEAAC_OK)
-            return rc;
+    const size_t set_floats = dev->chunk * (WS_W_FLOATS + WS_X_FLOATS);
+    hipStream_t s = (hipStream_t)stream;
+    // one chunk: everything on the caller's stream; more: fork onto the two lanes and join again
+    // (event fork / join, so the call stays capturable into a hipGraph)
+    const bool lanes = n > dev->chunk && dev->sets > 1;
+    const int nl = lanes ? dev->sets : 1;
+    if (lanes) {
+        if (hipEventRecord(dev->fork, s) != hipSuccess) return HEAAC_ERR_HIP;
+        for (int k = 0; k < nl; k++)
+            if (hipStreamWaitEvent(dev->lane[k], dev->fork, 0) != hipSuccess) return HEAAC_ERR_HIP;
     }
-    return HEAAC_OK;
+    int rc = HEAAC_OK;
+    size_t c = 0;
+    for (size_t f0 = 0; f0 < n && rc == HEAAC_OK; f0 += dev->chunk, c++) {
+        const size_t nc = n - f0 < dev->chunk ? n - f0 : dev->chunk;
+        const int k = (int)(c % nl);
+        float *ws_W = (float *)dev->d_work + k * set_floats;
+        float *ws_X = ws_W + dev->chunk * WS_W_FLOATS;
+        rc = heaac_launch_he(dev->d_tab, dev->d_rev, cfg,
+                             d_coeffs + f0 * ncore * 1024, d_ics + f0 * ncore,
+                             d_sbr + f0, d_hdr, d_ps ? d_ps + f0 : NULL,
+                             d_state_in + f0 * words, d_state_out + f0 * words,
+                             (char *)d_pcm + f0 * pcm_bytes, pcm_format,
+                             ws_W, ws_X, dev->d_queue + 16 * k, nc, 0, lanes ? dev->lane[k] : s);
+    }
+    if (lanes) {
+        // always rejoin, also after a failed launch (a capture must not be left forked)
+        for (int k = 0; k < nl; k++)
+            if (hipEventRecord(dev->join[k], dev->lane[k]) != hipSuccess ||
+                hipStreamWaitEvent(s, dev->join[k], 0) != hipSuccess)
+                rc = rc == HEAAC_OK ? HEAAC_ERR_HIP : rc;
+    }
+    return rc;
 }
 
 extern "C" int heaac_qmf_analysis_batch(HeaacDevice *dev, const float *d_in,
@@ -232,7 +290,7 @@ extern "C" int heaac_debug_workspace(HeaacDevice *dev, float **d_W, float **d_X,
 {
     if (!dev) return HEAAC_ERR_ARG;
     if (d_W) *d_W = (float *)dev->d_work;
-    if (d_X) *d_X = (float *)dev->d_work + dev->chunk * WS_W_FLOATS;
+    if (d_X) *d_X = (float *)dev->d_work + dev->chunk * WS_W_FLOATS;      /* set 0 */
     if (chunk) *chunk = dev->chunk;
     return HEAAC_OK;
 }

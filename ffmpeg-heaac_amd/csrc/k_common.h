@@ -86,25 +86,37 @@ __device__ __forceinline__ int opaque(int v)
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
 // ---------------------------------------------------------------------------
-// L2 prefetch of a record the wave will read a frame later: every lane loads one dword of a
-// different 128-byte line (sc1: past the CU's vector L1, allocated in the XCD's L2), the data is
-// thrown away.  `sink` is the one VGPR all these loads write; it must stay live (loop-carried) until
-// the l2_touch_drain() after the unit loop, so that a load returning late never lands in a register
-// the compiler has given to something else.  The compiler's own vmcnt bookkeeping stays correct:
-// these loads are older than anything it waits for afterwards (vmcnt retires in order).
+// L2 prefetch of a record the wave will read a little later: every lane loads one dword of a
+// different 128-byte line (sc1: past the CU's vector L1, allocated in the XCD's L2) and the data is
+// thrown away.  The loads are LDS-DMA (`global_load_lds_dword`): they have NO register destination,
+// so a load returning late cannot land in a register the compiler has meanwhile given to something
+// else (it schedules an asm statement as one opaque instruction and knows nothing of the load in
+// flight).  They write 256 bytes of LDS nobody reads: `dump` is that area's LDS byte address (wave
+// uniform; all waves of a workgroup may share it).  The compiler's own vmcnt bookkeeping stays
+// correct: these loads are older than anything it waits for afterwards (vmcnt retires in order).
+// A kernel that touches must end with l2_touch_drain(): its LDS may go to another workgroup only
+// once every DMA write has landed.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void l2_touch(const void *base, unsigned bytes, int lane, unsigned &sink)
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    // low half of a flat LDS address = the LDS byte offset
+    return __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(p));
+}
+__device__ __forceinline__ void l2_touch(const void *base, unsigned bytes, int lane, unsigned dump)
 {
     for (unsigned o = 0; o < bytes; o += WAVE * 128) {
         unsigned off = o + (unsigned)lane * 128;
         off = off < bytes ? off : bytes - 4;                 // surplus lanes re-touch the last line
         const char *p = reinterpret_cast<const char *>(base) + off;
-        asm volatile("global_load_dword %0, %1, off sc1" : "+v"(sink) : "v"(p) : "memory");
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dword %1, off sc1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(p), "s"(dump) : "memory");
     }
 }
-__device__ __forceinline__ void l2_touch_drain(unsigned &sink)
+__device__ __forceinline__ void l2_touch_drain()
 {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) :: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ---------------------------------------------------------------------------

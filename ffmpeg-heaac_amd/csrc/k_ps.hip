@@ -90,6 +90,7 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
     __shared__ signed char s_idx[HFPS_WAVES][2][5][WT::NPAR];
     __shared__ float s_noise[1024];                       // sbr_noise_table, staged once per workgroup
     __shared__ float s_hyb[8 * 14 + 8];                   // 20-band hybrid filters: f20_0_8, g1_Q2
+    __shared__ float s_dump[64];                          // where the L2 prefetches' LDS-DMA writes go (never read)
     wg_copy_f4(s_noise, g_tab + TB_NOISE, 1024);
     if (threadIdx.x < 112) s_hyb[threadIdx.x] = g_tab[TB_F20_0_8 + threadIdx.x];
     if (threadIdx.x < 8) s_hyb[112 + threadIdx.x] = g_tab[TB_G1_Q2 + threadIdx.x];
@@ -109,7 +110,7 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
 #ifndef HFPS_PREFETCH
 #define HFPS_PREFETCH 2
 #endif
-    unsigned sink = 0;
+    const unsigned sink = lds_addr(s_dump);
     unsigned long long f = (unsigned long long)blockIdx.x * HFPS_WAVES + wave;
     unsigned tk = 0;
     if (lane == 0) tk = atomicAdd(g_queue, 1u) + gridDim.x * HFPS_WAVES;          // queue starts behind the static ones
@@ -179,7 +180,7 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
         f = f1;
         f1 = (unsigned long long)__builtin_amdgcn_readfirstlane(nxt);
     }
-    l2_touch_drain(sink);
+    l2_touch_drain();
 }
 
 #define PS_WAVES_20 8
