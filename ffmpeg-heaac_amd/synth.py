@@ -71,10 +71,21 @@ def lc_stream(rng, n, steps, channels=2):
 # ---------------------------------------------------------------------------
 # HE-AAC (SBR + PS) parameter streams
 # ---------------------------------------------------------------------------
-def default_headers(pkg, extra=False):
+def null_header(pkg):
+    """The decoder's SBR state before any header has arrived: kx = 32, m = 0 (aacsbr.c:130), nothing
+    else set.  Frames that refer to it carry start = 0 ("pure upsampling": analysis, the low band
+    copied through, synthesis)."""
+    h = np.zeros(1, pkg.SBR_HDR_DT)
+    h["kx"] = 32
+    h["map_hi"] = h["map_lo"] = h["map_nq"] = h["map_lim"] = h["map_mid"] = h["map_src"] = 0xff
+    return h
+
+
+def default_headers(pkg, extra=False, null=False):
     """SBR header table.  Entry 0 is the survey's probe header (48 kHz SBR rate:
     k0=13, kx=13, m=32, 3 patches); `extra` adds variants (smoothing on,
-    non-interpolated envelopes, limiter off, other band layouts)."""
+    non-interpolated envelopes, limiter off, other band layouts); `null` appends null_header()
+    as the LAST entry."""
     hs = [pkg.sbr_make_header()]
     if extra:
         hs += [
@@ -89,6 +100,8 @@ def default_headers(pkg, extra=False):
             pkg.sbr_make_header(start_freq=2, stop_freq=1, xover=0, freq_scale=3, alter_scale=0,
                                 noise_bands=3, limiter_bands=3),
         ]
+    if null:
+        hs.append(null_header(pkg))
     return np.concatenate(hs)
 
 
@@ -232,35 +245,70 @@ class _PsChain:
         self.num_env, self.is34 = num_env, is34
 
 
-def he_stream(rng, cfg, n, steps, hdr, ps_mode="20", hdr_choice=None, core_bins=400, coupling=0.0):
+def he_stream(rng, cfg, n, steps, hdr, ps_mode="20", hdr_choice=None, core_bins=400, coupling=0.0,
+              events=None):
     """Yield dicts {coeffs, ics, sbr, ps} per step for n streams.
     hdr: header table; hdr_choice: per-stream header index (default all 0);
-    coupling: fraction of CPE streams coded with bs_coupling = 1 (HE-AACv1 only)."""
+    coupling: fraction of CPE streams coded with bs_coupling = 1 (HE-AACv1 only).
+    events: the decoder's degrade and transition paths, all off by default --
+      lead_in   : up to this many frames per stream BEFORE the first SBR header (start = 0 on the null
+                  header, which must be the table's last entry: ff_sbr_apply's pure-upsampling path,
+                  aacsbr.c:1723-1750 with kx = 32, m = 0)
+      p_switch  : per frame, the stream's header changes to another table entry (sbr->reset = 1,
+                  kx[0] / m[0] = the old header's, aacsbr.c:1062-1073, 1412-1446, 1632-1637)
+      p_drop    : per frame, the SBR payload is unusable (start = 0 mid-stream, aacsbr.c:989-1000): no HF
+                  stage, state passes through; the grid of the frame is never parsed
+      p_ps_off  : per frame, the PS payload is unusable (ps->start = 0, aacps.c:275-277): the mono QMF
+                  signal is copied to both channels (aacsbr.c:1755), PS state untouched."""
     ncore = 2 if cfg == CFG_HEV1 else 1
+    ev = dict(lead_in=0, p_switch=0.0, p_drop=0.0, p_ps_off=0.0)
+    ev.update(events or {})
+    nreal = len(hdr) - 1 if ev["lead_in"] else len(hdr)       # the null header is not a switch target
     if hdr_choice is None:
         hdr_choice = np.zeros(n, int)
+    hdr_choice = np.array(hdr_choice, int).copy()
     ics_chains = [_IcsChain(rng, n) for _ in range(ncore)]
     sbr_chains = [[_SbrChain(rng, hdr[hdr_choice[s]], hdr_choice[s]) for _ in range(ncore)] for s in range(n)]
     ps_chains = [_PsChain(rng, ps_mode) for _ in range(n)] if cfg == CFG_HEV2 else None
     coupled = (rng.random(n) < coupling) if cfg == CFG_HEV1 else np.zeros(n, bool)
-    first = True
-    for _ in range(steps):
+    lead = rng.integers(0, ev["lead_in"] + 1, n) if ev["lead_in"] else np.zeros(n, int)
+    started = np.zeros(n, bool)                               # a header has been seen
+    prev_kx_m = [(32, 0)] * n                                 # kx[1] / m[1] of the previous frame
+    for step in range(steps):
         ics = np.stack([ch.step() for ch in ics_chains], axis=1)
         coeffs = np.stack([_coeffs(rng, ics[:, c], core_bins) for c in range(ncore)], axis=1)
         sbr = np.zeros(n, SBR_FRAME_DT)
         ps = np.zeros(n, PS_FRAME_DT) if cfg == CFG_HEV2 else None
         for s in range(n):
-            h = hdr[hdr_choice[s]]
             fr = sbr[s]
-            fr["hdr"] = hdr_choice[s]
-            fr["start"] = 1
-            fr["reset"] = 1 if first else 0
-            # kx[0]/m[0]: previous frame's kx/m; 32/0 before the first header (aacsbr.c:130)
-            fr["kx_old"] = 32 if first else h["kx"]
-            fr["m_old"] = 0 if first else h["m"]
-            for c in range(ncore):
-                sbr_chains[s][c].step(fr["ch"][c])
-            if coupled[s]:
+            fr["kx_old"], fr["m_old"] = prev_kx_m[s]
+            if step < lead[s]:
+                # no header yet: kx = 32, m = 0, nothing parsed
+                fr["hdr"] = len(hdr) - 1
+                fr["start"] = 0
+                prev_kx_m[s] = (32, 0)
+            else:
+                reset = not started[s]
+                if started[s] and nreal > 1 and ev["p_switch"] > 0 and rng.random() < ev["p_switch"]:
+                    hdr_choice[s] = (hdr_choice[s] + 1 + int(rng.integers(0, nreal - 1))) % nreal
+                    for c in range(ncore):
+                        sbr_chains[s][c].hdr, sbr_chains[s][c].hdr_idx = hdr[hdr_choice[s]], hdr_choice[s]
+                    reset = True
+                h = hdr[hdr_choice[s]]
+                fr["hdr"] = hdr_choice[s]
+                fr["reset"] = 1 if reset else 0
+                prev_kx_m[s] = (int(h["kx"]), int(h["m"]))
+                if started[s] and not reset and ev["p_drop"] > 0 and rng.random() < ev["p_drop"]:
+                    fr["start"] = 0
+                    for c in range(ncore):
+                        ch = sbr_chains[s][c]
+                        fr["ch"][c]["t_env_num_env_old"] = 0 if ch.first else ch.t_env_last
+                else:
+                    fr["start"] = 1
+                    started[s] = True
+                    for c in range(ncore):
+                        sbr_chains[s][c].step(fr["ch"][c])
+            if fr["start"] and coupled[s]:
                 # read_sbr_channel_pair_element with bs_coupling (aacsbr.c:842-858): channel 1 takes
                 # channel 0's grid (copy_sbr_grid, :747-766) and inverse-filtering modes; envelope and
                 # noise data are read per channel (balance values for channel 1)
@@ -279,8 +327,10 @@ def he_stream(rng, cfg, n, steps, hdr, ps_mode="20", hdr_choice=None, core_bins=
                 ch1.num_env, ch1.t_env_last, ch1.e_a1 = ch0.num_env, ch0.t_env_last, ch0.e_a1
                 ch1.freq_res_last, ch1.invf = ch0.freq_res_last, c1["bs_invf_mode"][0].copy()
             if ps is not None:
-                ps_chains[s].step(ps[s])
-        first = False
+                if ev["p_ps_off"] > 0 and rng.random() < ev["p_ps_off"]:
+                    ps[s]["start"] = 0
+                else:
+                    ps_chains[s].step(ps[s])
         yield dict(coeffs=np.ascontiguousarray(coeffs), ics=np.ascontiguousarray(ics), sbr=sbr, ps=ps)
 
 

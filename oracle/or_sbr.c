@@ -678,9 +678,16 @@ static void sbr_pack(float *st, const float *st_in, const sbr_ch *d, const Heaac
         return;
     memcpy(st + HEAAC_SBR_YTAIL, d->Y[1][32], 6 * 64 * 2 * sizeof(float));
     if (!h->bs_smoothing_mode) {
+        /* Only the m[1] bands of the current header are live history: a wider range arrives only
+         * with sbr->reset, which refills the rows from gain[0] / q_m[0] (aacsbr.c:1632-1637) before
+         * anything reads them.  The reference's persistent g_temp rows keep whatever an older, wider
+         * header left above m[1]; the state record defines those words as zero. */
+        const int m_max = h->m < 48 ? h->m : 48;
         for (j = 0; j < 4; j++) {
-            memcpy(st + HEAAC_SBR_GTAIL + 48 * j, d->g_temp[2 * c->t_env[c->bs_num_env] + j], 48 * sizeof(float));
-            memcpy(st + HEAAC_SBR_QTAIL + 48 * j, d->q_temp[2 * c->t_env[c->bs_num_env] + j], 48 * sizeof(float));
+            memset(st + HEAAC_SBR_GTAIL + 48 * j, 0, 48 * sizeof(float));
+            memset(st + HEAAC_SBR_QTAIL + 48 * j, 0, 48 * sizeof(float));
+            memcpy(st + HEAAC_SBR_GTAIL + 48 * j, d->g_temp[2 * c->t_env[c->bs_num_env] + j], m_max * sizeof(float));
+            memcpy(st + HEAAC_SBR_QTAIL + 48 * j, d->q_temp[2 * c->t_env[c->bs_num_env] + j], m_max * sizeof(float));
         }
     }
     memcpy(st + HEAAC_SBR_BW, d->bw_array, 5 * sizeof(float));
@@ -774,6 +781,15 @@ static int he_frame(int cfg, const float *coeffs, const HeaacIcs *ics,
             if (dp->Xlow)  memcpy(dp->Xlow, s.X_low, sizeof(s.X_low));
             if (dp->Xhigh) memcpy(dp->Xhigh, s.X_high, sizeof(s.X_high));
             if (dp->Y)     memcpy(dp->Y, d[ch].Y[1], sizeof(d[ch].Y[1]));
+        }
+        if (!fr->start) {
+            /* No HF stage this frame, so no Y[0] <- Y[1] either (aacsbr.c:1629): the reference's
+             * sbr_x_gen would read a Y[0] that is one frame older than the state record holds, and,
+             * above kx[1], the whole stale Y[1] of the last frame that had one.  Neither is live state
+             * of an error-free stream (start = 0 mid-stream follows a payload that failed to parse);
+             * the record's rule: the first i_Temp slots take the Y tail it carries,
+             * Y[1][i < 32] reads as zero. */
+            memcpy(d[ch].Y[0], d[ch].Y[1], sizeof(d[ch].Y[0]));
         }
         x_gen(s.X[ch], s.X_low, d[ch].Y, fr->kx_old, fr->m_old, kx1, m1, c->t_env_num_env_old);
         sbr_pack(st_out + off_sbr[ch], st_in + off_sbr[ch], &d[ch], c, h, fr->start);

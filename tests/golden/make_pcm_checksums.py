@@ -21,7 +21,12 @@ CASES = {
     "hev2_20": ("he", "CFG_HEV2", 12, 4, 505, "20"),
     "hev2_mix": ("he", "CFG_HEV2", 10, 5, 506, "mix"),
     "tools_cpe": ("tools", None, 40, 2, 507, None),
+    # the decoder's degrade and transition paths (synth.he_stream events): frames before the first SBR
+    # header, mid-stream header changes, unusable SBR / PS payloads
+    "hev1_events": ("he_ev", "CFG_HEV1", 14, 7, 508, None),
+    "hev2_events": ("he_ev", "CFG_HEV2", 14, 7, 509, "mix"),
 }
+EVENTS = dict(lead_in=2, p_switch=0.3, p_drop=0.15, p_ps_off=0.2)
 
 
 def _h(*arrays):
@@ -42,12 +47,15 @@ def run_case(name, pkg, synth, decode_lc, decode_he, tools):
         for coeffs, ics in synth.lc_stream(rng, n, steps, ch):
             pcm, state = decode_lc(ch, coeffs, ics, state, pkg.PCM_S16)
             out.append(_h(pcm, state))
-    elif kind == "he":
+    elif kind in ("he", "he_ev"):
         cfg = getattr(pkg, cfg_name)
-        hdr = synth.default_headers(pkg, extra=True)
+        hdr = synth.default_headers(pkg, extra=True, null=kind == "he_ev")
         state = np.zeros((n, pkg.STATE_WORDS[cfg]), np.float32)
         kw = dict(ps_mode=ps_mode) if ps_mode else {}
-        for fr in synth.he_stream(rng, cfg, n, steps, hdr, hdr_choice=np.arange(n) % len(hdr), **kw):
+        if kind == "he_ev":
+            kw.update(events=EVENTS, coupling=0.3)
+        nh = len(hdr) - (kind == "he_ev")
+        for fr in synth.he_stream(rng, cfg, n, steps, hdr, hdr_choice=np.arange(n) % nh, **kw):
             pcm, state = decode_he(cfg, fr["coeffs"], fr["ics"], fr["sbr"], hdr, fr["ps"], state, pkg.PCM_S16)
             out.append(_h(pcm, state))
     else:

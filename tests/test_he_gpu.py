@@ -69,7 +69,7 @@ def test_qmf_synthesis_downsampled_batch(pkg, oracle, dev, n):
 
 
 def _run_chain(pkg, oracle, dev, cfg, n, steps, seed, hdr, ps_mode="20", hdr_choice=None, fmt=None,
-               check_state=True, coupling=0.0):
+               check_state=True, coupling=0.0, events=None, in_place=False):
     import torch
     synth = _synth()
     rng = np.random.default_rng(seed)
@@ -77,13 +77,18 @@ def _run_chain(pkg, oracle, dev, cfg, n, steps, seed, hdr, ps_mode="20", hdr_cho
     state = np.zeros((n, pkg.STATE_WORDS[cfg]), np.float32)
     d_state = torch.from_numpy(state).cuda()
     d_hdr = pkg.to_device(hdr)
+    seen = dict(lead=0, reset=0, drop=0, ps_off=0)
     for step, fr in enumerate(synth.he_stream(rng, cfg, n, steps, hdr, ps_mode=ps_mode, hdr_choice=hdr_choice,
-                                              coupling=coupling)):
+                                              coupling=coupling, events=events)):
+        seen["lead"] += int(((fr["sbr"]["start"] == 0) & (fr["sbr"]["hdr"] == len(hdr) - 1)).sum())
+        seen["drop"] += int(((fr["sbr"]["start"] == 0) & (fr["sbr"]["hdr"] != len(hdr) - 1)).sum())
+        seen["reset"] += int((fr["sbr"]["reset"] == 1).sum()) if step else 0
+        seen["ps_off"] += int((fr["ps"]["start"] == 0).sum()) if fr["ps"] is not None else 0
         ref_pcm, state = oracle.he_decode_batch(cfg, fr["coeffs"], fr["ics"], fr["sbr"], hdr, fr["ps"], state, fmt)
         pcm, d_state = dev.he_decode(cfg, torch.from_numpy(fr["coeffs"]).cuda(), pkg.to_device(fr["ics"]),
                                      pkg.to_device(fr["sbr"]), d_hdr,
                                      pkg.to_device(fr["ps"]) if fr["ps"] is not None else None,
-                                     d_state, pcm_format=fmt)
+                                     d_state, state_out=d_state if in_place else None, pcm_format=fmt)
         got = pcm.cpu().numpy()
         if fmt == pkg.PCM_F32:
             nbad, where = _mismatch(got, ref_pcm)
@@ -93,6 +98,7 @@ def _run_chain(pkg, oracle, dev, cfg, n, steps, seed, hdr, ps_mode="20", hdr_cho
         if check_state:
             nbad, where = _mismatch(d_state.cpu().numpy(), state)
             assert nbad == 0, "step %d: %d state words differ, first at %s" % (step, nbad, where)
+    return seen
 
 
 def test_hev1_stereo_chain_default_header(pkg, oracle, dev):
@@ -265,3 +271,37 @@ def test_random_sbr_headers(pkg, oracle, dev, cfg_name):
     n = 2 * len(hdr)
     _run_chain(pkg, oracle, dev, getattr(pkg, cfg_name), n, 4, 71, hdr, hdr_choice=np.arange(n) % len(hdr),
                ps_mode="mix")
+
+
+EVENTS = dict(lead_in=3, p_switch=0.3, p_drop=0.15, p_ps_off=0.2)
+
+
+@pytest.mark.parametrize("in_place", [False, True])
+def test_hev1_degrade_and_transition_paths(pkg, oracle, dev, in_place):
+    """Frames before the first SBR header (start = 0 on the null header: pure upsampling,
+    aacsbr.c:1723-1750), mid-stream header changes (reset = 1, kx[0] / m[0] of the old header:
+    sbr_x_gen's i_Temp path :1412-1446, g_temp refill :1632-1637) and unusable SBR payloads (start = 0
+    mid-stream, state passes through), coupled and uncoupled channel pairs."""
+    hdr = _synth().default_headers(pkg, extra=True, null=True)
+    n = 72
+    seen = _run_chain(pkg, oracle, dev, pkg.CFG_HEV1, n, 9, 61, hdr, hdr_choice=np.arange(n) % (len(hdr) - 1),
+                      coupling=0.3, events=EVENTS, in_place=in_place)
+    assert seen["lead"] > 20 and seen["reset"] > 60 and seen["drop"] > 20, seen
+
+
+@pytest.mark.parametrize("ps_mode,in_place", [("20", False), ("mix", False), ("mix", True)])
+def test_hev2_degrade_and_transition_paths(pkg, oracle, dev, ps_mode, in_place):
+    """The same for HE-AACv2, plus PS payloads that fail to parse (ps->start = 0: L copied to R,
+    aacsbr.c:1755, PS state untouched, num_env_old / is34bands_old of the last parsed frame after it)."""
+    hdr = _synth().default_headers(pkg, extra=True, null=True)
+    n = 72
+    seen = _run_chain(pkg, oracle, dev, pkg.CFG_HEV2, n, 9, 62, hdr, ps_mode=ps_mode,
+                      hdr_choice=np.arange(n) % (len(hdr) - 1), events=EVENTS, in_place=in_place)
+    assert seen["lead"] > 20 and seen["reset"] > 60 and seen["drop"] > 20 and seen["ps_off"] > 60, seen
+
+
+def test_hev2_degrade_paths_s16(pkg, oracle, dev):
+    hdr = _synth().default_headers(pkg, extra=True, null=True)
+    n = 40
+    _run_chain(pkg, oracle, dev, pkg.CFG_HEV2, n, 6, 63, hdr, ps_mode="mix",
+               hdr_choice=np.arange(n) % (len(hdr) - 1), events=EVENTS, fmt=pkg.PCM_S16)
