@@ -103,6 +103,7 @@ EXPORTED = [
     "heaac_he_decode_batch", "heaac_qmf_analysis_batch", "heaac_qmf_synthesis_batch",
     "heaac_qmf_synthesis_ds_batch",
     "heaac_sbr_make_header", "heaac_build_info", "heaac_spectral_tools_batch",
+    "heaac_validate_frame", "heaac_he_check_batch",
     # heaac_fft.h
     "ff_fft_init", "ff_fft_end", "ff_fft_permute", "ff_fft_calc",
     "ff_mdct_init", "ff_mdct_end", "ff_imdct_half", "ff_imdct_calc",
@@ -113,8 +114,30 @@ EXPORTED = [
 ]
 
 
+# heaac_dsp.h: first rule a record breaks
+BAD_RULES = ["NONE", "HDR_INDEX", "HDR_RANGE", "HDR_COUNTS", "HDR_TABLE", "HDR_MAP", "HDR_FLAGS", "HDR_UNSTARTED",
+             "SBR_NUM_ENV", "SBR_T_ENV", "SBR_T_Q", "SBR_FLAGS", "SBR_OLD_RANGE",
+             "PS_NUM_ENV", "PS_BORDER", "PS_NR_PAR", "PS_PAR"]
+
+
 class HeaacError(RuntimeError):
     pass
+
+
+def validate_frame(cfg, sbr, hdr, ps=None):
+    """Host-side record check of ONE frame (numpy records): returns the name of the first rule broken,
+    "NONE" if the frame is valid."""
+    sbr = np.ascontiguousarray(sbr, dtype=SBR_FRAME_DT).reshape(-1)[:1]
+    hdr = np.ascontiguousarray(hdr, dtype=SBR_HDR_DT).reshape(-1)
+    p = None
+    if ps is not None:
+        ps = np.ascontiguousarray(ps, dtype=PS_FRAME_DT).reshape(-1)[:1]
+        p = ps.ctypes.data_as(C.c_void_p)
+    r = lib().heaac_validate_frame(C.c_int(cfg), sbr.ctypes.data_as(C.c_void_p), hdr.ctypes.data_as(C.c_void_p),
+                                   C.c_size_t(hdr.shape[0]), p)
+    if r < 0:
+        raise HeaacError("heaac_validate_frame: bad call")
+    return BAD_RULES[r]
 
 
 _lib = None
@@ -256,6 +279,24 @@ class Device:
         return coeffs
 
     # -- HE-AAC --
+    def he_check(self, cfg, sbr, hdr, ps=None):
+        """heaac_he_check_batch on device-resident records (byte tensors as he_decode takes them):
+        returns None if every frame is valid, else (first bad frame index, rule name)."""
+        import torch
+        n = sbr.numel() // SBR_FRAME_DT.itemsize
+        first, rule = C.c_size_t(0), C.c_int(0)
+        rc = lib().heaac_he_check_batch(self._h, C.c_int(cfg), C.c_void_p(sbr.data_ptr()), C.c_void_p(hdr.data_ptr()),
+                                        C.c_size_t(hdr.numel() // SBR_HDR_DT.itemsize),
+                                        C.c_void_p(ps.data_ptr()) if ps is not None else None, C.c_size_t(n),
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(first), C.byref(rule))
+        if rc == 0:
+            return None
+        if rc != -1:
+            _check(rc, "heaac_he_check_batch")
+        if first.value == C.c_size_t(-1).value:
+            raise HeaacError("heaac_he_check_batch: bad arguments")
+        return int(first.value), BAD_RULES[rule.value] if 0 <= rule.value < len(BAD_RULES) else str(rule.value)
+
     def he_decode(self, cfg, coeffs, ics, sbr, hdr, ps, state_in, state_out=None, pcm=None,
                   pcm_format=PCM_F32):
         import torch

@@ -234,7 +234,7 @@ extern "C" int heaac_he_decode_batch(HeaacDevice *dev, int cfg,
         float *ws_X = ws_W + dev->chunk * WS_W_FLOATS;
         rc = heaac_launch_he(dev->d_tab, dev->d_rev, cfg,
                              d_coeffs + f0 * ncore * 1024, d_ics + f0 * ncore,
-                             d_sbr + f0, d_hdr, d_ps ? d_ps + f0 : NULL,
+                             d_sbr + f0, d_hdr, (unsigned)(n_hdr > 0xffffu ? 0x10000u : n_hdr), d_ps ? d_ps + f0 : NULL,
                              d_state_in + f0 * words, d_state_out + f0 * words,
                              (char *)d_pcm + f0 * pcm_bytes, pcm_format,
                              ws_W, ws_X, dev->d_queue + 16 * k, nc, 0, lanes ? dev->lane[k] : s);

@@ -244,7 +244,7 @@ void k_core_ana(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_
 
 __global__ __launch_bounds__(HF_WAVES * WAVE)
 void k_hfadj(const float *__restrict__ g_tab,
-             const HeaacSbrFrame *__restrict__ g_sbr, const HeaacSbrHeader *__restrict__ g_hdr,
+             const HeaacSbrFrame *__restrict__ g_sbr, const HeaacSbrHeader *__restrict__ g_hdr, unsigned n_hdr,
              const float *g_W, const float *g_state_in, float *g_state_out, int state_words,
              int ncore, int off_sbr0, float *g_X, unsigned long long n_units, unsigned *g_queue)
 {
@@ -267,7 +267,7 @@ void k_hfadj(const float *__restrict__ g_tab,
         const int ch = (int)(u - f * ncore);
         const int off = off_sbr0 + ch * HEAAC_ST_SBR;
         float *X0 = g_X + (f * 2 + ch) * (2 * 38 * 64), *X1 = X0 + 38 * 64;
-        hf_channel(S, s_noise, &g_sbr[f], g_hdr, ch, g_W + u * 2048,
+        hf_channel(S, s_noise, &g_sbr[f], g_hdr, n_hdr, ch, g_W + u * 2048,
                    g_state_in + f * state_words + off, g_state_out + f * state_words + off, lane,
                    [&](int i, float re, float im) { X0[i * 64 + lane] = re; X1[i * 64 + lane] = im; });
       }
@@ -656,7 +656,7 @@ static bool he_fused()
 
 extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cfg,
                                const float *d_coeffs, const HeaacIcs *d_ics,
-                               const HeaacSbrFrame *d_sbr, const HeaacSbrHeader *d_hdr,
+                               const HeaacSbrFrame *d_sbr, const HeaacSbrHeader *d_hdr, unsigned n_hdr,
                                const HeaacPsFrame *d_ps,
                                const float *d_state_in, float *d_state_out,
                                void *d_pcm, int pcm_format,
@@ -688,17 +688,17 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
         // HF adjustment + baseline PS in one kernel; the general PS kernel finishes the
         // frames with another PS layout (it skips the rest)
         const int off_ps = off_syn0 + 2 * HEAAC_ST_SYNTH;
-        int rc = heaac_launch_hfps(d_tab, d_sbr, d_hdr, d_ps, d_ws_W, d_state_in, d_state_out, words,
+        int rc = heaac_launch_hfps(d_tab, d_sbr, d_hdr, n_hdr, d_ps, d_ws_W, d_state_in, d_state_out, words,
                                    off_sbr0, off_ps, d_ws_X, n, d_queue, s);
         if (rc != HEAAC_OK) return rc;
-        rc = heaac_launch_ps(d_tab, d_ps, d_sbr, d_hdr, d_state_in, d_state_out, words, off_ps, d_ws_X, n, 2, s);
+        rc = heaac_launch_ps(d_tab, d_ps, d_sbr, d_hdr, n_hdr, d_state_in, d_state_out, words, off_ps, d_ws_X, n, 2, s);
         if (rc != HEAAC_OK) return rc;
     } else {
         hipLaunchKernelGGL(k_hfadj, dim3(he_grid((units + 1) / 2, HF_WAVES)), dim3(HF_WAVES * WAVE), 0, s,
-                           d_tab, d_sbr, d_hdr, d_ws_W, d_state_in, d_state_out, words, ncore, off_sbr0,
+                           d_tab, d_sbr, d_hdr, n_hdr, d_ws_W, d_state_in, d_state_out, words, ncore, off_sbr0,
                            d_ws_X, units, d_queue + 1);
         if (cfg == HEAAC_CFG_HEV2) {
-            int rc = heaac_launch_ps(d_tab, d_ps, d_sbr, d_hdr, d_state_in, d_state_out, words,
+            int rc = heaac_launch_ps(d_tab, d_ps, d_sbr, d_hdr, n_hdr, d_state_in, d_state_out, words,
                                      off_syn0 + 2 * HEAAC_ST_SYNTH, d_ws_X, n, 3, s);
             if (rc != HEAAC_OK) return rc;
         }

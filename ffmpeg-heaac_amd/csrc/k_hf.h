@@ -144,7 +144,7 @@ __device__ __forceinline__ v2f xhigh3_pk(v2f x2, v2f x1, v2f x0, const float *a)
 // loaded for its later stages beside them, in the same wait).
 template <class Emit, class Hook = NoHook>
 __device__ __forceinline__ void hf_channel(const HfWave &w, const float *g_noise /* LDS */,
-                                           const HeaacSbrFrame *g_fr, const HeaacSbrHeader *g_hdr,
+                                           const HeaacSbrFrame *g_fr, const HeaacSbrHeader *g_hdr, unsigned n_hdr,
                                            int ch, const float *g_W,
                                            const float *st_in, float *st_out, int lane_in, Emit emit,
                                            Hook after_params = Hook())
@@ -154,7 +154,8 @@ __device__ __forceinline__ void hf_channel(const HfWave &w, const float *g_noise
     const int lane = opaque(lane_in);
     HSTAMP(0);
     // ---- issue every global load up front: parameters, W, state ----
-    const int hdr_idx = g_fr->hdr;
+    // (clamped: an index past the table must not become an address -- heaac_dsp.h, record validation)
+    const int hdr_idx = g_fr->hdr < n_hdr ? g_fr->hdr : n_hdr - 1;
     // channel records (2 x 336 B = 168 dwords) and the header (532 B = 133 dwords):
     // all loads issued before any LDS store
     uint32_t creg[3], hreg[3];

@@ -19,7 +19,7 @@
 template <bool GENERAL, int WAVES>
 __global__ __launch_bounds__(WAVES * WAVE)
 void k_ps(const float *__restrict__ g_tab, const HeaacPsFrame *__restrict__ g_ps,
-          const HeaacSbrFrame *__restrict__ g_sbr, const HeaacSbrHeader *__restrict__ g_hdr,
+          const HeaacSbrFrame *__restrict__ g_sbr, const HeaacSbrHeader *__restrict__ g_hdr, unsigned n_hdr,
           const float *g_state_in, float *g_state_out, int state_words, int off_ps,
           float *g_X, unsigned long long n)
 {
@@ -52,7 +52,8 @@ void k_ps(const float *__restrict__ g_tab, const HeaacPsFrame *__restrict__ g_ps
             const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
             todo &= todo - 1;
             const unsigned long long f = base + (unsigned long long)j * nw;
-            const HeaacSbrHeader &h = g_hdr[g_sbr[f].hdr];
+            const unsigned hi = g_sbr[f].hdr;
+            const HeaacSbrHeader &h = g_hdr[hi < n_hdr ? hi : n_hdr - 1];
             const int top = h.kx + h.m;             // ff_ps_apply(..., sbr->kx[1] + sbr->m[1])
             float *XL = g_X + (f * 2) * (2 * 38 * 64);
             ps_frame<GENERAL>(W, g_tab, &g_ps[f], top, g_state_in + f * state_words + off_ps,
@@ -74,7 +75,7 @@ void k_ps(const float *__restrict__ g_tab, const HeaacPsFrame *__restrict__ g_ps
 
 __global__ __launch_bounds__(HFPS_WAVES * WAVE)
 void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g_sbr,
-            const HeaacSbrHeader *__restrict__ g_hdr, const HeaacPsFrame *__restrict__ g_ps,
+            const HeaacSbrHeader *__restrict__ g_hdr, unsigned n_hdr, const HeaacPsFrame *__restrict__ g_ps,
             const float *g_W, const float *g_state_in, float *g_state_out, int state_words,
             int off_sbr, int off_ps, float *g_X, unsigned long long n, unsigned *g_queue)
 {
@@ -149,7 +150,7 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
                 hist_im = st_in[off_ps + HEAAC_PS_INBUF + 2 * lane + 1];
             }
         }
-        hf_channel(H, s_noise, &g_sbr[f], g_hdr, 0, g_W + f * 2048, st_in + off_sbr, st_out + off_sbr, lane,
+        hf_channel(H, s_noise, &g_sbr[f], g_hdr, n_hdr, 0, g_W + f * 2048, st_in + off_sbr, st_out + off_sbr, lane,
                    [&](int i, float re, float im) {
                        if (i < 32) {
                            col[i] = v2f{re, im};
@@ -188,7 +189,7 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
 
 // variants: bit 0 = baseline kernel, bit 1 = general kernel
 extern "C" int heaac_launch_ps(const float *d_tab, const HeaacPsFrame *d_ps, const HeaacSbrFrame *d_sbr,
-                               const HeaacSbrHeader *d_hdr, const float *d_state_in, float *d_state_out,
+                               const HeaacSbrHeader *d_hdr, unsigned n_hdr, const float *d_state_in, float *d_state_out,
                                int state_words, int off_ps, float *d_ws_X, size_t n, int variants,
                                hipStream_t s)
 {
@@ -197,20 +198,20 @@ extern "C" int heaac_launch_ps(const float *d_tab, const HeaacPsFrame *d_ps, con
     if (g > 256) g = 256;
     if (variants & 1)
         hipLaunchKernelGGL((k_ps<false, PS_WAVES_20>), dim3((unsigned)g), dim3(PS_WAVES_20 * WAVE), 0, s, d_tab,
-                           d_ps, d_sbr, d_hdr, d_state_in, d_state_out, state_words, off_ps, d_ws_X,
+                           d_ps, d_sbr, d_hdr, n_hdr, d_state_in, d_state_out, state_words, off_ps, d_ws_X,
                            (unsigned long long)n);
     g = (n + PS_WAVES_GEN - 1) / PS_WAVES_GEN;
     if (g > 256) g = 256;
     if (variants & 2)
         hipLaunchKernelGGL((k_ps<true, PS_WAVES_GEN>), dim3((unsigned)g), dim3(PS_WAVES_GEN * WAVE), 0, s, d_tab,
-                           d_ps, d_sbr, d_hdr, d_state_in, d_state_out, state_words, off_ps, d_ws_X,
+                           d_ps, d_sbr, d_hdr, n_hdr, d_state_in, d_state_out, state_words, off_ps, d_ws_X,
                            (unsigned long long)n);
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
 }
 
 // HF adjustment of the mono core channel fused with baseline Parametric Stereo
 extern "C" int heaac_launch_hfps(const float *d_tab, const HeaacSbrFrame *d_sbr, const HeaacSbrHeader *d_hdr,
-                                 const HeaacPsFrame *d_ps, const float *d_ws_W,
+                                 unsigned n_hdr, const HeaacPsFrame *d_ps, const float *d_ws_W,
                                  const float *d_state_in, float *d_state_out, int state_words,
                                  int off_sbr, int off_ps, float *d_ws_X, size_t n, unsigned *d_queue,
                                  hipStream_t s)
@@ -218,7 +219,7 @@ extern "C" int heaac_launch_hfps(const float *d_tab, const HeaacSbrFrame *d_sbr,
     if (!n) return HEAAC_OK;
     unsigned long long g = (n + HFPS_WAVES - 1) / HFPS_WAVES;
     if (g > 256) g = 256;
-    hipLaunchKernelGGL(k_hfps, dim3((unsigned)g), dim3(HFPS_WAVES * WAVE), 0, s, d_tab, d_sbr, d_hdr, d_ps,
+    hipLaunchKernelGGL(k_hfps, dim3((unsigned)g), dim3(HFPS_WAVES * WAVE), 0, s, d_tab, d_sbr, d_hdr, n_hdr, d_ps,
                        d_ws_W, d_state_in, d_state_out, state_words, off_sbr, off_ps, d_ws_X,
                        (unsigned long long)n, d_queue);
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;

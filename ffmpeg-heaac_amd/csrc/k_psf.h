@@ -613,8 +613,11 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
 #pragma unroll
         for (int e = 0; e < 5; e++) {
             const int ee = e < p.num_env ? e : 0;
-            const float4 h4 = *reinterpret_cast<const float4 *>(
-                LUT + ((w.iid_m[ee][b] + 7 + 23 * p.iid_quant) * 8 + w.icc_m[ee][b]) * 4);
+            // (row and column clamped to the table: heaac_dsp.h, record validation)
+            int row = w.iid_m[ee][b] + 7 + 23 * (p.iid_quant ? 1 : 0), colx = w.icc_m[ee][b];
+            row = row < 0 ? 0 : row > 45 ? 45 : row;
+            colx = colx < 0 ? 0 : colx > 7 ? 7 : colx;
+            const float4 h4 = *reinterpret_cast<const float4 *>(LUT + (row * 8 + colx) * 4);
             hl[e][0] = h4.x; hl[e][1] = h4.y; hl[e][2] = h4.z; hl[e][3] = h4.w;
         }
     }
@@ -755,8 +758,8 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
             float h11 = hl[e][0], h12 = hl[e][1], h21 = hl[e][2], h22 = hl[e][3];
             float h11i = 0.0f, h12i = 0.0f, h21i = 0.0f, h22i = 0.0f;
             if (GENERAL && p.enable_ipdopd && b < p.nr_ipdopd_par) {
-                const int opd_idx = opd_hist * 8 + w.opd_m[e][b];
-                const int ipd_idx = ipd_hist * 8 + w.ipd_m[e][b];
+                const int opd_idx = (opd_hist * 8 + w.opd_m[e][b]) & 511;      // (& 511: no-op on valid indices)
+                const int ipd_idx = (ipd_hist * 8 + w.ipd_m[e][b]) & 511;
                 const float opd_re = g_tab[TB_PD_RE + opd_idx], opd_im = g_tab[TB_PD_IM + opd_idx];
                 const float ipd_re = g_tab[TB_PD_RE + ipd_idx], ipd_im = g_tab[TB_PD_IM + ipd_idx];
                 opd_hist = opd_idx & 0x3F;

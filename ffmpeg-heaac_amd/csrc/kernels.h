@@ -19,7 +19,7 @@ int heaac_launch_imdct_half(const float *d_tab, const uint16_t *d_rev, int which
 extern "C" {
 int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cfg,
                     const float *d_coeffs, const HeaacIcs *d_ics,
-                    const HeaacSbrFrame *d_sbr, const HeaacSbrHeader *d_hdr,
+                    const HeaacSbrFrame *d_sbr, const HeaacSbrHeader *d_hdr, unsigned n_hdr,
                     const HeaacPsFrame *d_ps,
                     const float *d_state_in, float *d_state_out,
                     void *d_pcm, int pcm_format,
@@ -27,11 +27,11 @@ int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cfg,
                     size_t n, size_t pcm_frame0, hipStream_t s);
 
 int heaac_launch_ps(const float *d_tab, const HeaacPsFrame *d_ps, const HeaacSbrFrame *d_sbr,
-                    const HeaacSbrHeader *d_hdr, const float *d_state_in, float *d_state_out,
+                    const HeaacSbrHeader *d_hdr, unsigned n_hdr, const float *d_state_in, float *d_state_out,
                     int state_words, int off_ps, float *d_ws_X, size_t n, int variants, hipStream_t s);
 
 int heaac_launch_hfps(const float *d_tab, const HeaacSbrFrame *d_sbr, const HeaacSbrHeader *d_hdr,
-                      const HeaacPsFrame *d_ps, const float *d_ws_W,
+                      unsigned n_hdr, const HeaacPsFrame *d_ps, const float *d_ws_W,
                       const float *d_state_in, float *d_state_out, int state_words,
                       int off_sbr, int off_ps, float *d_ws_X, size_t n, unsigned *d_queue, hipStream_t s);
 

@@ -13,6 +13,7 @@
 #include "heaac_codec.h"
 #include "tables.h"
 #include "kernels.h"
+#include "validate.h"
 
 // capi.hip
 extern "C" const float *heaac_device_tables(HeaacDevice *dev, const uint16_t **rev);
@@ -311,12 +312,16 @@ static int dec_frame(HeaacCodecContext *avctx, void *data, int *data_size, Heaac
     if (hp.flags & HEAAC_PKT_NEW_SBR_HEADER) {
         need += sizeof(HeaacSbrHeader);
         if ((size_t)avpkt->size < need || !he || sbr.hdr >= MAX_HDRS) return -1;
-        memcpy(&p->hdr[sbr.hdr], q, sizeof(HeaacSbrHeader));
-        if (p->hdr[sbr.hdr].m > 48) return -1;
+        HeaacSbrHeader nh;
+        memcpy(&nh, q, sizeof(nh));
+        if (heaac_check_sbr_header(&nh)) return -1;          // validate before it reaches the device table
+        p->hdr[sbr.hdr] = nh;
         if (hipMemcpy(p->d_hdr + sbr.hdr, &p->hdr[sbr.hdr], sizeof(HeaacSbrHeader),
                       hipMemcpyHostToDevice) != hipSuccess) return -1;
     }
     if (he && sbr.hdr >= MAX_HDRS) return -1;
+    // one frame: the host check is free (the reference rejects these while parsing, aacsbr.c:609-745)
+    if (he && heaac_validate_frame(p->cfg, &sbr, p->hdr, MAX_HDRS, p->cfg == HEAAC_CFG_HEV2 ? &ps : NULL)) return -1;
 
     uint8_t *d_ics = p->d_side, *d_sbr = p->d_side + 16, *d_ps = p->d_side + 16 + 688;
     if (hipMemcpy(p->d_coeffs, coeffs, (size_t)p->ncore * 4096, hipMemcpyHostToDevice) != hipSuccess ||

@@ -285,6 +285,45 @@ int heaac_he_decode_batch(HeaacDevice *dev, int cfg,
                           void *d_pcm, int pcm_format,
                           size_t n, void *stream);
 
+/* Record validation.  The bitstream parsers live outside this library, so the per-frame records are
+ * where malformed data would arrive; the rules are the reference parser's own rejections
+ * (read_sbr_grid aacsbr.c:609-745, sbr_make_f_master / sbr_make_f_derived :296-593, ff_ps_read_data
+ * aacps.c:150-279) plus the bounds the kernels index with.  heaac_he_decode_batch does NOT validate:
+ * it clamps what forms a global address (a bad record gives wrong audio for that frame, never a
+ * fault), and expects untrusted input to have passed one of these first. */
+/* first rule a record breaks (0 = valid) */
+enum {
+    HEAAC_BAD_NONE = 0,
+    HEAAC_BAD_HDR_INDEX,        /* frame.hdr >= n_hdr                                        */
+    HEAAC_BAD_HDR_RANGE,        /* kx > 32, m > 48, kx + m > 64, k0 > 32 (aacsbr.c:499-507)   */
+    HEAAC_BAD_HDR_COUNTS,       /* n[0] > 24, n[1] > 48, n_q > 5, n_lim > 29, patches > 5     */
+    HEAAC_BAD_HDR_TABLE,        /* a frequency table is not increasing from kx to kx + m      */
+    HEAAC_BAD_HDR_MAP,          /* a per-band lookup points outside its table                 */
+    HEAAC_BAD_HDR_FLAGS,
+    HEAAC_BAD_HDR_UNSTARTED,    /* start = 1 on a header without SBR range (m = 0)            */
+    HEAAC_BAD_SBR_NUM_ENV,      /* bs_num_env not in 1..5, bs_num_noise not in 1..2 (:627, :684) */
+    HEAAC_BAD_SBR_T_ENV,        /* borders not increasing, t_env[L] > 19, or > 16 + 3 slots   */
+    HEAAC_BAD_SBR_T_Q,          /* noise borders not borders of the envelope grid             */
+    HEAAC_BAD_SBR_FLAGS,        /* freq_res / amp_res / invf_mode / e_a / coupling out of range */
+    HEAAC_BAD_SBR_OLD_RANGE,    /* kx_old > 32 or kx_old + m_old > 64, t_env_num_env_old > 19 */
+    HEAAC_BAD_PS_NUM_ENV,       /* num_env not in 1..5 (0 only as num_env_old)                */
+    HEAAC_BAD_PS_BORDER,        /* border[0] != -1, not increasing, last != 31                */
+    HEAAC_BAD_PS_NR_PAR,        /* nr_*_par outside {10, 20, 34} / {5, 11, 17}, modes > 5     */
+    HEAAC_BAD_PS_PAR,           /* |iid| > 7 + 8 quant, icc not in 0..7, ipd / opd not in 0..7 */
+};
+
+
+/* One frame's records on the host: 0 if valid, else the HEAAC_BAD_* rule broken first (-1: bad call). */
+int heaac_validate_frame(int cfg, const HeaacSbrFrame *sbr, const HeaacSbrHeader *hdr, size_t n_hdr,
+                         const HeaacPsFrame *ps);
+
+/* A batch of device-resident records (the arguments of heaac_he_decode_batch).  Returns HEAAC_OK, or
+ * HEAAC_ERR_ARG with *first_bad = lowest failing frame index and *rule = its HEAAC_BAD_* code (either
+ * pointer may be NULL).  Synchronises `stream`. */
+int heaac_he_check_batch(HeaacDevice *dev, int cfg, const HeaacSbrFrame *d_sbr,
+                         const HeaacSbrHeader *d_hdr, size_t n_hdr, const HeaacPsFrame *d_ps,
+                         size_t n, void *stream, size_t *first_bad, int *rule);
+
 /* Stage-level entry points (same kernels, exposed for parity tests and for
  * hosts that keep part of the pipeline themselves). */
 
