@@ -108,7 +108,8 @@ EXPORTED = [
     "ff_fft_init", "ff_fft_end", "ff_fft_permute", "ff_fft_calc",
     "ff_mdct_init", "ff_mdct_end", "ff_imdct_half", "ff_imdct_calc",
     "ff_kbd_window_init", "ff_sine_window_init", "ff_init_ff_sine_windows", "ff_sine_windows",
-    "av_mdct_init", "av_imdct_half", "av_imdct_calc", "av_mdct_end",
+    "av_mdct_init", "av_imdct_half", "av_imdct_calc", "av_mdct_calc", "av_mdct_end",
+    "av_fft_init", "av_fft_permute", "av_fft_calc", "av_fft_end",
     # heaac_codec.h
     "heaac_aac_decoder", "heaac_codec_open", "heaac_codec_decode", "heaac_codec_close",
 ]
@@ -301,9 +302,19 @@ class Device:
                   pcm_format=PCM_F32):
         import torch
         n = coeffs.shape[0]
-        assert state_in.numel() == n * STATE_WORDS[cfg]
+        # a wrong-length tensor would be a silent device out-of-bounds read: check them all here
+        assert coeffs.dtype == torch.float32 and coeffs.numel() == n * CORE_CH[cfg] * 1024, "coeffs"
+        assert state_in.dtype == torch.float32 and state_in.numel() == n * STATE_WORDS[cfg], "state_in"
+        assert ics.numel() * ics.element_size() == n * CORE_CH[cfg] * ICS_DT.itemsize, "ics"
+        assert sbr.numel() * sbr.element_size() == n * SBR_FRAME_DT.itemsize, "sbr"
+        assert hdr.numel() * hdr.element_size() >= SBR_HDR_DT.itemsize and \
+            (hdr.numel() * hdr.element_size()) % SBR_HDR_DT.itemsize == 0, "hdr"
+        if cfg == CFG_HEV2:
+            assert ps is not None and ps.numel() * ps.element_size() == n * PS_FRAME_DT.itemsize, "ps"
         if state_out is None:
             state_out = torch.empty_like(state_in)
+        else:
+            assert state_out.dtype == torch.float32 and state_out.numel() == state_in.numel(), "state_out"
         if pcm is None:
             if pcm_format == PCM_F32:
                 pcm = torch.empty((n, OUT_CH[cfg], 2048), dtype=torch.float32, device=coeffs.device)

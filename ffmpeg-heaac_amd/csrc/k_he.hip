@@ -448,7 +448,7 @@ template <int FMT>
 __global__ __launch_bounds__(SYN_WAVES_F32 * WAVE)
 void k_synth(const float *__restrict__ g_tab, const float *g_X,
              const float *g_state_in, float *g_state_out, int state_words, int off_syn0,
-             int nout, int copy_mono, void *__restrict__ g_pcm, float scale, float bias,
+             int nout, void *__restrict__ g_pcm, float scale, float bias,
              unsigned long long n_frames, unsigned long long pcm_frame0, unsigned *g_queue)
 {
     constexpr int NW = SYN_WAVES_F32;
@@ -683,7 +683,6 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
     hipLaunchKernelGGL(k_core_ana, dim3(he_grid((units + 1) / 2, CA_WAVES)), dim3(CA_WAVES * WAVE), 0, s,
                        d_tab, d_rev, d_coeffs, d_ics, d_state_in, d_state_out, words, ncore,
                        off_saved0, off_sbr0, d_ws_W, 1 / (-1024 * sf_scale), units);
-    int copy_mono = 0;
     if (cfg == HEAAC_CFG_HEV2 && he_fused()) {
         // HF adjustment + baseline PS in one kernel; the general PS kernel finishes the
         // frames with another PS layout (it skips the rest)
@@ -707,11 +706,11 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
     const dim3 g(he_grid(n, SYN_WAVES_F32)), b(SYN_WAVES_F32 * WAVE);
     if (pcm_format == HEAAC_PCM_F32_PLANAR)
         hipLaunchKernelGGL((k_synth<HEAAC_PCM_F32_PLANAR>), g, b, 0, s, d_tab, d_ws_X, d_state_in, d_state_out,
-                           words, off_syn0, nout, copy_mono, d_pcm, scale, bias,
+                           words, off_syn0, nout, d_pcm, scale, bias,
                            (unsigned long long)n, (unsigned long long)pcm_frame0, d_queue + 2);
     else if (pcm_format == HEAAC_PCM_S16_INTERLEAVED)
         hipLaunchKernelGGL((k_synth<HEAAC_PCM_S16_INTERLEAVED>), g, b, 0, s, d_tab, d_ws_X, d_state_in, d_state_out,
-                           words, off_syn0, nout, copy_mono, d_pcm, scale, bias,
+                           words, off_syn0, nout, d_pcm, scale, bias,
                            (unsigned long long)n, (unsigned long long)pcm_frame0, d_queue + 2);
     else
         return HEAAC_ERR_ARG;

@@ -18,19 +18,10 @@
 // capi.hip
 extern "C" const float *heaac_device_tables(HeaacDevice *dev, const uint16_t **rev);
 
-static HeaacDevice *g_dev;
+#include <pthread.h>
 
-static HeaacDevice *default_device(void)
-{
-    if (!g_dev) {
-        const int rc = heaac_device_create(&g_dev, 64);
-        if (rc != HEAAC_OK) {
-            fprintf(stderr, "heaac: cannot create device context: %s\n", heaac_strerror(rc));
-            g_dev = NULL;
-        }
-    }
-    return g_dev;
-}
+static HeaacDevice *g_dev;
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;     // g_dev and the side-record list
 
 static void die(const char *what)
 {
@@ -40,22 +31,84 @@ static void die(const char *what)
 
 #define HIPCHK(x, what) do { if ((x) != hipSuccess) die(what); } while (0)
 
+static HeaacDevice *default_device(void)
+{
+    pthread_mutex_lock(&g_lock);
+    if (!g_dev) {
+        const int rc = heaac_device_create(&g_dev, 64);
+        if (rc != HEAAC_OK) {
+            fprintf(stderr, "heaac: cannot create device context: %s\n", heaac_strerror(rc));
+            g_dev = NULL;
+        }
+    }
+    HeaacDevice *d = g_dev;
+    pthread_mutex_unlock(&g_lock);
+    return d;
+}
+
 // ---------------------------------------------------------------------------
 // FFTContext surface
 // ---------------------------------------------------------------------------
+// struct FFTContext has no field for a backend's own data (fft.h:32-53), so each initialised
+// context has a side record, found through the table pointer the context owns (revtab: one heap block
+// per context, so the link also survives a by-value copy of the struct): which transform instance it is
+// and the device buffers its calls reuse.
+struct FftSide {
+    const void *key;              // s->revtab
+    int which;                    // MDCT instance 0..3 (heaac_dsp.h), -1 = plain FFT
+    float *d_in, *d_out;          // device staging, sized for the transform
+    FftSide *next;
+};
+static FftSide *g_sides;
+
+static FftSide *side_of(const FFTContext *s)
+{
+    pthread_mutex_lock(&g_lock);
+    FftSide *p = g_sides;
+    while (p && p->key != s->revtab) p = p->next;
+    pthread_mutex_unlock(&g_lock);
+    return p;
+}
+
+static FftSide *side_add(const FFTContext *s, size_t in_bytes, size_t out_bytes)
+{
+    FftSide *p = (FftSide *)calloc(1, sizeof(*p));
+    if (!p) return NULL;
+    p->key = s->revtab;
+    p->which = -1;
+    if (hipMalloc((void **)&p->d_in, in_bytes) != hipSuccess ||
+        (out_bytes && hipMalloc((void **)&p->d_out, out_bytes) != hipSuccess)) {
+        if (p->d_in) (void)hipFree(p->d_in);
+        free(p);
+        return NULL;
+    }
+    pthread_mutex_lock(&g_lock);
+    p->next = g_sides;
+    g_sides = p;
+    pthread_mutex_unlock(&g_lock);
+    return p;
+}
+
+static void side_drop(const FFTContext *s)
+{
+    if (!s->revtab) return;
+    pthread_mutex_lock(&g_lock);
+    FftSide **pp = &g_sides;
+    while (*pp && (*pp)->key != s->revtab) pp = &(*pp)->next;
+    FftSide *p = *pp;
+    if (p) *pp = p->next;
+    pthread_mutex_unlock(&g_lock);
+    if (p) {
+        if (p->d_in) (void)hipFree(p->d_in);
+        if (p->d_out) (void)hipFree(p->d_out);
+        free(p);
+    }
+}
+
 static void *aligned16(size_t bytes)
 {
     void *p = NULL;                     // av_malloc: 16-byte aligned (libavutil/mem.c:83)
     return posix_memalign(&p, 16, bytes ? bytes : 16) == 0 ? p : NULL;
-}
-
-static int mdct_which(const FFTContext *s)
-{
-    // recover the instance from the tables ff_mdct_init built
-    if (s->mdct_bits == 11) return 0;
-    if (s->mdct_bits == 8)  return 1;
-    if (s->mdct_bits == 7)  return (s->exptab1 != NULL) ? 3 : 2;   // see ff_mdct_init
-    return -1;
 }
 
 static void hip_fft_permute(FFTContext *s, FFTComplex *z)
@@ -69,32 +122,26 @@ static void hip_fft_permute(FFTContext *s, FFTComplex *z)
 static void hip_fft_calc(FFTContext *s, FFTComplex *z)
 {
     HeaacDevice *dev = default_device();
-    if (!dev) die("ff_fft_calc");
+    FftSide *sd = side_of(s);
+    if (!dev || !sd) die("ff_fft_calc");
     const size_t bytes = sizeof(FFTComplex) << s->nbits;
-    float *d = NULL;
-    HIPCHK(hipMalloc((void **)&d, bytes), "hipMalloc");
-    HIPCHK(hipMemcpy(d, z, bytes, hipMemcpyHostToDevice), "hipMemcpy");
-    if (heaac_launch_fft_calc(heaac_device_tables(dev, NULL), s->nbits, d, 1, 0) != HEAAC_OK) die("ff_fft_calc");
-    HIPCHK(hipMemcpy(z, d, bytes, hipMemcpyDeviceToHost), "hipMemcpy");
-    (void)hipFree(d);
+    HIPCHK(hipMemcpy(sd->d_in, z, bytes, hipMemcpyHostToDevice), "hipMemcpy");
+    if (heaac_launch_fft_calc(heaac_device_tables(dev, NULL), s->nbits, sd->d_in, 1, 0) != HEAAC_OK) die("ff_fft_calc");
+    HIPCHK(hipMemcpy(z, sd->d_in, bytes, hipMemcpyDeviceToHost), "hipMemcpy");
 }
 
 static void hip_imdct(FFTContext *s, FFTSample *output, const FFTSample *input, int full)
 {
     HeaacDevice *dev = default_device();
-    const int which = mdct_which(s);
-    if (!dev || which < 0) die("ff_imdct_half");
+    FftSide *sd = side_of(s);
+    if (!dev || !sd || sd->which < 0) die("ff_imdct_half");
     const int n = 1 << s->mdct_bits, n2 = n >> 1, n4 = n >> 2;
-    float *d_in = NULL, *d_out = NULL;
-    HIPCHK(hipMalloc((void **)&d_in, n2 * sizeof(float)), "hipMalloc");
-    HIPCHK(hipMalloc((void **)&d_out, n * sizeof(float)), "hipMalloc");
-    HIPCHK(hipMemcpy(d_in, input, n2 * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy");
-    if (heaac_imdct_half_batch(dev, which, full ? d_out + n4 : d_out, d_in, 1, NULL) != HEAAC_OK)
+    // the FFT staging block (n/4 complex = n2 floats) takes the input, d_out the n outputs
+    HIPCHK(hipMemcpy(sd->d_in, input, n2 * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy");
+    if (heaac_imdct_half_batch(dev, sd->which, full ? sd->d_out + n4 : sd->d_out, sd->d_in, 1, NULL) != HEAAC_OK)
         die("ff_imdct_half");
-    if (full && heaac_launch_imdct_mirror(d_out, n, 1, 0) != HEAAC_OK) die("ff_imdct_calc");
-    HIPCHK(hipMemcpy(output, d_out, (full ? n : n2) * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy");
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
+    if (full && heaac_launch_imdct_mirror(sd->d_out, n, 1, 0) != HEAAC_OK) die("ff_imdct_calc");
+    HIPCHK(hipMemcpy(output, sd->d_out, (full ? n : n2) * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy");
 }
 
 static void hip_imdct_half(FFTContext *s, FFTSample *o, const FFTSample *i) { hip_imdct(s, o, i, 0); }
@@ -134,12 +181,16 @@ extern "C" int ff_fft_init(FFTContext *s, int nbits, int inverse)
     s->imdct_half  = hip_imdct_half;
     s->mdct_calc   = hip_mdct_calc;
     s->split_radix = 1;
+    // device staging reused by every call on this context: n complex in place for the FFT;
+    // an MDCT over it (n4 = this n) needs 2 n floats in and 4 n floats out
+    if (!side_add(s, (size_t)n * sizeof(FFTComplex), (size_t)n * 4 * sizeof(float))) { ff_fft_end(s); return -1; }
     return 0;
 }
 
 extern "C" void ff_fft_end(FFTContext *s)
 {
     if (!s) return;
+    side_drop(s);
     free(s->revtab);  s->revtab = NULL;
     free(s->tmp_buf); s->tmp_buf = NULL;
     s->exptab = NULL; s->exptab1 = NULL;
@@ -173,9 +224,9 @@ extern "C" int ff_mdct_init(FFTContext *s, int nbits, int inverse, double scale)
     const int off = which == 0 ? TB_ROT2048 : which == 1 ? TB_ROT256 : which == 2 ? TB_ROT128S : TB_ROT128A;
     memcpy(s->tcos, t->f + off, n / 2 * sizeof(float));
     free(t);
-    // The two N = 128 instances differ only in their tables; tag the analysis
-    // one through the (otherwise unused, SSE-only) exptab1 pointer.
-    s->exptab1 = which == 3 ? (FFTComplex *)s->tcos : NULL;
+    FftSide *sd = side_of(s);
+    if (!sd) { ff_mdct_end(s); return -1; }
+    sd->which = which;            // (the two N = 128 instances differ only in their tables)
     return 0;
 }
 
@@ -231,7 +282,21 @@ extern "C" FFTContext *av_mdct_init(int nbits, int inverse, double scale)
 }
 extern "C" void av_imdct_calc(FFTContext *s, FFTSample *o, const FFTSample *i) { s->imdct_calc(s, o, i); }
 extern "C" void av_imdct_half(FFTContext *s, FFTSample *o, const FFTSample *i) { s->imdct_half(s, o, i); }
+extern "C" void av_mdct_calc(FFTContext *s, FFTSample *o, const FFTSample *i) { s->mdct_calc(s, o, i); }
 extern "C" void av_mdct_end(FFTContext *s) { if (s) { ff_mdct_end(s); free(s); } }
+
+// avfft.c:25-51
+extern "C" FFTContext *av_fft_init(int nbits, int inverse)
+{
+    FFTContext *s = (FFTContext *)aligned16(sizeof(*s));
+    if (!s) return NULL;
+    memset(s, 0, sizeof(*s));
+    if (ff_fft_init(s, nbits, inverse) < 0) { free(s); return NULL; }   // (the reference returns a dead context here)
+    return s;
+}
+extern "C" void av_fft_permute(FFTContext *s, FFTComplex *z) { s->fft_permute(s, z); }
+extern "C" void av_fft_calc(FFTContext *s, FFTComplex *z) { s->fft_calc(s, z); }
+extern "C" void av_fft_end(FFTContext *s) { if (s) { ff_fft_end(s); free(s); } }
 
 // ---------------------------------------------------------------------------
 // AVCodec-shaped decoder
@@ -348,8 +413,13 @@ static int dec_frame(HeaacCodecContext *avctx, void *data, int *data_size, Heaac
     return (int)need;            // bytes consumed (aacdec.c:2102-2107)
 }
 
+// aacdec.c:2128-2142 (channel layouts: the two this path decodes)
+static const int dec_sample_fmts[] = { HEAAC_SAMPLE_FMT_S16, HEAAC_SAMPLE_FMT_NONE };
+static const int64_t dec_channel_layouts[] = { HEAAC_CH_LAYOUT_MONO, HEAAC_CH_LAYOUT_STEREO, 0 };
 extern "C" HeaacCodec heaac_aac_decoder = {
     "aac", 1, HEAAC_CODEC_ID_AAC, (int)sizeof(HeaacDecoderPriv), dec_init, NULL, dec_close, dec_frame,
+    0, NULL, NULL, NULL, NULL, "Advanced Audio Coding (HE-AAC DSP on gfx950)", NULL,
+    dec_sample_fmts, dec_channel_layouts,
 };
 
 extern "C" int heaac_codec_open(HeaacCodecContext *avctx, HeaacCodec *codec)

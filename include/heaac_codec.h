@@ -68,16 +68,32 @@ typedef struct HeaacCodecContext {
     void *priv_data;
 } HeaacCodecContext;
 
+/* Field for field `struct AVCodec` of libavcodec/avcodec.h:2675-2711 (same order, same types up to
+ * the names of the context / packet structs), so that the record can sit in libavcodec's codec list
+ * (register_avcodec, utils.c / allcodecs.c:218 REGISTER_ENCDEC) next to the built-in ones. */
 typedef struct HeaacCodec {
     const char *name;
-    int type;                     /* 1 = AVMEDIA_TYPE_AUDIO                  */
-    int id;
+    int type;                     /* enum AVMediaType: 1 = AVMEDIA_TYPE_AUDIO */
+    int id;                       /* enum CodecID                            */
     int priv_data_size;
     int (*init)(HeaacCodecContext *);
     int (*encode)(HeaacCodecContext *, uint8_t *buf, int buf_size, void *data);
     int (*close)(HeaacCodecContext *);
     int (*decode)(HeaacCodecContext *, void *outdata, int *outdata_size, HeaacPacket *avpkt);
+    int capabilities;             /* CODEC_CAP_*: none                       */
+    struct HeaacCodec *next;
+    void (*flush)(HeaacCodecContext *);
+    const void *supported_framerates;   /* const AVRational *: video only    */
+    const int *pix_fmts;                /* const enum PixelFormat *: video   */
+    const char *long_name;
+    const int *supported_samplerates;
+    const int *sample_fmts;             /* const enum SampleFormat *: {SAMPLE_FMT_S16, SAMPLE_FMT_NONE} */
+    const int64_t *channel_layouts;     /* {CH_LAYOUT_MONO, CH_LAYOUT_STEREO, 0} */
 } HeaacCodec;
+#define HEAAC_SAMPLE_FMT_NONE (-1)      /* avcodec.h:376-378 */
+#define HEAAC_SAMPLE_FMT_S16  1
+#define HEAAC_CH_LAYOUT_MONO   0x4      /* CH_FRONT_CENTER, avcodec.h:388, 413 */
+#define HEAAC_CH_LAYOUT_STEREO 0x3      /* CH_FRONT_LEFT | CH_FRONT_RIGHT, :386-387, 414 */
 
 extern HeaacCodec heaac_aac_decoder;
 

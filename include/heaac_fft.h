@@ -11,8 +11,11 @@
  *   ff_kbd_window_init                libavcodec/mdct.c:35-54
  *   ff_sine_window_init,
  *   ff_init_ff_sine_windows           libavcodec/mdct_tablegen.h:49-59
+ *   av_fft_init / av_fft_permute /
+ *   av_fft_calc / av_fft_end          libavcodec/avfft.h:35-49, avfft.c:25-51
  *   av_mdct_init / av_imdct_half /
- *   av_imdct_calc / av_mdct_end       libavcodec/avfft.c:55-90
+ *   av_imdct_calc / av_mdct_calc /
+ *   av_mdct_end                       libavcodec/avfft.h:51-55, avfft.c:55-90
  *
  * The reference lets per-arch code overwrite the function pointers in
  * ff_fft_init (fft.c:113-115: ff_fft_init_arm / _altivec / _mmx).  This build
@@ -84,9 +87,15 @@ void ff_sine_window_init(float *window, int n);
 void ff_init_ff_sine_windows(int index);
 extern float *const ff_sine_windows[13];   /* entries 7 (128) and 10 (1024) are backed */
 
+FFTContext *av_fft_init(int nbits, int inverse);
+void av_fft_permute(FFTContext *s, FFTComplex *z);
+void av_fft_calc(FFTContext *s, FFTComplex *z);
+void av_fft_end(FFTContext *s);
+
 FFTContext *av_mdct_init(int nbits, int inverse, double scale);
 void av_imdct_calc(FFTContext *s, FFTSample *output, const FFTSample *input);
 void av_imdct_half(FFTContext *s, FFTSample *output, const FFTSample *input);
+void av_mdct_calc(FFTContext *s, FFTSample *output, const FFTSample *input);   /* forward: not on the decode path, aborts */
 void av_mdct_end(FFTContext *s);
 
 #ifdef __cplusplus

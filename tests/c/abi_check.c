@@ -1,0 +1,197 @@
+/* abi_check.c -- the C ABI exercised from plain C (gcc), the way a host decoder would link it:
+ *   abi_check cpu   layouts, host-side entry points, loud failure without a device
+ *   abi_check gpu   transform plugin surface against O(N^2) double-precision references (the
+ *                   reference's own fft-test.c criterion: every |err| < 1e-3), av_fft_*, two N = 128
+ *                   MDCT contexts alive at once, the AVCodec-shaped decoder on AAC-LC packets
+ * Exit code 0 = all checks passed.  Test infrastructure: links the product only.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "heaac_dsp.h"
+#include "heaac_fft.h"
+#include "heaac_codec.h"
+
+static int fails;
+#define CHECK(c) do { if (!(c)) { printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); fails++; } } while (0)
+
+/* what struct AVCodec looks like on LP64 (avcodec.h:2675-2711) */
+struct ref_AVCodec {
+    const char *name; int type; int id; int priv_data_size;
+    int (*init)(void *); int (*encode)(void *, uint8_t *, int, void *); int (*close)(void *);
+    int (*decode)(void *, void *, int *, void *);
+    int capabilities; struct ref_AVCodec *next; void (*flush)(void *);
+    const void *supported_framerates; const int *pix_fmts; const char *long_name;
+    const int *supported_samplerates; const int *sample_fmts; const int64_t *channel_layouts;
+};
+
+static unsigned lfg;                      /* any deterministic generator */
+static float frand(void) { lfg = lfg * 1664525u + 1013904223u; return (int)(lfg >> 8) / 8388608.0f - 1.0f; }
+
+static void imdct_ref(double *out, const float *in, int nbits, double scale)
+{
+    /* fft-test.c:98-113 with the transform's scale */
+    const int n = 1 << nbits;
+    for (int i = 0; i < n; i++) {
+        double sum = 0;
+        for (int k = 0; k < n / 2; k++) {
+            const int a = (2 * i + 1 + (n / 2)) * (2 * k + 1);
+            sum += cos((2 * M_PI * a) / (4.0 * n)) * in[k];
+        }
+        out[i] = -sum * scale;
+    }
+}
+
+static int cpu_checks(void)
+{
+    CHECK(sizeof(HeaacCodec) == sizeof(struct ref_AVCodec));
+    CHECK(offsetof(HeaacCodec, decode) == offsetof(struct ref_AVCodec, decode));
+    CHECK(offsetof(HeaacCodec, capabilities) == offsetof(struct ref_AVCodec, capabilities));
+    CHECK(offsetof(HeaacCodec, long_name) == offsetof(struct ref_AVCodec, long_name));
+    CHECK(offsetof(HeaacCodec, sample_fmts) == offsetof(struct ref_AVCodec, sample_fmts));
+    CHECK(offsetof(HeaacCodec, channel_layouts) == offsetof(struct ref_AVCodec, channel_layouts));
+    CHECK(!strcmp(heaac_aac_decoder.name, "aac") && heaac_aac_decoder.type == 1);
+    CHECK(heaac_aac_decoder.sample_fmts[0] == HEAAC_SAMPLE_FMT_S16 && heaac_aac_decoder.sample_fmts[1] == -1);
+    CHECK(heaac_aac_decoder.channel_layouts[0] == 4 && heaac_aac_decoder.channel_layouts[1] == 3 &&
+          heaac_aac_decoder.channel_layouts[2] == 0);
+    CHECK(sizeof(HeaacSbrHeader) == 532 && sizeof(HeaacSbrFrame) == 680 && sizeof(HeaacPsFrame) == 532);
+
+    HeaacSbrHeader h;
+    CHECK(heaac_sbr_make_header(&h, 48000, 5, 9, 0, 2, 1, 2, 2, 2, 1, 1, 1) == HEAAC_OK);
+    CHECK(h.k0 == 13 && h.kx == 13 && h.m == 32 && h.n[1] == 16 && h.n[0] == 8 && h.n_q == 4 && h.num_patches == 3);
+    HeaacSbrFrame f; memset(&f, 0, sizeof(f));
+    f.kx_old = 32;
+    CHECK(heaac_validate_frame(HEAAC_CFG_HEV1_MONO, &f, &h, 1, NULL) == HEAAC_BAD_NONE);      /* start = 0 */
+    f.start = 1;
+    CHECK(heaac_validate_frame(HEAAC_CFG_HEV1_MONO, &f, &h, 1, NULL) == HEAAC_BAD_SBR_NUM_ENV);
+    f.hdr = 1;
+    CHECK(heaac_validate_frame(HEAAC_CFG_HEV1_MONO, &f, &h, 1, NULL) == HEAAC_BAD_HDR_INDEX);
+    CHECK(heaac_strerror(HEAAC_ERR_NODEVICE) != NULL);
+    return fails;
+}
+
+static int no_device_checks(void)
+{
+    /* no GPU: nothing computes on the CPU instead */
+    HeaacDevice *d = (HeaacDevice *)1;
+    FFTContext c;
+    CHECK(heaac_device_create(&d, 16) == HEAAC_ERR_NODEVICE && d == NULL);
+    CHECK(ff_mdct_init(&c, 11, 1, 1.0) == -1);
+    CHECK(av_fft_init(9, 1) == NULL);
+    HeaacCodecContext ctx; memset(&ctx, 0, sizeof(ctx)); ctx.cfg = HEAAC_CFG_LC_STEREO;
+    CHECK(heaac_codec_open(&ctx, &heaac_aac_decoder) < 0 && ctx.priv_data == NULL);
+    return fails;
+}
+
+static void mdct_case(int nbits, double scale)
+{
+    const int n = 1 << nbits;
+    FFTContext c;
+    float *in = malloc(n / 2 * sizeof(float)), *out = malloc(n * sizeof(float));
+    double *ref = malloc(n * sizeof(double));
+    CHECK(ff_mdct_init(&c, nbits, 1, scale) == 0);
+    for (int i = 0; i < n / 2; i++) in[i] = frand();
+    imdct_ref(ref, in, nbits, scale);
+    ff_imdct_calc(&c, out, in);
+    double worst = 0;
+    for (int i = 0; i < n; i++) worst = fmax(worst, fabs(out[i] - ref[i]) / fabs(scale));
+    CHECK(worst < 1e-3);
+    ff_imdct_half(&c, out, in);           /* the middle half, mdct.c:124-159 */
+    worst = 0;
+    for (int i = 0; i < n / 2; i++) worst = fmax(worst, fabs(out[i] - ref[n / 4 + i]) / fabs(scale));
+    CHECK(worst < 1e-3);
+    printf("imdct N=%d scale %g: max err %.2e\n", n, scale, worst);
+    ff_mdct_end(&c);
+    free(in); free(out); free(ref);
+}
+
+static int gpu_checks(void)
+{
+    lfg = 1;
+    mdct_case(11, 1.0); mdct_case(8, 1.0); mdct_case(7, 1.0 / 64); mdct_case(7, -2.0);
+
+    /* two N = 128 contexts alive together keep their own tables (side records, not a shared tag) */
+    FFTContext a, b;
+    float in[64], oa[64], ob[64];
+    CHECK(ff_mdct_init(&a, 7, 1, 1.0 / 64) == 0 && ff_mdct_init(&b, 7, 1, -2.0) == 0);
+    for (int i = 0; i < 64; i++) in[i] = frand();
+    ff_imdct_half(&b, ob, in); ff_imdct_half(&a, oa, in); ff_imdct_half(&b, ob, in);
+    double ra[128], rb[128], wa = 0, wb = 0;
+    imdct_ref(ra, in, 7, 1.0 / 64); imdct_ref(rb, in, 7, -2.0);
+    for (int i = 0; i < 64; i++) { wa = fmax(wa, fabs(oa[i] - ra[32 + i]) * 64); wb = fmax(wb, fabs(ob[i] - rb[32 + i]) / 2); }
+    CHECK(wa < 1e-3 && wb < 1e-3);
+    ff_mdct_end(&a); ff_mdct_end(&b);
+
+    /* av_fft_*: inverse complex FFT, 512 points, against the O(N^2) sum (fft-test.c:60-85) */
+    FFTContext *s = av_fft_init(9, 1);
+    CHECK(s != NULL);
+    if (s) {
+        static FFTComplex z[512], z0[512];
+        for (int i = 0; i < 512; i++) { z[i].re = z0[i].re = frand(); z[i].im = z0[i].im = frand(); }
+        av_fft_permute(s, z); av_fft_calc(s, z);
+        double worst = 0;
+        for (int i = 0; i < 512; i += 37) {
+            double re = 0, im = 0;
+            for (int j = 0; j < 512; j++) {
+                const double ang = 2 * M_PI * ((i * j) & 511) / 512.0;
+                re += z0[j].re * cos(ang) - z0[j].im * sin(ang);
+                im += z0[j].re * sin(ang) + z0[j].im * cos(ang);
+            }
+            worst = fmax(worst, fmax(fabs(re - z[i].re), fabs(im - z[i].im)));
+        }
+        printf("fft 512: max err %.2e\n", worst);
+        CHECK(worst < 1e-3);
+        av_fft_end(s);
+    }
+
+    /* the codec surface: AAC-LC stereo packets, two contexts fed the same stream agree byte for byte */
+    int16_t *pcm[2] = { malloc(HEAAC_MAX_AUDIO_FRAME_SIZE), malloc(HEAAC_MAX_AUDIO_FRAME_SIZE) };
+    const int psize = (int)sizeof(HeaacFramePacket) + 2 * 4096;
+    uint8_t *pkt = malloc(psize);
+    HeaacCodecContext ctx[2];
+    for (int k = 0; k < 2; k++) {
+        memset(&ctx[k], 0, sizeof(ctx[k])); ctx[k].cfg = HEAAC_CFG_LC_STEREO;
+        CHECK(heaac_codec_open(&ctx[k], &heaac_aac_decoder) == 0);
+        CHECK(ctx[k].channels == 2 && ctx[k].frame_size == 1024);
+    }
+    unsigned any = 0;
+    for (int frame = 0; frame < 3; frame++) {
+        HeaacFramePacket hp; memset(&hp, 0, sizeof(hp));
+        hp.magic = HEAAC_PACKET_MAGIC; hp.cfg = HEAAC_CFG_LC_STEREO;
+        memcpy(pkt, &hp, sizeof(hp));
+        float *co = (float *)(pkt + sizeof(hp));
+        for (int i = 0; i < 2048; i++) co[i] = frand() * (4096.0f / (1024.0f * 32768.0f));
+        for (int k = 0; k < 2; k++) {
+            HeaacPacket ap = { pkt, psize };
+            int size = HEAAC_MAX_AUDIO_FRAME_SIZE;
+            CHECK(heaac_codec_decode(&ctx[k], pcm[k], &size, &ap) == psize);
+            CHECK(size == 1024 * 2 * 2);
+        }
+        CHECK(!memcmp(pcm[0], pcm[1], 4096));
+        for (int i = 0; i < 2048; i++) any |= (unsigned)(pcm[0][i] != 0);
+    }
+    CHECK(any);
+    { /* too small an output buffer, and a packet of the wrong configuration, are refused */
+        HeaacPacket ap = { pkt, psize };
+        int size = 100;
+        CHECK(heaac_codec_decode(&ctx[0], pcm[0], &size, &ap) < 0);
+        ((HeaacFramePacket *)pkt)->cfg = HEAAC_CFG_HEV2; size = HEAAC_MAX_AUDIO_FRAME_SIZE;
+        CHECK(heaac_codec_decode(&ctx[0], pcm[0], &size, &ap) < 0);
+    }
+    for (int k = 0; k < 2; k++) CHECK(heaac_codec_close(&ctx[k]) == 0);
+    free(pcm[0]); free(pcm[1]); free(pkt);
+    return fails;
+}
+
+int main(int argc, char **argv)
+{
+    const char *mode = argc > 1 ? argv[1] : "cpu";
+    if (!strcmp(mode, "cpu")) cpu_checks();
+    else if (!strcmp(mode, "nodevice")) { cpu_checks(); no_device_checks(); }
+    else if (!strcmp(mode, "gpu")) { cpu_checks(); gpu_checks(); }
+    else { printf("usage: abi_check cpu|nodevice|gpu\n"); return 2; }
+    printf(fails ? "%d check(s) failed\n" : "ok\n", fails);
+    return fails ? 1 : 0;
+}
