@@ -102,15 +102,16 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
     // low half of a flat LDS address = the LDS byte offset
     return __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(p));
 }
+#define L2_TOUCH_STRIDE 128        // one load per 128-byte line (a second one per line fetches nothing more)
 __device__ __forceinline__ void l2_touch(const void *base, unsigned bytes, int lane, unsigned dump)
 {
-    for (unsigned o = 0; o < bytes; o += WAVE * 128) {
-        unsigned off = o + (unsigned)lane * 128;
+    for (unsigned o = 0; o < bytes; o += WAVE * L2_TOUCH_STRIDE) {
+        unsigned off = o + (unsigned)lane * L2_TOUCH_STRIDE;
         off = off < bytes ? off : bytes - 4;                 // surplus lanes re-touch the last line
         const char *p = reinterpret_cast<const char *>(base) + off;
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                     "global_load_lds_dword %1, off sc1\n\ts_mov_b32 m0, %0"
+                     "global_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(p), "s"(dump) : "memory");
     }
 }

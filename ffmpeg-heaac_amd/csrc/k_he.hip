@@ -116,9 +116,6 @@ void k_core_ana(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_
     cpx *T0 = reinterpret_cast<cpx *>(w.tu), *T1 = T0 + C2_TSTRIDE;
     const float *c16 = L.tab + TB_COS16, *c32 = L.tab + TB_COS32;
     const unsigned long long pairs = (n_units + 1) / 2;
-    __shared__ float s_dump[64];                 // where the L2 prefetches' LDS-DMA writes go (never read)
-    const unsigned sink = lds_addr(s_dump);
-
     for (unsigned long long pr = (unsigned long long)blockIdx.x * CA_WAVES + wave; pr < pairs;
          pr += (unsigned long long)gridDim.x * CA_WAVES) {
         const unsigned long long u0 = 2 * pr;
@@ -134,22 +131,6 @@ void k_core_ana(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_
             const bool eight = (half ? ics1.window_sequence[0] : ics0.window_sequence[0]) == HEAAC_EIGHT_SHORT_SEQUENCE;
             cpx *T = half ? T1 : T0;
             imdct_half_regs(L, reinterpret_cast<const float *>(T), T, eight, hl);
-        }
-        // the next pair's coefficients and state go into L2 now (static stride: its index is known)
-        {
-            const unsigned long long pn = pr + (unsigned long long)gridDim.x * CA_WAVES;
-            if (pn < pairs) {
-                const unsigned long long v0 = 2 * pn, fn = v0 / ncore;
-                l2_touch(g_coeffs + v0 * 1024, (v0 + 1 < n_units ? 2 : 1) * 1024 * 4, lane, sink);
-                l2_touch(g_state_in + fn * state_words + off_saved0, (ncore == 2 ? 2 : 1) * HEAAC_ST_SAVED * 4, lane, sink);
-                l2_touch(g_state_in + fn * state_words + off_sbr0 + HEAAC_SBR_XHIST, 288 * 4, lane, sink);
-                if (ncore == 1 && v0 + 1 < n_units) {
-                    l2_touch(g_state_in + (fn + 1) * state_words + off_saved0, HEAAC_ST_SAVED * 4, lane, sink);
-                    l2_touch(g_state_in + (fn + 1) * state_words + off_sbr0 + HEAAC_SBR_XHIST, 288 * 4, lane, sink);
-                } else if (ncore == 2) {
-                    l2_touch(g_state_in + fn * state_words + off_sbr0 + HEAAC_ST_SBR + HEAAC_SBR_XHIST, 288 * 4, lane, sink);
-                }
-            }
         }
         // windowing (bias 0) -> x = [history 288 | out * scale] per channel (vector_fmul_scalar,
         // aacsbr.c:1142), x history in / out
@@ -239,7 +220,6 @@ void k_core_ana(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_
         }
         wave_sync();
     }
-    l2_touch_drain();
 }
 
 __global__ __launch_bounds__(HF_WAVES * WAVE)

@@ -106,10 +106,13 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
     // Frames cost between ~0.8x and ~1.3x the mean (envelope counts, smoothing, patches), so the
     // waves draw them from a queue instead of a fixed stride: the first one is the wave's own index,
     // each next one is fetched (one atomic, in flight during the frame) from g_queue.
-    // Two tickets are held: the frame being processed and the next one, whose records are touched
-    // into L2 while the current frame computes (the queue hands the next index out a frame early).
+    // Two tickets are held: the frame being processed and the next one, whose parameter records are
+    // touched into the caches two thirds into the PS pass of the current frame (the queue hands the next
+    // index out a frame early).  Level 1 = the SBR and PS frame records (1.2 KB): k_hfps -6.8 %.  Level 2
+    // adds W and the SBR state (16 KB) for another 0.3 %, but those lines leave L2 again before they are
+    // used and are fetched twice (measured: +14.5 KiB per frame of FETCH_SIZE) -- not worth the traffic.
 #ifndef HFPS_PREFETCH
-#define HFPS_PREFETCH 2
+#define HFPS_PREFETCH 1
 #endif
     const unsigned sink = lds_addr(s_dump);
     unsigned long long f = (unsigned long long)blockIdx.x * HFPS_WAVES + wave;
