@@ -112,6 +112,9 @@ EXPORTED = [
     "av_fft_init", "av_fft_permute", "av_fft_calc", "av_fft_end",
     # heaac_codec.h
     "heaac_aac_decoder", "heaac_codec_open", "heaac_codec_decode", "heaac_codec_close",
+    # heaac_parse.h
+    "heaac_asc_parse", "heaac_adts_parse_header", "heaac_aac_parse_frame", "heaac_aac_parse_batch",
+    "heaac_aac_tables_fingerprint",
 ]
 
 
@@ -357,3 +360,55 @@ class Device:
                                                   C.c_float(scale), C.c_float(bias), C.c_size_t(n), _stream()),
                "heaac_qmf_synthesis_ds_batch")
         return out, vo
+
+
+# ---------------------------------------------------------------------------------------------------
+# host-side AAC parser (include/heaac_parse.h)
+# ---------------------------------------------------------------------------------------------------
+class AacConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("object_type", "sampling_index", "sample_rate", "chan_config", "sbr",
+                                       "ext_object_type", "ext_sampling_index", "ext_sample_rate",
+                                       "ext_chan_config", "ps")]
+
+
+class AdtsHeader(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("sample_rate", "samples", "bit_rate", "object_type", "sampling_index",
+                                       "chan_config", "crc_absent", "num_aac_frames", "frame_length")]
+
+
+AAC_STREAM_DT = np.dtype([("window_sequence", "u1", (2,)), ("use_kb_window", "u1", (2,)), ("pad", "u1", (4,))])
+AAC_INFO_DT = np.dtype([("channels", "<i4"), ("bits_consumed", "<i4"), ("sbr_payload_bit", "<i4"),
+                        ("sbr_payload_bytes", "<i4"), ("sbr_crc", "<i4")])
+
+
+def asc_parse(buf):
+    """heaac_asc_parse: (AacConfig, bit offset of the specific config)."""
+    c = AacConfig()
+    r = lib().heaac_asc_parse(C.byref(c), bytes(buf), len(buf))
+    if r < 0:
+        raise HeaacError("heaac_asc_parse -> %d" % r)
+    return c, r
+
+
+def adts_parse_header(buf):
+    h = AdtsHeader()
+    r = lib().heaac_adts_parse_header(C.byref(h), bytes(buf), len(buf))
+    return h, r
+
+
+def aac_parse_batch(cfg, streams, aus, threads=0):
+    """heaac_aac_parse_batch over a list of access units (bytes), one per stream.  `streams`: AAC_STREAM_DT
+    array updated in place.  Returns dict(coeffs [n][2][1024], ics [n][2], tools [n], info [n], status [n])."""
+    n = len(aus)
+    keep = [C.create_string_buffer(bytes(a), len(a)) for a in aus]
+    ptrs = (C.c_char_p * n)(*[C.cast(k, C.c_char_p) for k in keep])
+    sizes = (C.c_int * n)(*[len(a) for a in aus])
+    out = dict(coeffs=np.zeros((n, 2, 1024), np.float32), ics=np.zeros((n, 2), ICS_DT),
+               tools=np.zeros(n, TOOLS_FRAME_DT), info=np.zeros(n, AAC_INFO_DT), status=np.zeros(n, np.int32))
+    assert streams.dtype == AAC_STREAM_DT and streams.shape == (n,)
+    failed = lib().heaac_aac_parse_batch(C.byref(cfg), streams.ctypes.data_as(C.c_void_p), ptrs, sizes, C.c_size_t(n),
+                                         out["coeffs"].ctypes.data_as(C.c_void_p), out["ics"].ctypes.data_as(C.c_void_p),
+                                         out["tools"].ctypes.data_as(C.c_void_p), out["info"].ctypes.data_as(C.c_void_p),
+                                         out["status"].ctypes.data_as(C.c_void_p), C.c_int(threads))
+    out["failed"] = failed
+    return out

@@ -1,0 +1,691 @@
+/* aac_parse.c -- host-side AAC access-unit parser (include/heaac_parse.h).
+ *
+ * Own structure: a bit reader over the access unit, binary code trees built once from the ISO code /
+ * length tables (aac_iso_tables.h), one pass per element that writes straight into the records of the
+ * batched GPU entry points.  The VALUES follow the reference bit for bit: which bits are read in which
+ * order (ISO/IEC 14496-3 tables 4.4 - 4.54 as aacdec.c reads them) and how a quantised line becomes a
+ * float (decode_spectrum_and_dequant, aacdec.c:988-1245): mag(q) = q^(4/3) as a float for q < 16,
+ * cbrtf(n) * n for an escape value, times the band's scalefactor -2^((sf - 200) / 4) with the line's
+ * sign; pulses re-quantise the line as :1222-1236 does.
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include "heaac_parse.h"
+#include "aac_iso_tables.h"
+
+/* ------------------------------------------------------------------------------------------ */
+/* bit reader (MSB first); reading past the end yields zeros and sets `over`                     */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const uint8_t *buf;
+    int size_bits, pos, over;
+} Bits;
+
+static void bits_init(Bits *b, const uint8_t *buf, int bytes)
+{
+    b->buf = buf; b->size_bits = bytes * 8; b->pos = 0; b->over = 0;
+}
+static inline unsigned bit1(Bits *b)
+{
+    if (b->pos >= b->size_bits) { b->over = 1; b->pos++; return 0; }
+    const unsigned v = (b->buf[b->pos >> 3] >> (7 - (b->pos & 7))) & 1;
+    b->pos++;
+    return v;
+}
+static inline unsigned bits(Bits *b, int n)          /* n <= 25 */
+{
+    unsigned v = 0;
+    while (n-- > 0) v = (v << 1) | bit1(b);
+    return v;
+}
+static inline unsigned peek(Bits *b, int n)
+{
+    Bits t = *b;
+    return bits(&t, n);
+}
+static inline int bits_left(const Bits *b) { return b->size_bits - b->pos; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* code trees                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { int16_t child[2]; } Node;           /* >= 0: node index, < 0: -(symbol + 1), 0 at root only */
+typedef struct { Node *n; int count; } Tree;
+
+static Tree g_sf_tree, g_spec_tree[11];
+static float g_pow2sf[428];                           /* ff_aac_pow2sf_tab: 2^((i - 200) / 4), aac_tablegen.h */
+static float g_mag[16];                               /* q^(4/3), q = 0..15 (aactab.c: codebook vector values) */
+static pthread_once_t g_once = PTHREAD_ONCE_INIT;
+
+static void tree_build(Tree *t, const uint32_t *code32, const uint16_t *code16, const uint8_t *len, int n)
+{
+    int cap = 2 * n + 2;
+    t->n = (Node *)calloc(cap, sizeof(Node));
+    t->count = 1;
+    for (int s = 0; s < n; s++) {
+        const uint32_t c = code32 ? code32[s] : code16[s];
+        int at = 0;
+        for (int i = len[s] - 1; i >= 0; i--) {
+            const int bit = (c >> i) & 1;
+            if (i == 0) {
+                t->n[at].child[bit] = (int16_t)-(s + 1);
+            } else {
+                if (t->n[at].child[bit] <= 0) {
+                    t->n[at].child[bit] = (int16_t)t->count;
+                    t->count++;
+                }
+                at = t->n[at].child[bit];
+            }
+        }
+    }
+}
+
+static inline int tree_read(const Tree *t, Bits *b)
+{
+    int at = 0;
+    for (int depth = 0; depth < 24; depth++) {
+        const int c = t->n[at].child[bit1(b)];
+        if (c < 0) return -c - 1;
+        if (c == 0) return -1;                        /* not a code of this book */
+        at = c;
+    }
+    return -1;
+}
+
+static void tables_init(void)
+{
+    tree_build(&g_sf_tree, aac_sf_code, NULL, aac_sf_bits, 121);
+    for (int b = 0; b < 11; b++)
+        tree_build(&g_spec_tree[b], NULL, aac_spec_code + aac_spec_first[b], aac_spec_bits + aac_spec_first[b],
+                   aac_spec_first[b + 1] - aac_spec_first[b]);
+    for (int i = 0; i < 428; i++) g_pow2sf[i] = (float)pow(2, (i - 200) / 4.);
+    for (int q = 0; q < 16; q++) g_mag[q] = (float)pow((double)q, 4.0 / 3.0);
+}
+
+uint64_t heaac_aac_tables_fingerprint(void)
+{
+    uint64_t h = 1469598103934665603ull;
+#define MIX(arr) do { const uint8_t *p_ = (const uint8_t *)(arr); for (size_t i_ = 0; i_ < sizeof(arr); i_++) { h ^= p_[i_]; h *= 1099511628211ull; } } while (0)
+    MIX(aac_sf_code); MIX(aac_sf_bits); MIX(aac_spec_first); MIX(aac_spec_code); MIX(aac_spec_bits);
+    MIX(aac_num_swb_1024); MIX(aac_num_swb_128); MIX(aac_pred_sfb_max); MIX(aac_tns_max_bands_1024);
+    MIX(aac_tns_max_bands_128); MIX(aac_swb_offset_1024); MIX(aac_swb_offset_128); MIX(aac_tns_map);
+#undef MIX
+    return h;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* AudioSpecificConfig, ADTS                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+static const int k_rates[16] = { 96000, 88200, 64000, 48000, 44100, 32000, 24000, 22050, 16000, 12000,
+                                 11025, 8000, 7350, 0, 0, 0 };
+
+static int get_object_type(Bits *b)
+{
+    int t = (int)bits(b, 5);
+    if (t == 31) t = 32 + (int)bits(b, 6);
+    return t;
+}
+static int get_sample_rate(Bits *b, int *index)
+{
+    *index = (int)bits(b, 4);
+    return *index == 0x0f ? (int)bits(b, 24) : k_rates[*index];
+}
+
+int heaac_asc_parse(HeaacAacConfig *c, const uint8_t *buf, int size)
+{
+    if (!c || !buf || size <= 0) return HEAAC_PARSE_ERR_ARG;
+    Bits b;
+    bits_init(&b, buf, size);
+    memset(c, 0, sizeof(*c));
+    c->object_type = get_object_type(&b);
+    c->sample_rate = get_sample_rate(&b, &c->sampling_index);
+    c->chan_config = (int)bits(&b, 4);
+    c->sbr = -1;
+    c->ps = -1;
+    if (c->object_type == HEAAC_AOT_SBR ||
+        (c->object_type == HEAAC_AOT_PS && !((peek(&b, 3) & 0x03) && !(peek(&b, 9) & 0x3F)))) {
+        if (c->object_type == HEAAC_AOT_PS) c->ps = 1;
+        c->ext_object_type = HEAAC_AOT_SBR;
+        c->sbr = 1;
+        c->ext_sample_rate = get_sample_rate(&b, &c->ext_sampling_index);
+        c->object_type = get_object_type(&b);
+        if (c->object_type == 22)                      /* AOT_ER_BSAC */
+            c->ext_chan_config = (int)bits(&b, 4);
+    }
+    const int specific = b.pos;
+    if (c->object_type == 36)                          /* AOT_ALS: not an AAC configuration */
+        return HEAAC_PARSE_ERR_UNSUPPORTED;
+    if (c->ext_object_type != HEAAC_AOT_SBR) {
+        while (bits_left(&b) > 15) {
+            if (peek(&b, 11) == 0x2b7) {               /* sync extension */
+                bits(&b, 11);
+                c->ext_object_type = get_object_type(&b);
+                if (c->ext_object_type == HEAAC_AOT_SBR && (c->sbr = (int)bit1(&b)) == 1)
+                    c->ext_sample_rate = get_sample_rate(&b, &c->ext_sampling_index);
+                if (bits_left(&b) > 11 && bits(&b, 11) == 0x548)
+                    c->ps = (int)bit1(&b);
+                break;
+            }
+            bit1(&b);
+        }
+    }
+    if (!c->sbr) c->ps = 0;                            /* PS requires SBR */
+    const int channels = c->chan_config < 8 ? (c->chan_config == 7 ? 8 : c->chan_config) : 0;
+    if ((c->ps == -1 && c->object_type != HEAAC_AOT_AAC_LC) || (channels & ~0x01))
+        c->ps = 0;                                     /* implicit PS only in the HE-AACv2 profile */
+    if (b.over) return HEAAC_PARSE_ERR_OVERREAD;
+    return specific;
+}
+
+int heaac_adts_parse_header(HeaacAdtsHeader *h, const uint8_t *buf, int size)
+{
+    if (!h || !buf || size < 7) return HEAAC_PARSE_ERR_ARG;
+    Bits b;
+    bits_init(&b, buf, size);
+    if (bits(&b, 12) != 0xfff) return -1;
+    bit1(&b);                                          /* id */
+    bits(&b, 2);                                       /* layer */
+    const int crc_abs = (int)bit1(&b);
+    const int aot = (int)bits(&b, 2);
+    const int sr = (int)bits(&b, 4);
+    if (!k_rates[sr]) return -2;
+    bit1(&b);                                          /* private_bit */
+    const int ch = (int)bits(&b, 3);
+    bits(&b, 4);                                       /* original/copy, home, copyright id bit + start */
+    const int flen = (int)bits(&b, 13);
+    if (flen < 7) return -3;
+    bits(&b, 11);                                      /* adts_buffer_fullness */
+    const int rdb = (int)bits(&b, 2);
+    h->object_type = aot + 1;
+    h->chan_config = ch;
+    h->crc_absent = crc_abs;
+    h->num_aac_frames = rdb + 1;
+    h->sampling_index = sr;
+    h->sample_rate = k_rates[sr];
+    h->samples = (rdb + 1) * 1024;
+    h->bit_rate = (int)((long long)flen * 8 * h->sample_rate / h->samples);
+    h->frame_length = flen;
+    return crc_abs ? 7 : 9;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* individual channel stream                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int num_pulse, pos[4], amp[4];
+} Pulse;
+
+typedef struct {
+    uint8_t window_sequence[2], use_kb_window[2];
+} WinInfo;
+
+/* decode_ics_info + decode_prediction (aacdec.c:622-742) */
+static int read_ics_info(const HeaacAacConfig *cfg, Bits *b, HeaacToolsIcs *ics, HeaacPrediction *pred, WinInfo *w)
+{
+    const int si = cfg->sampling_index;
+    if (bit1(b)) return HEAAC_PARSE_ERR_DATA;          /* reserved bit */
+    w->window_sequence[1] = w->window_sequence[0];
+    w->window_sequence[0] = (uint8_t)bits(b, 2);
+    w->use_kb_window[1] = w->use_kb_window[0];
+    w->use_kb_window[0] = (uint8_t)bit1(b);
+    memset(ics, 0, sizeof(*ics));
+    memset(pred, 0, sizeof(*pred));
+    ics->num_window_groups = 1;
+    ics->group_len[0] = 1;
+    pred->pred_sfb_max = aac_pred_sfb_max[si];
+    if (w->window_sequence[0] == HEAAC_EIGHT_SHORT_SEQUENCE) {
+        ics->max_sfb = (uint8_t)bits(b, 4);
+        for (int i = 0; i < 7; i++) {
+            if (bit1(b)) {
+                ics->group_len[ics->num_window_groups - 1]++;
+            } else {
+                ics->num_window_groups++;
+                ics->group_len[ics->num_window_groups - 1] = 1;
+            }
+        }
+        ics->num_windows = 8;
+        ics->num_swb = aac_num_swb_128[si];
+        ics->tns_max_bands = aac_tns_max_bands_128[si];
+        memcpy(ics->swb_offset, aac_swb_offset_128 + aac_swb_first_128[si], (ics->num_swb + 1) * sizeof(uint16_t));
+    } else {
+        ics->max_sfb = (uint8_t)bits(b, 6);
+        ics->num_windows = 1;
+        ics->num_swb = aac_num_swb_1024[si];
+        ics->tns_max_bands = aac_tns_max_bands_1024[si];
+        memcpy(ics->swb_offset, aac_swb_offset_1024 + aac_swb_first_1024[si], (ics->num_swb + 1) * sizeof(uint16_t));
+        pred->predictor_present = (uint8_t)bit1(b);
+        if (pred->predictor_present) {
+            if (cfg->object_type == HEAAC_AOT_AAC_MAIN) {
+                if (bit1(b)) {
+                    pred->predictor_reset_group = (uint8_t)bits(b, 5);
+                    if (pred->predictor_reset_group == 0 || pred->predictor_reset_group > 30)
+                        return HEAAC_PARSE_ERR_DATA;
+                }
+                const int lim = ics->max_sfb < pred->pred_sfb_max ? ics->max_sfb : pred->pred_sfb_max;
+                for (int sfb = 0; sfb < lim; sfb++) pred->prediction_used[sfb] = (uint8_t)bit1(b);
+            } else if (cfg->object_type == HEAAC_AOT_AAC_LC) {
+                return HEAAC_PARSE_ERR_DATA;           /* prediction is not allowed in AAC-LC */
+            } else {
+                return HEAAC_PARSE_ERR_UNSUPPORTED;    /* LTP */
+            }
+        }
+    }
+    if (ics->max_sfb > ics->num_swb) return HEAAC_PARSE_ERR_DATA;
+    return HEAAC_PARSE_OK;
+}
+
+/* decode_band_types (:755-801) */
+static int read_band_types(Bits *b, const HeaacToolsIcs *ics, int eight, uint8_t band_type[128], uint8_t run_end[128])
+{
+    const int nb = eight ? 3 : 5;
+    int idx = 0;
+    for (int g = 0; g < ics->num_window_groups; g++) {
+        int k = 0;
+        while (k < ics->max_sfb) {
+            int sect_end = k, incr;
+            const int bt = (int)bits(b, 4);
+            if (bt == 12) return HEAAC_PARSE_ERR_DATA;
+            while ((incr = (int)bits(b, nb)) == (1 << nb) - 1) {
+                sect_end += incr;
+                if (b->over) return HEAAC_PARSE_ERR_OVERREAD;
+            }
+            sect_end += incr;
+            if (b->over) return HEAAC_PARSE_ERR_OVERREAD;
+            if (sect_end > ics->max_sfb) return HEAAC_PARSE_ERR_DATA;
+            for (; k < sect_end; k++) {
+                band_type[idx] = (uint8_t)bt;
+                run_end[idx++] = (uint8_t)sect_end;
+            }
+        }
+    }
+    return HEAAC_PARSE_OK;
+}
+
+/* decode_scalefactors (:815-873) on the C path: sf_offset = 0 (+12 for eight short) */
+static int read_scalefactors(Bits *b, const HeaacToolsIcs *ics, int eight, unsigned global_gain,
+                             const uint8_t band_type[128], const uint8_t run_end[128], float sf[128])
+{
+    const int sf_offset = eight ? 12 : 0;
+    int offset[3] = { (int)global_gain, (int)global_gain - 90, 100 };
+    int noise_flag = 1, idx = 0;
+    for (int g = 0; g < ics->num_window_groups; g++) {
+        for (int i = 0; i < ics->max_sfb;) {
+            const int end = run_end[idx];
+            const int bt = band_type[idx];
+            if (bt == 0) {
+                for (; i < end; i++, idx++) sf[idx] = 0.f;
+            } else if (bt == HEAAC_INTENSITY_BT || bt == HEAAC_INTENSITY_BT2) {
+                for (; i < end; i++, idx++) {
+                    const int s = tree_read(&g_sf_tree, b);
+                    if (s < 0) return HEAAC_PARSE_ERR_DATA;
+                    offset[2] += s - 60;
+                    if ((unsigned)offset[2] > 255U) return HEAAC_PARSE_ERR_DATA;
+                    sf[idx] = g_pow2sf[-offset[2] + 300];
+                }
+            } else if (bt == HEAAC_NOISE_BT) {
+                for (; i < end; i++, idx++) {
+                    if (noise_flag-- > 0) {
+                        offset[1] += (int)bits(b, 9) - 256;
+                    } else {
+                        const int s = tree_read(&g_sf_tree, b);
+                        if (s < 0) return HEAAC_PARSE_ERR_DATA;
+                        offset[1] += s - 60;
+                    }
+                    if ((unsigned)offset[1] > 255U) return HEAAC_PARSE_ERR_DATA;
+                    sf[idx] = -g_pow2sf[offset[1] + sf_offset + 100];
+                }
+            } else {
+                for (; i < end; i++, idx++) {
+                    const int s = tree_read(&g_sf_tree, b);
+                    if (s < 0) return HEAAC_PARSE_ERR_DATA;
+                    offset[0] += s - 60;
+                    if ((unsigned)offset[0] > 255U) return HEAAC_PARSE_ERR_DATA;
+                    sf[idx] = -g_pow2sf[offset[0] + sf_offset];
+                }
+            }
+        }
+    }
+    return b->over ? HEAAC_PARSE_ERR_OVERREAD : HEAAC_PARSE_OK;
+}
+
+/* decode_pulses (:878-900) */
+static int read_pulses(Bits *b, const HeaacToolsIcs *ics, Pulse *p)
+{
+    p->num_pulse = (int)bits(b, 2) + 1;
+    const int swb = (int)bits(b, 6);
+    if (swb >= ics->num_swb) return HEAAC_PARSE_ERR_DATA;
+    p->pos[0] = ics->swb_offset[swb] + (int)bits(b, 5);
+    if (p->pos[0] > 1023) return HEAAC_PARSE_ERR_DATA;
+    p->amp[0] = (int)bits(b, 4);
+    for (int i = 1; i < p->num_pulse; i++) {
+        p->pos[i] = (int)bits(b, 5) + p->pos[i - 1];
+        if (p->pos[i] > 1023) return HEAAC_PARSE_ERR_DATA;
+        p->amp[i] = (int)bits(b, 4);
+    }
+    return HEAAC_PARSE_OK;
+}
+
+/* decode_tns (:907-945) */
+static int read_tns(const HeaacAacConfig *cfg, Bits *b, const HeaacToolsIcs *ics, int eight, HeaacTns *tns)
+{
+    const int max_order = eight ? 7 : cfg->object_type == HEAAC_AOT_AAC_MAIN ? 20 : 12;
+    for (int w = 0; w < ics->num_windows; w++) {
+        tns->n_filt[w] = (uint8_t)bits(b, 2 - eight);
+        if (!tns->n_filt[w]) continue;
+        const int coef_res = (int)bit1(b);
+        for (int f = 0; f < tns->n_filt[w]; f++) {
+            tns->length[w][f] = (uint8_t)bits(b, 6 - 2 * eight);
+            tns->order[w][f] = (uint8_t)bits(b, 5 - 2 * eight);
+            if (tns->order[w][f] > max_order) { tns->order[w][f] = 0; return HEAAC_PARSE_ERR_DATA; }
+            if (tns->order[w][f]) {
+                tns->direction[w][f] = (uint8_t)bit1(b);
+                const int compress = (int)bit1(b);
+                const int len = coef_res + 3 - compress;
+                const float *map = aac_tns_map[2 * compress + coef_res];
+                for (int i = 0; i < tns->order[w][f]; i++)
+                    tns->coef[w][f][i] = map[bits(b, len)];
+            }
+        }
+    }
+    return b->over ? HEAAC_PARSE_ERR_OVERREAD : HEAAC_PARSE_OK;
+}
+
+/* one quantised line of magnitude q (< 16 from the books, any from an escape) and sign -> float */
+static inline float dequant(unsigned q, int negative, float sf)
+{
+    const float mag = q < 16 ? g_mag[q] : cbrtf((float)q) * (float)q;
+    return (negative ? -mag : mag) * sf;
+}
+
+/* decode_spectrum_and_dequant (:988-1245).  NOISE_BT bands are zeroed (the GPU fills them). */
+static int read_spectrum(Bits *b, const HeaacToolsIcs *ics, const uint8_t band_type[128], const float sf[128],
+                         int pulse_present, const Pulse *pulse, float coef[1024])
+{
+    const int c = 1024 / ics->num_windows;
+    const uint16_t *off = ics->swb_offset;
+    float *base = coef;
+    int idx = 0;
+    for (int g = 0; g < ics->num_windows; g++)
+        memset(coef + g * 128 + off[ics->max_sfb], 0, sizeof(float) * (c - off[ics->max_sfb]));
+    for (int g = 0; g < ics->num_window_groups; g++) {
+        const int g_len = ics->group_len[g];
+        for (int i = 0; i < ics->max_sfb; i++, idx++) {
+            const int bt = band_type[idx];
+            float *cfo = coef + off[i];
+            const int len = off[i + 1] - off[i];
+            if (bt == 0 || bt >= HEAAC_NOISE_BT) {
+                for (int w = 0; w < g_len; w++) memset(cfo + 128 * w, 0, len * sizeof(float));
+                continue;
+            }
+            const Tree *t = &g_spec_tree[bt - 1];
+            const float s = sf[idx];
+            for (int w = 0; w < g_len; w++) {
+                float *cf = cfo + 128 * w;
+                if (bt <= 4) {
+                    /* quads: books 1, 2 signed (-1..1), books 3, 4 unsigned (0..2) + sign bits */
+                    for (int k = 0; k < len; k += 4) {
+                        const int code = tree_read(t, b);
+                        if (code < 0) return HEAAC_PARSE_ERR_DATA;
+                        int q[4] = { code / 27, code / 9 % 3, code / 3 % 3, code % 3 };
+                        for (int j = 0; j < 4; j++) {
+                            if (bt <= 2) {
+                                const int v = q[j] - 1;
+                                cf[k + j] = dequant((unsigned)abs(v), v < 0, s);
+                            } else {
+                                const int neg = q[j] ? (int)bit1(b) : 0;
+                                cf[k + j] = dequant((unsigned)q[j], neg, s);
+                            }
+                        }
+                    }
+                } else {
+                    /* pairs: books 5, 6 signed (-4..4); 7, 8 (0..7), 9, 10 (0..12), 11 (0..16, 16 = escape) unsigned */
+                    const int mod = bt <= 6 ? 9 : bt <= 8 ? 8 : bt <= 10 ? 13 : 17;
+                    for (int k = 0; k < len; k += 2) {
+                        const int code = tree_read(t, b);
+                        if (code < 0) return HEAAC_PARSE_ERR_DATA;
+                        int q[2] = { code / mod, code % mod };
+                        if (bt <= 6) {
+                            for (int j = 0; j < 2; j++) {
+                                const int v = q[j] - 4;
+                                cf[k + j] = dequant((unsigned)abs(v), v < 0, s);
+                            }
+                        } else {
+                            int neg[2];
+                            for (int j = 0; j < 2; j++) neg[j] = q[j] ? (int)bit1(b) : 0;
+                            for (int j = 0; j < 2; j++) {
+                                unsigned v = (unsigned)q[j];
+                                if (bt == 11 && q[j] == 16) {
+                                    /* escape_sequence: N ones, a zero, then N + 4 bits (:1174-1197) */
+                                    int n = 0;
+                                    while (bit1(b)) {
+                                        if (++n > 8) return HEAAC_PARSE_ERR_DATA;
+                                    }
+                                    v = (1u << (n + 4)) + bits(b, n + 4);
+                                }
+                                cf[k + j] = dequant(v, neg[j], s);
+                            }
+                        }
+                    }
+                }
+                if (b->over) return HEAAC_PARSE_ERR_OVERREAD;
+            }
+        }
+        coef += g_len << 7;
+    }
+    if (pulse_present) {
+        /* :1222-1236 */
+        idx = 0;
+        for (int i = 0; i < pulse->num_pulse; i++) {
+            float co = base[pulse->pos[i]];
+            while (off[idx + 1] <= pulse->pos[i]) idx++;
+            if (band_type[idx] != HEAAC_NOISE_BT && sf[idx]) {
+                float ico = -(float)pulse->amp[i];
+                if (co) {
+                    co /= sf[idx];
+                    ico = co / sqrtf(sqrtf(fabsf(co))) + (co > 0 ? -ico : ico);
+                }
+                base[pulse->pos[i]] = cbrtf(fabsf(ico)) * ico * sf[idx];
+            }
+        }
+    }
+    return HEAAC_PARSE_OK;
+}
+
+/* decode_ics (:1334-1388) without apply_prediction (a GPU stage) */
+static int read_ics(const HeaacAacConfig *cfg, Bits *b, int common_window, HeaacToolsChannel *ch, WinInfo *w, float coef[1024])
+{
+    Pulse pulse;
+    pulse.num_pulse = 0;
+    const unsigned global_gain = bits(b, 8);
+    int r;
+    if (!common_window && (r = read_ics_info(cfg, b, &ch->ics, &ch->pred, w)) < 0)
+        return r;
+    const int eight = w->window_sequence[0] == HEAAC_EIGHT_SHORT_SEQUENCE;
+    uint8_t run_end[128];
+    memset(ch->band_type, 0, sizeof(ch->band_type));
+    memset(ch->sf, 0, sizeof(ch->sf));
+    memset(&ch->tns, 0, sizeof(ch->tns));
+    if ((r = read_band_types(b, &ch->ics, eight, ch->band_type, run_end)) < 0) return r;
+    if ((r = read_scalefactors(b, &ch->ics, eight, global_gain, ch->band_type, run_end, ch->sf)) < 0) return r;
+    const int pulse_present = (int)bit1(b);
+    if (pulse_present) {
+        if (eight) return HEAAC_PARSE_ERR_DATA;        /* pulse tool not allowed in eight short sequence */
+        if ((r = read_pulses(b, &ch->ics, &pulse)) < 0) return r;
+    }
+    ch->tns.present = (uint8_t)bit1(b);
+    if (ch->tns.present && (r = read_tns(cfg, b, &ch->ics, eight, &ch->tns)) < 0) return r;
+    if (bit1(b)) return HEAAC_PARSE_ERR_UNSUPPORTED;   /* gain control (SSR) */
+    return read_spectrum(b, &ch->ics, ch->band_type, ch->sf, pulse_present, &pulse, coef);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* access unit                                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+enum { TYPE_SCE, TYPE_CPE, TYPE_CCE, TYPE_LFE, TYPE_DSE, TYPE_PCE, TYPE_FIL, TYPE_END };
+enum { EXT_SBR_DATA = 0xd, EXT_SBR_DATA_CRC = 0xe };
+
+int heaac_aac_parse_frame(const HeaacAacConfig *cfg, HeaacAacStream *st,
+                          const uint8_t *au, int size,
+                          float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
+                          HeaacAacFrameInfo *info)
+{
+    if (!cfg || !st || !au || size <= 0 || !coeffs || !ics || !tools ||
+        cfg->sampling_index < 0 || cfg->sampling_index > 12)
+        return HEAAC_PARSE_ERR_ARG;
+    pthread_once(&g_once, tables_init);
+    Bits b;
+    bits_init(&b, au, size);
+    if (peek(&b, 12) == 0xfff) {
+        /* an ADTS header in front of the raw data block (aacdec.c:1988-1997) */
+        HeaacAdtsHeader h;
+        const int hs = heaac_adts_parse_header(&h, au, size);
+        if (hs < 0) return HEAAC_PARSE_ERR_DATA;
+        b.pos = hs * 8;
+    }
+    WinInfo w[2];
+    for (int c = 0; c < 2; c++) {
+        w[c].window_sequence[0] = st->window_sequence[c];
+        w[c].use_kb_window[0] = st->use_kb_window[c];
+        w[c].window_sequence[1] = w[c].use_kb_window[1] = 0;
+    }
+    memset(tools, 0, sizeof(*tools));
+    HeaacAacFrameInfo fi = { 0, 0, -1, 0, 0 };
+    int elem, r;
+    while ((elem = (int)bits(&b, 3)) != TYPE_END) {
+        int elem_id = (int)bits(&b, 4);
+        switch (elem) {
+        case TYPE_SCE:
+        case TYPE_LFE:
+            if (fi.channels) return HEAAC_PARSE_ERR_UNSUPPORTED;
+            if ((r = read_ics(cfg, &b, 0, &tools->ch[0], &w[0], coeffs)) < 0) return r;
+            fi.channels = 1;
+            break;
+        case TYPE_CPE: {
+            if (fi.channels) return HEAAC_PARSE_ERR_UNSUPPORTED;
+            /* decode_cpe (:1453-1492) without the spectral tools (GPU stages) */
+            const int common = (int)bit1(&b);
+            tools->common_window = (uint8_t)common;
+            if (common) {
+                if ((r = read_ics_info(cfg, &b, &tools->ch[0].ics, &tools->ch[0].pred, &w[0])) < 0) return r;
+                /* channel 1 takes channel 0's ics, keeping its own previous window shape (:1462-1464) */
+                const uint8_t kb_prev1 = w[1].use_kb_window[0];
+                w[1] = w[0];
+                w[1].use_kb_window[1] = kb_prev1;
+                tools->ch[1].ics = tools->ch[0].ics;
+                tools->ch[1].pred = tools->ch[0].pred;
+                tools->ms_present = (uint8_t)bits(&b, 2);
+                if (tools->ms_present == 3) return HEAAC_PARSE_ERR_DATA;
+                const int nb = tools->ch[0].ics.num_window_groups * tools->ch[0].ics.max_sfb;
+                if (tools->ms_present == 1)
+                    for (int i = 0; i < nb; i++) tools->ms_mask[i] = (uint8_t)bit1(&b);
+                else if (tools->ms_present == 2)
+                    memset(tools->ms_mask, 1, nb);
+            }
+            if ((r = read_ics(cfg, &b, common, &tools->ch[0], &w[0], coeffs)) < 0) return r;
+            if ((r = read_ics(cfg, &b, common, &tools->ch[1], &w[1], coeffs + 1024)) < 0) return r;
+            fi.channels = 2;
+            break;
+        }
+        case TYPE_DSE: {
+            /* skip_data_stream_element (:602-620) */
+            const int align = (int)bit1(&b);
+            int count = (int)bits(&b, 8);
+            if (count == 255) count += (int)bits(&b, 8);
+            if (align) b.pos = (b.pos + 7) & ~7;
+            if (bits_left(&b) < 8 * count) return HEAAC_PARSE_ERR_OVERREAD;
+            b.pos += 8 * count;
+            break;
+        }
+        case TYPE_FIL: {
+            if (elem_id == 15) elem_id += (int)bits(&b, 8) - 1;
+            if (bits_left(&b) < 8 * elem_id) return HEAAC_PARSE_ERR_OVERREAD;
+            /* decode_extension_payload (:1650-1690): every payload type is `cnt` bytes here; an SBR
+             * payload is reported, not parsed */
+            if (elem_id > 0) {
+                const int type = (int)bits(&b, 4);
+                if ((type == EXT_SBR_DATA || type == EXT_SBR_DATA_CRC) && fi.channels && fi.sbr_payload_bit < 0) {
+                    fi.sbr_payload_bit = b.pos;
+                    fi.sbr_payload_bytes = elem_id;
+                    fi.sbr_crc = type == EXT_SBR_DATA_CRC;
+                }
+                b.pos += 8 * elem_id - 4;
+            }
+            break;
+        }
+        case TYPE_CCE:
+        case TYPE_PCE:
+        default:
+            return HEAAC_PARSE_ERR_UNSUPPORTED;
+        }
+        if (b.over) return HEAAC_PARSE_ERR_OVERREAD;
+        if (bits_left(&b) < 3) return HEAAC_PARSE_ERR_OVERREAD;
+    }
+    if (!fi.channels) return HEAAC_PARSE_ERR_DATA;
+    for (int c = 0; c < fi.channels; c++) {
+        ics[c].window_sequence[0] = w[c].window_sequence[0];
+        ics[c].window_sequence[1] = w[c].window_sequence[1];
+        ics[c].use_kb_window[0] = w[c].use_kb_window[0];
+        ics[c].use_kb_window[1] = w[c].use_kb_window[1];
+        st->window_sequence[c] = w[c].window_sequence[0];
+        st->use_kb_window[c] = w[c].use_kb_window[0];
+    }
+    fi.bits_consumed = b.pos;
+    if (info) *info = fi;
+    return HEAAC_PARSE_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* batch over streams                                                                            */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const HeaacAacConfig *cfg; HeaacAacStream *st; const uint8_t *const *au; const int *size;
+    float *coeffs; HeaacIcs *ics; HeaacToolsFrame *tools; HeaacAacFrameInfo *info; int *status;
+    size_t lo, hi; int failed;
+} Job;
+
+static void *job_run(void *p)
+{
+    Job *j = (Job *)p;
+    for (size_t f = j->lo; f < j->hi; f++) {
+        const int r = heaac_aac_parse_frame(j->cfg, &j->st[f], j->au[f], j->size[f], j->coeffs + f * 2048,
+                                            j->ics + f * 2, j->tools + f, j->info ? j->info + f : NULL);
+        if (j->status) j->status[f] = r;
+        j->failed += r != HEAAC_PARSE_OK;
+    }
+    return NULL;
+}
+
+int heaac_aac_parse_batch(const HeaacAacConfig *cfg, HeaacAacStream *st,
+                          const uint8_t *const *au, const int *size, size_t n,
+                          float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
+                          HeaacAacFrameInfo *info, int *status, int threads)
+{
+    if (!cfg || !st || !au || !size || !coeffs || !ics || !tools) return HEAAC_PARSE_ERR_ARG;
+    if (!n) return 0;
+    pthread_once(&g_once, tables_init);
+    if (threads <= 0) threads = (int)sysconf(_SC_NPROCESSORS_ONLN);
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > n) threads = (int)n;
+    if (threads > 256) threads = 256;
+    Job jobs[256];
+    pthread_t tid[256];
+    for (int t = 0; t < threads; t++) {
+        Job j = { cfg, st, au, size, coeffs, ics, tools, info, status, n * t / threads, n * (t + 1) / threads, 0 };
+        jobs[t] = j;
+    }
+    int started = 0;
+    for (int t = 1; t < threads; t++) {
+        if (pthread_create(&tid[t], NULL, job_run, &jobs[t]) != 0) break;
+        started = t;
+    }
+    job_run(&jobs[0]);
+    for (int t = started + 1; t < threads; t++) job_run(&jobs[t]);     /* threads that could not start: inline */
+    int failed = jobs[0].failed;
+    for (int t = 1; t < threads; t++) {
+        if (t <= started) pthread_join(tid[t], NULL);
+        failed += jobs[t].failed;
+    }
+    return failed;
+}

@@ -320,8 +320,10 @@ __device__ __forceinline__ void imdct128_reg(In in, float *out, const float *rot
 __device__ __forceinline__ int float_to_int16_one(float f)
 {
     int tmp = __float_as_int(f);
+    // (unsigned subtraction: for a negative float the reference's int expression overflows; the
+    // two's-complement wrap is the value a sub / sar pair gives)
     if (tmp & 0xf0000)
-        tmp = (0x43c0ffff - tmp) >> 31;
+        tmp = (int)(0x43c0ffffu - (unsigned)tmp) >> 31;
     return (int)(short)(tmp - 0x8000);
 }
 

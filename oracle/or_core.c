@@ -521,8 +521,11 @@ int oracle_float_to_int16_one(float f)
 {
     int32_t tmp;
     memcpy(&tmp, &f, 4);
+    /* dsputil.c:3975-3980.  For a NEGATIVE float the reference's `0x43c0ffff - tmp` overflows int (undefined in C;
+     * the two's-complement wrap is what a plain sub / sar pair computes): written out with unsigned arithmetic
+     * here so that no optimiser can pick another answer.  Only reachable more than 385 full scales below zero. */
     if (tmp & 0xf0000)
-        tmp = (0x43c0ffff - tmp) >> 31;
+        tmp = (int32_t)(0x43c0ffffu - (uint32_t)tmp) >> 31;
     return (int16_t)(tmp - 0x8000);
 }
 
