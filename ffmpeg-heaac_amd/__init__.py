@@ -100,7 +100,7 @@ EXPORTED = [
     # heaac_dsp.h
     "heaac_device_create", "heaac_device_destroy", "heaac_device_workspace_bytes",
     "heaac_strerror", "heaac_imdct_half_batch", "heaac_lc_decode_batch",
-    "heaac_he_decode_batch", "heaac_qmf_analysis_batch", "heaac_qmf_synthesis_batch",
+    "heaac_he_decode_batch", "heaac_he_decode_batch_ex", "heaac_qmf_analysis_batch", "heaac_qmf_synthesis_batch",
     "heaac_qmf_synthesis_ds_batch",
     "heaac_sbr_make_header", "heaac_build_info", "heaac_spectral_tools_batch",
     "heaac_validate_frame", "heaac_he_check_batch",
@@ -302,7 +302,8 @@ class Device:
         return int(first.value), BAD_RULES[rule.value] if 0 <= rule.value < len(BAD_RULES) else str(rule.value)
 
     def he_decode(self, cfg, coeffs, ics, sbr, hdr, ps, state_in, state_out=None, pcm=None,
-                  pcm_format=PCM_F32):
+                  pcm_format=PCM_F32, downsampled=False):
+        """downsampled: HEAAC_HE_DOWNSAMPLED -- output at the core rate, 1024 samples per channel."""
         import torch
         n = coeffs.shape[0]
         # a wrong-length tensor would be a silent device out-of-bounds read: check them all here
@@ -318,15 +319,18 @@ class Device:
             state_out = torch.empty_like(state_in)
         else:
             assert state_out.dtype == torch.float32 and state_out.numel() == state_in.numel(), "state_out"
+        length = 1024 if downsampled else 2048
         if pcm is None:
             if pcm_format == PCM_F32:
-                pcm = torch.empty((n, OUT_CH[cfg], 2048), dtype=torch.float32, device=coeffs.device)
+                pcm = torch.empty((n, OUT_CH[cfg], length), dtype=torch.float32, device=coeffs.device)
             else:
-                pcm = torch.empty((n, 2048, OUT_CH[cfg]), dtype=torch.int16, device=coeffs.device)
+                pcm = torch.empty((n, length, OUT_CH[cfg]), dtype=torch.int16, device=coeffs.device)
+        else:
+            assert pcm.numel() == n * OUT_CH[cfg] * length, "pcm"
         n_hdr = hdr.numel() // SBR_HDR_DT.itemsize
-        _check(lib().heaac_he_decode_batch(self._h, cfg, _ptr(coeffs), _ptr(ics), _ptr(sbr), _ptr(hdr),
-                                           C.c_size_t(n_hdr), _ptr(ps), _ptr(state_in), _ptr(state_out),
-                                           _ptr(pcm), pcm_format, C.c_size_t(n), _stream()),
+        _check(lib().heaac_he_decode_batch_ex(self._h, cfg, 1 if downsampled else 0, _ptr(coeffs), _ptr(ics), _ptr(sbr),
+                                              _ptr(hdr), C.c_size_t(n_hdr), _ptr(ps), _ptr(state_in), _ptr(state_out),
+                                              _ptr(pcm), pcm_format, C.c_size_t(n), _stream()),
                "heaac_he_decode_batch")
         return pcm, state_out
 

@@ -192,6 +192,15 @@ extern "C" int heaac_spectral_tools_batch(HeaacDevice *dev, int channels, float 
                                        (hipStream_t)stream);
 }
 
+extern "C" int heaac_he_decode_batch_ex(HeaacDevice *dev, int cfg, int flags,
+                                        const float *d_coeffs, const HeaacIcs *d_ics,
+                                        const HeaacSbrFrame *d_sbr,
+                                        const HeaacSbrHeader *d_hdr, size_t n_hdr,
+                                        const HeaacPsFrame *d_ps,
+                                        const float *d_state_in, float *d_state_out,
+                                        void *d_pcm, int pcm_format,
+                                        size_t n, void *stream);
+
 extern "C" int heaac_he_decode_batch(HeaacDevice *dev, int cfg,
                                      const float *d_coeffs, const HeaacIcs *d_ics,
                                      const HeaacSbrFrame *d_sbr,
@@ -201,8 +210,22 @@ extern "C" int heaac_he_decode_batch(HeaacDevice *dev, int cfg,
                                      void *d_pcm, int pcm_format,
                                      size_t n, void *stream)
 {
+    return heaac_he_decode_batch_ex(dev, cfg, 0, d_coeffs, d_ics, d_sbr, d_hdr, n_hdr, d_ps, d_state_in, d_state_out,
+                                    d_pcm, pcm_format, n, stream);
+}
+
+extern "C" int heaac_he_decode_batch_ex(HeaacDevice *dev, int cfg, int flags,
+                                     const float *d_coeffs, const HeaacIcs *d_ics,
+                                     const HeaacSbrFrame *d_sbr,
+                                     const HeaacSbrHeader *d_hdr, size_t n_hdr,
+                                     const HeaacPsFrame *d_ps,
+                                     const float *d_state_in, float *d_state_out,
+                                     void *d_pcm, int pcm_format,
+                                     size_t n, void *stream)
+{
     if (!dev || (cfg != HEAAC_CFG_HEV1 && cfg != HEAAC_CFG_HEV1_MONO && cfg != HEAAC_CFG_HEV2) ||
-        (pcm_format != HEAAC_PCM_F32_PLANAR && pcm_format != HEAAC_PCM_S16_INTERLEAVED))
+        (pcm_format != HEAAC_PCM_F32_PLANAR && pcm_format != HEAAC_PCM_S16_INTERLEAVED) ||
+        (flags & ~HEAAC_HE_DOWNSAMPLED))
         return HEAAC_ERR_ARG;
     if (n == 0)
         return HEAAC_OK;
@@ -213,7 +236,8 @@ extern "C" int heaac_he_decode_batch(HeaacDevice *dev, int cfg,
     const int nout  = cfg == HEAAC_CFG_HEV1_MONO ? 1 : 2;
     const size_t words = cfg == HEAAC_CFG_HEV1 ? HEAAC_STATE_WORDS_HEV1 :
                          cfg == HEAAC_CFG_HEV2 ? HEAAC_STATE_WORDS_HEV2 : HEAAC_STATE_WORDS_HEV1_MONO;
-    const size_t pcm_bytes = (size_t)nout * 2048 * (pcm_format == HEAAC_PCM_F32_PLANAR ? 4 : 2);
+    const size_t pcm_bytes = (size_t)nout * ((flags & HEAAC_HE_DOWNSAMPLED) ? 1024 : 2048) *
+                             (pcm_format == HEAAC_PCM_F32_PLANAR ? 4 : 2);
     const size_t set_floats = dev->chunk * (WS_W_FLOATS + WS_X_FLOATS);
     hipStream_t s = (hipStream_t)stream;
     // one chunk: everything on the caller's stream; more: fork onto the two lanes and join again
@@ -237,7 +261,7 @@ extern "C" int heaac_he_decode_batch(HeaacDevice *dev, int cfg,
                              d_sbr + f0, d_hdr, (unsigned)(n_hdr > 0xffffu ? 0x10000u : n_hdr), d_ps ? d_ps + f0 : NULL,
                              d_state_in + f0 * words, d_state_out + f0 * words,
                              (char *)d_pcm + f0 * pcm_bytes, pcm_format,
-                             ws_W, ws_X, dev->d_queue + 16 * k, nc, 0, lanes ? dev->lane[k] : s);
+                             ws_W, ws_X, dev->d_queue + 16 * k, nc, 0, flags, lanes ? dev->lane[k] : s);
     }
     if (lanes) {
         // always rejoin, also after a failed launch (a capture must not be left forked)

@@ -562,57 +562,108 @@ void k_qmf_synthesis(const float *__restrict__ g_tab, const float *__restrict__ 
 // the slots' 128-point IMDCTs (one per slot), then every lane forms two output samples per pass:
 // lane = (slot parity, n).
 #define DS_STRIDE 65
+struct SynDsLds {
+    float win[320];               // sbr_qmf_window_ds
+    float rot[64], c16[8], c32[12];
+    float vb[SYN_WAVES][41 * DS_STRIDE];
+};
+__device__ __forceinline__ void syn_ds_lds_init(SynDsLds &S, const float *g_tab)
+{
+    for (int i = threadIdx.x; i < 320; i += blockDim.x) S.win[i] = g_tab[TB_QMF_DS + i];
+    if (threadIdx.x < 64) S.rot[threadIdx.x] = g_tab[TB_ROT128S + threadIdx.x];
+    if (threadIdx.x < 5) S.c16[threadIdx.x] = g_tab[TB_COS16 + threadIdx.x];
+    if (threadIdx.x < 9) S.c32[threadIdx.x] = g_tab[TB_COS32 + threadIdx.x];
+    __syncthreads();
+}
+
+// One channel of the downsampled bank.  X0 / X1: re / im planes, row stride 64 (bands 0..31 used);
+// v_in / v_out: 576 floats; emit(i, n, value) receives out[32 i + n].
+template <class Emit>
+__device__ __forceinline__ void synth_ds_channel(const SynDsLds &S, float *vb, const float *X0, const float *X1,
+                                                 const float *v_in, float *v_out, float scale, float bias,
+                                                 int lane, Emit emit)
+{
+    // history: 9 slots of 64 behind the 32 new ones
+    for (int t = lane; t < 576; t += WAVE) vb[(32 + (t >> 6)) * DS_STRIDE + (t & 63)] = v_in[t];
+    if (lane < 32) {
+        const int i = lane;
+        const float *r0 = X0 + i * 64, *r1 = X1 + i * 64;
+        float o[64];
+        // X[0][i][n] = -X[0][i][n]; X[0][i][32+n] = X[1][i][31-n]
+        imdct128_reg([&](int j) -> float { return j < 32 ? -r0[j] : r1[63 - j]; }, o, S.rot, S.c16, S.c32);
+        float *v = vb + (31 - i) * DS_STRIDE;
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            v[k]      =  o[63 - 2 * k];
+            v[63 - k] = -o[62 - 2 * k];
+        }
+    }
+    wave_sync();
+    {
+        const int nn = lane & 31, par = lane >> 5;
+        float wt[10];
+#pragma unroll
+        for (int j = 0; j < 10; j++) wt[j] = S.win[32 * j + nn];
+        const bool scale_and_bias = scale != 1.0f || bias != 0.0f;
+        for (int i = par; i < 32; i += 2) {
+            const float *v = vb + (31 - i) * DS_STRIDE + nn;
+            float acc = v[0] * wt[0] + 0.0f;
+#pragma unroll
+            for (int j = 1; j < 10; j++) acc = v[j * DS_STRIDE + ((j & 1) ? 32 : 0)] * wt[j] + acc;
+            if (scale_and_bias) acc = acc * scale + bias;
+            emit(i, nn, acc);
+        }
+    }
+    for (int t = lane; t < 576; t += WAVE) v_out[t] = vb[(t >> 6) * DS_STRIDE + (t & 63)];
+    wave_sync();
+}
+
 __global__ __launch_bounds__(SYN_WAVES * WAVE)
 void k_qmf_synthesis_ds(const float *__restrict__ g_tab, const float *__restrict__ g_X /* [n][2][32][64] */,
                         const float *g_v_in, float *g_v_out, float *__restrict__ g_out,
                         float scale, float bias, unsigned long long n)
 {
-    __shared__ float s_win[320];
-    __shared__ float s_rot[64], s_c16[8], s_c32[12];
-    __shared__ float s_vb[SYN_WAVES][41 * DS_STRIDE];
-    for (int i = threadIdx.x; i < 320; i += blockDim.x) s_win[i] = g_tab[TB_QMF_DS + i];
-    if (threadIdx.x < 64) s_rot[threadIdx.x] = g_tab[TB_ROT128S + threadIdx.x];
-    if (threadIdx.x < 5) s_c16[threadIdx.x] = g_tab[TB_COS16 + threadIdx.x];
-    if (threadIdx.x < 9) s_c32[threadIdx.x] = g_tab[TB_COS32 + threadIdx.x];
-    __syncthreads();
+    __shared__ SynDsLds S;
+    syn_ds_lds_init(S, g_tab);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
-    float *vb = s_vb[wave];
     for (unsigned long long u = (unsigned long long)blockIdx.x * SYN_WAVES + wave; u < n;
          u += (unsigned long long)gridDim.x * SYN_WAVES) {
-        const float *X0 = g_X + u * 4096, *X1 = X0 + 2048;
-        // history: 9 slots of 64 behind the 32 new ones
-        for (int t = lane; t < 576; t += WAVE) vb[(32 + (t >> 6)) * DS_STRIDE + (t & 63)] = g_v_in[u * 576 + t];
-        if (lane < 32) {
-            const int i = lane;
-            const float *r0 = X0 + i * 64, *r1 = X1 + i * 64;
-            float o[64];
-            // X[0][i][n] = -X[0][i][n]; X[0][i][32+n] = X[1][i][31-n]
-            imdct128_reg([&](int j) -> float { return j < 32 ? -r0[j] : r1[63 - j]; }, o, s_rot, s_c16, s_c32);
-            float *v = vb + (31 - i) * DS_STRIDE;
-#pragma unroll
-            for (int k = 0; k < 32; k++) {
-                v[k]      =  o[63 - 2 * k];
-                v[63 - k] = -o[62 - 2 * k];
+        float *o = g_out + u * 1024;
+        synth_ds_channel(S, S.vb[wave], g_X + u * 4096, g_X + u * 4096 + 2048, g_v_in + u * 576, g_v_out + u * 576,
+                         scale, bias, lane, [&](int i, int nn, float v) { o[32 * i + nn] = v; });
+    }
+}
+
+// The downsampled bank inside the HE pipeline (ff_sbr_apply with ext_sample_rate < sbr->sample_rate,
+// aacsbr.c:1719, 1194-1203): one wave per frame, X from the stage workspace, 1024 samples per channel.
+// The ring state is the first 576 words of the channel's synthesis state; the rest passes through.
+template <int FMT>
+__global__ __launch_bounds__(SYN_WAVES * WAVE)
+void k_synth_ds(const float *__restrict__ g_tab, const float *g_X,
+                const float *g_state_in, float *g_state_out, int state_words, int off_syn0,
+                int nout, void *__restrict__ g_pcm, float scale, float bias, unsigned long long n_frames)
+{
+    __shared__ SynDsLds S;
+    syn_ds_lds_init(S, g_tab);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
+    for (unsigned long long f = (unsigned long long)blockIdx.x * SYN_WAVES + wave; f < n_frames;
+         f += (unsigned long long)gridDim.x * SYN_WAVES) {
+        for (int ch = 0; ch < nout; ch++) {
+            const float *X0 = g_X + (f * 2 + ch) * (2 * 38 * 64), *X1 = X0 + 38 * 64;
+            const float *v_in = g_state_in + f * state_words + off_syn0 + ch * HEAAC_ST_SYNTH;
+            float *v_out = g_state_out + f * state_words + off_syn0 + ch * HEAAC_ST_SYNTH;
+            if (v_out != v_in)
+                for (int t = 576 + lane; t < HEAAC_ST_SYNTH; t += WAVE) v_out[t] = v_in[t];
+            if (FMT == HEAAC_PCM_F32_PLANAR) {
+                float *o = reinterpret_cast<float *>(g_pcm) + (f * nout + ch) * 1024;
+                synth_ds_channel(S, S.vb[wave], X0, X1, v_in, v_out, scale, bias, lane,
+                                 [&](int i, int nn, float v) { o[32 * i + nn] = v; });
+            } else {
+                int16_t *o = reinterpret_cast<int16_t *>(g_pcm) + f * 1024 * nout + ch;
+                synth_ds_channel(S, S.vb[wave], X0, X1, v_in, v_out, scale, bias, lane,
+                                 [&](int i, int nn, float v) { o[(32 * i + nn) * nout] = (int16_t)float_to_int16_one(v); });
             }
         }
-        wave_sync();
-        {
-            const int nn = lane & 31, par = lane >> 5;
-            float wt[10];
-#pragma unroll
-            for (int j = 0; j < 10; j++) wt[j] = s_win[32 * j + nn];
-            const bool scale_and_bias = scale != 1.0f || bias != 0.0f;
-            for (int i = par; i < 32; i += 2) {
-                const float *v = vb + (31 - i) * DS_STRIDE + nn;
-                float acc = v[0] * wt[0] + 0.0f;
-#pragma unroll
-                for (int j = 1; j < 10; j++) acc = v[j * DS_STRIDE + ((j & 1) ? 32 : 0)] * wt[j] + acc;
-                if (scale_and_bias) acc = acc * scale + bias;
-                g_out[u * 1024 + 32 * i + nn] = acc;
-            }
-        }
-        for (int t = lane; t < 576; t += WAVE) g_v_out[u * 576 + t] = vb[(t >> 6) * DS_STRIDE + (t & 63)];
-        wave_sync();
     }
 }
 
@@ -641,7 +692,7 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
                                const float *d_state_in, float *d_state_out,
                                void *d_pcm, int pcm_format,
                                float *d_ws_W, float *d_ws_X, unsigned *d_queue,
-                               size_t n, size_t pcm_frame0, hipStream_t s)
+                               size_t n, size_t pcm_frame0, int flags, hipStream_t s)
 {
     const int ncore = cfg == HEAAC_CFG_HEV1 ? 2 : 1;
     const int nout  = cfg == HEAAC_CFG_HEV1_MONO ? 1 : 2;
@@ -683,6 +734,17 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
         }
     }
     const float scale = -1024 * sf_scale, bias = HEAAC_ADD_BIAS;
+    if (flags & HEAAC_HE_DOWNSAMPLED) {
+        const dim3 gd(he_grid(n, SYN_WAVES)), bd(SYN_WAVES * WAVE);
+        char *pcm = (char *)d_pcm + pcm_frame0 * nout * 1024 * (pcm_format == HEAAC_PCM_F32_PLANAR ? 4 : 2);
+        if (pcm_format == HEAAC_PCM_F32_PLANAR)
+            hipLaunchKernelGGL((k_synth_ds<HEAAC_PCM_F32_PLANAR>), gd, bd, 0, s, d_tab, d_ws_X, d_state_in, d_state_out,
+                               words, off_syn0, nout, (void *)pcm, scale, bias, (unsigned long long)n);
+        else
+            hipLaunchKernelGGL((k_synth_ds<HEAAC_PCM_S16_INTERLEAVED>), gd, bd, 0, s, d_tab, d_ws_X, d_state_in, d_state_out,
+                               words, off_syn0, nout, (void *)pcm, scale, bias, (unsigned long long)n);
+        return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
+    }
     const dim3 g(he_grid(n, SYN_WAVES_F32)), b(SYN_WAVES_F32 * WAVE);
     if (pcm_format == HEAAC_PCM_F32_PLANAR)
         hipLaunchKernelGGL((k_synth<HEAAC_PCM_F32_PLANAR>), g, b, 0, s, d_tab, d_ws_X, d_state_in, d_state_out,

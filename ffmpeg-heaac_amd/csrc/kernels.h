@@ -24,7 +24,7 @@ int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cfg,
                     const float *d_state_in, float *d_state_out,
                     void *d_pcm, int pcm_format,
                     float *d_ws_W, float *d_ws_X, unsigned *d_queue,
-                    size_t n, size_t pcm_frame0, hipStream_t s);
+                    size_t n, size_t pcm_frame0, int flags, hipStream_t s);
 
 int heaac_launch_ps(const float *d_tab, const HeaacPsFrame *d_ps, const HeaacSbrFrame *d_sbr,
                     const HeaacSbrHeader *d_hdr, unsigned n_hdr, const float *d_state_in, float *d_state_out,

@@ -285,6 +285,22 @@ int heaac_he_decode_batch(HeaacDevice *dev, int cfg,
                           void *d_pcm, int pcm_format,
                           size_t n, void *stream);
 
+/* The same with options.  flags:
+ *   HEAAC_HE_DOWNSAMPLED  the output runs at the CORE rate: ff_sbr_apply selects the 32-band synthesis
+ *                         bank (div = 1, aacsbr.c:1719, 1194-1203) when m4ac.ext_sample_rate <
+ *                         sbr->sample_rate.  d_pcm then holds 1024 samples per channel
+ *                         (F32: [n][out_channels][1024], S16: [n][1024][out_channels]); of each channel's
+ *                         synthesis state the first 576 words are the ring, the rest passes through. */
+enum { HEAAC_HE_DOWNSAMPLED = 1 };
+int heaac_he_decode_batch_ex(HeaacDevice *dev, int cfg, int flags,
+                             const float *d_coeffs, const HeaacIcs *d_ics,
+                             const HeaacSbrFrame *d_sbr,
+                             const HeaacSbrHeader *d_hdr, size_t n_hdr,
+                             const HeaacPsFrame *d_ps,
+                             const float *d_state_in, float *d_state_out,
+                             void *d_pcm, int pcm_format,
+                             size_t n, void *stream);
+
 /* Record validation.  The bitstream parsers live outside this library, so the per-frame records are
  * where malformed data would arrive; the rules are the reference parser's own rejections
  * (read_sbr_grid aacsbr.c:609-745, sbr_make_f_master / sbr_make_f_derived :296-593, ff_ps_read_data

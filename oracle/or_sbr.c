@@ -703,7 +703,7 @@ typedef struct {
     float *W, *Xlow, *Xhigh, *Y, *Xsbr, *X;
 } dump_ptrs;
 
-static int he_frame(int cfg, const float *coeffs, const HeaacIcs *ics,
+static int he_frame(int cfg, int flags, const float *coeffs, const HeaacIcs *ics,
                     const HeaacSbrFrame *fr, const HeaacSbrHeader *hdr_tab, size_t n_hdr,
                     const HeaacPsFrame *ps,
                     const float *st_in, float *st_out, float *ret[2], const dump_ptrs *dp)
@@ -813,7 +813,18 @@ static int he_frame(int cfg, const float *coeffs, const HeaacIcs *ics,
     for (ch = 0; ch < nch; ch++) {
         float v[1152];
         memcpy(v, st_in + off_syn[ch], sizeof(v));
-        qmf_synthesis(ret[ch], s.X[ch], v, HEAAC_ADD_BIAS, -1024 * sf_scale);
+        if (flags & HEAAC_HE_DOWNSAMPLED) {
+            /* downsampled = ext_sample_rate < sbr->sample_rate (aacsbr.c:1719): div = 1, 1024 samples */
+            static float Xds[2][32][64];
+            int i;
+            for (i = 0; i < 32; i++) {
+                memcpy(Xds[0][i], s.X[ch][0][i], sizeof(Xds[0][i]));
+                memcpy(Xds[1][i], s.X[ch][1][i], sizeof(Xds[1][i]));
+            }
+            oracle_qmf_synthesis_ds(&Xds[0][0][0], v, ret[ch], -1024 * sf_scale, HEAAC_ADD_BIAS);
+        } else {
+            qmf_synthesis(ret[ch], s.X[ch], v, HEAAC_ADD_BIAS, -1024 * sf_scale);
+        }
         memcpy(st_out + off_syn[ch], v, sizeof(v));
     }
     return 0;
@@ -835,6 +846,15 @@ int oracle_he_decode_batch(int cfg, const float *coeffs, const HeaacIcs *ics,
                            const float *state_in, float *state_out,
                            void *pcm, int pcm_format, size_t n)
 {
+    return oracle_he_decode_batch_ex(cfg, 0, coeffs, ics, sbr, hdr, n_hdr, ps, state_in, state_out, pcm, pcm_format, n);
+}
+
+int oracle_he_decode_batch_ex(int cfg, int flags, const float *coeffs, const HeaacIcs *ics,
+                              const HeaacSbrFrame *sbr, const HeaacSbrHeader *hdr, size_t n_hdr,
+                              const HeaacPsFrame *ps,
+                              const float *state_in, float *state_out,
+                              void *pcm, int pcm_format, size_t n)
+{
     const int words = cfg_words(cfg);
     const int ncore = (cfg == HEAAC_CFG_HEV1) ? 2 : 1;
     const int nout = (cfg == HEAAC_CFG_HEV1_MONO) ? 1 : 2;
@@ -854,12 +874,12 @@ int oracle_he_decode_batch(int cfg, const float *coeffs, const HeaacIcs *ics,
             memcpy(tmp, sin_, words * sizeof(float));
             sin_ = tmp;
         }
-        r = he_frame(cfg, coeffs + f * ncore * 1024, ics + f * ncore, &sbr[f], hdr, n_hdr,
+        r = he_frame(cfg, flags, coeffs + f * ncore * 1024, ics + f * ncore, &sbr[f], hdr, n_hdr,
                      ps ? &ps[f] : NULL, sin_, sout, ret, NULL);
         free(tmp);
         if (r < 0)
             return r;
-        or_store_pcm(pcm, pcm_format, f, nout, 2048, ret);
+        or_store_pcm(pcm, pcm_format, f, nout, (flags & HEAAC_HE_DOWNSAMPLED) ? 1024 : 2048, ret);
     }
     return 0;
 }
@@ -880,7 +900,7 @@ int oracle_he_decode_debug(int cfg, const float *coeffs, const HeaacIcs *ics,
     if (cfg_words(cfg) < 0)
         return HEAAC_ERR_ARG;
     oracle_tables();
-    r = he_frame(cfg, coeffs, ics, sbr, hdr, 0, ps, state_in, state_out, ret, &dp);
+    r = he_frame(cfg, 0, coeffs, ics, sbr, hdr, 0, ps, state_in, state_out, ret, &dp);
     if (r < 0)
         return r;
     if (pcm_f32)

@@ -102,6 +102,13 @@ int oracle_he_decode_batch(int cfg, const float *coeffs, const HeaacIcs *ics,
                            const float *state_in, float *state_out,
                            void *pcm, int pcm_format, size_t n);
 
+/* flags: HEAAC_HE_DOWNSAMPLED = the 32-band synthesis bank (aacsbr.c:1719, 1194-1203), 1024 samples per channel */
+int oracle_he_decode_batch_ex(int cfg, int flags, const float *coeffs, const HeaacIcs *ics,
+                              const HeaacSbrFrame *sbr, const HeaacSbrHeader *hdr, size_t n_hdr,
+                              const HeaacPsFrame *ps,
+                              const float *state_in, float *state_out,
+                              void *pcm, int pcm_format, size_t n);
+
 /* Same, but also dumps stage boundaries of frame 0 of the batch (NULL = skip):
  *   dump_W    [ch][32][32][2]   after sbr_qmf_analysis
  *   dump_X    [2][2][38][64]    X[ch][re/im][slot][band] before synthesis

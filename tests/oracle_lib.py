@@ -204,7 +204,7 @@ def spectral_tools_batch(channels, coeffs, tools, rng=None, pred=None):
     return res[0] if len(res) == 1 else res
 
 
-def he_decode_batch(cfg, coeffs, ics, sbr, hdr, ps, state_in, pcm_format=PCM_F32):
+def he_decode_batch(cfg, coeffs, ics, sbr, hdr, ps, state_in, pcm_format=PCM_F32, downsampled=False):
     coeffs = _f32(coeffs)
     n = coeffs.shape[0]
     ics = np.ascontiguousarray(ics, dtype=ICS_DT)
@@ -215,11 +215,12 @@ def he_decode_batch(cfg, coeffs, ics, sbr, hdr, ps, state_in, pcm_format=PCM_F32
     state_in = _f32(state_in)
     assert state_in.shape == (n, STATE_WORDS[cfg]), (state_in.shape, STATE_WORDS[cfg])
     state_out = np.zeros_like(state_in)
+    length = 1024 if downsampled else 2048
     if pcm_format == PCM_F32:
-        pcm = np.zeros((n, OUT_CH[cfg], 2048), np.float32)
+        pcm = np.zeros((n, OUT_CH[cfg], length), np.float32)
     else:
-        pcm = np.zeros((n, 2048, OUT_CH[cfg]), np.int16)
-    r = lib().oracle_he_decode_batch(C.c_int(cfg), _p(coeffs), _p(ics), _p(sbr), _p(hdr),
+        pcm = np.zeros((n, length, OUT_CH[cfg]), np.int16)
+    r = lib().oracle_he_decode_batch_ex(C.c_int(cfg), C.c_int(1 if downsampled else 0), _p(coeffs), _p(ics), _p(sbr), _p(hdr),
                                      C.c_size_t(hdr.shape[0]), _p(ps), _p(state_in), _p(state_out),
                                      _p(pcm), C.c_int(pcm_format), C.c_size_t(n))
     if r:

@@ -69,7 +69,7 @@ def test_qmf_synthesis_downsampled_batch(pkg, oracle, dev, n):
 
 
 def _run_chain(pkg, oracle, dev, cfg, n, steps, seed, hdr, ps_mode="20", hdr_choice=None, fmt=None,
-               check_state=True, coupling=0.0, events=None, in_place=False):
+               check_state=True, coupling=0.0, events=None, in_place=False, downsampled=False):
     import torch
     synth = _synth()
     rng = np.random.default_rng(seed)
@@ -84,11 +84,13 @@ def _run_chain(pkg, oracle, dev, cfg, n, steps, seed, hdr, ps_mode="20", hdr_cho
         seen["drop"] += int(((fr["sbr"]["start"] == 0) & (fr["sbr"]["hdr"] != len(hdr) - 1)).sum())
         seen["reset"] += int((fr["sbr"]["reset"] == 1).sum()) if step else 0
         seen["ps_off"] += int((fr["ps"]["start"] == 0).sum()) if fr["ps"] is not None else 0
-        ref_pcm, state = oracle.he_decode_batch(cfg, fr["coeffs"], fr["ics"], fr["sbr"], hdr, fr["ps"], state, fmt)
+        ref_pcm, state = oracle.he_decode_batch(cfg, fr["coeffs"], fr["ics"], fr["sbr"], hdr, fr["ps"], state, fmt,
+                                                downsampled=downsampled)
         pcm, d_state = dev.he_decode(cfg, torch.from_numpy(fr["coeffs"]).cuda(), pkg.to_device(fr["ics"]),
                                      pkg.to_device(fr["sbr"]), d_hdr,
                                      pkg.to_device(fr["ps"]) if fr["ps"] is not None else None,
-                                     d_state, state_out=d_state if in_place else None, pcm_format=fmt)
+                                     d_state, state_out=d_state if in_place else None, pcm_format=fmt,
+                                     downsampled=downsampled)
         got = pcm.cpu().numpy()
         if fmt == pkg.PCM_F32:
             nbad, where = _mismatch(got, ref_pcm)
@@ -305,3 +307,14 @@ def test_hev2_degrade_paths_s16(pkg, oracle, dev):
     n = 40
     _run_chain(pkg, oracle, dev, pkg.CFG_HEV2, n, 6, 63, hdr, ps_mode="mix",
                hdr_choice=np.arange(n) % (len(hdr) - 1), events=EVENTS, fmt=pkg.PCM_S16)
+
+
+@pytest.mark.parametrize("cfgname,fmtname,in_place", [("CFG_HEV1", "PCM_F32", False), ("CFG_HEV2", "PCM_S16", True),
+                                                       ("CFG_HEV1_MONO", "PCM_S16", False)])
+def test_downsampled_output_inside_the_decode_call(pkg, oracle, dev, cfgname, fmtname, in_place):
+    """ff_sbr_apply with ext_sample_rate < sbr->sample_rate (aacsbr.c:1719): the 32-band synthesis bank
+    (div = 1, :1194-1203), 1024 samples per channel, ring state in the first 576 words."""
+    hdr = _synth().default_headers(pkg, extra=True)
+    n = 40
+    _run_chain(pkg, oracle, dev, getattr(pkg, cfgname), n, 4, 71, hdr, ps_mode="mix", hdr_choice=np.arange(n) % len(hdr),
+               fmt=getattr(pkg, fmtname), in_place=in_place, downsampled=True)
