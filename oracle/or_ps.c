@@ -346,8 +346,8 @@ static void remap(int to34, int8_t (*dst)[34], const int8_t *src, int stride,
 static void decorrelation(ps_ctx *ps, float (*out)[32][2], const float (*s)[32][2], int is34, int is34_old)
 {
     const or_tables *t = oracle_tables();
-    static float power[34][32];
-    static float transient_gain[34][32];
+    static __thread float power[34][32];          /* (thread-local: the CPU baseline runs the oracle on all cores) */
+    static __thread float transient_gain[34][32];
     float *peak_decay_nrg = ps->peak_decay_nrg;
     float *power_smooth = ps->power_smooth;
     float *peak_decay_diff_smooth = ps->peak_decay_diff_smooth;
@@ -593,8 +593,8 @@ static void stereo_processing(const HeaacPsFrame *p, ps_ctx *ps, float (*l)[32][
 /* ff_ps_apply, aacps.c:973-992, on the packed state record (in place). */
 void or_ps_apply(const HeaacPsFrame *p, float *st, float L[2][38][64], float R[2][38][64], int top)
 {
-    static ps_ctx ps;
-    static float Lbuf[91][32][2], Rbuf[91][32][2];
+    static __thread ps_ctx ps;
+    static __thread float Lbuf[91][32][2], Rbuf[91][32][2];
     const int len = 32;
     const int is34 = p->is34bands;
     int i, k, m, j, c;

@@ -133,8 +133,8 @@ static void qmf_analysis(const float *in, float *x, float W[2][32][32][2], float
 
 void oracle_qmf_analysis(const float *in, float *xhist, float *Wout, float scale)
 {
-    static float x[1312];
-    static float W[2][32][32][2];
+    static __thread float x[1312];
+    static __thread float W[2][32][32][2];
     memset(W, 0, sizeof(W));
     memcpy(x + 1024, xhist, 288 * sizeof(float));
     qmf_analysis(in, x, W, scale);
@@ -183,7 +183,7 @@ static void qmf_synthesis(float *out, float X[2][38][64], float *vstate, float b
 
 void oracle_qmf_synthesis(const float *Xin, float *v, float *out, float scale, float bias)
 {
-    static float X[2][38][64];
+    static __thread float X[2][38][64];
     int p, i;
     memset(X, 0, sizeof(X));
     for (p = 0; p < 2; p++)
@@ -712,8 +712,8 @@ static int he_frame(int cfg, int flags, const float *coeffs, const HeaacIcs *ics
     const int ncore = cpe ? 2 : 1;
     const int with_ps = (cfg == HEAAC_CFG_HEV2);
     const HeaacSbrHeader *h;
-    static sbr_ch d[2];
-    static sbr_scratch s;
+    static __thread sbr_ch d[2];                  /* (thread-local: the CPU baseline runs the oracle on all cores) */
+    static __thread sbr_scratch s;
     int ch, nch;
     /* state record sub-offsets */
     size_t off_saved[2], off_sbr[2], off_syn[2], off_ps = 0;
@@ -815,7 +815,7 @@ static int he_frame(int cfg, int flags, const float *coeffs, const HeaacIcs *ics
         memcpy(v, st_in + off_syn[ch], sizeof(v));
         if (flags & HEAAC_HE_DOWNSAMPLED) {
             /* downsampled = ext_sample_rate < sbr->sample_rate (aacsbr.c:1719): div = 1, 1024 samples */
-            static float Xds[2][32][64];
+            static __thread float Xds[2][32][64];
             int i;
             for (i = 0; i < 32; i++) {
                 memcpy(Xds[0][i], s.X[ch][0][i], sizeof(Xds[0][i]));
