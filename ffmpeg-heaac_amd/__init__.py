@@ -115,6 +115,9 @@ EXPORTED = [
     # heaac_parse.h
     "heaac_asc_parse", "heaac_adts_parse_header", "heaac_aac_parse_frame", "heaac_aac_parse_batch",
     "heaac_aac_tables_fingerprint",
+    "heaac_sbr_table_create", "heaac_sbr_table_destroy", "heaac_sbr_table_count", "heaac_sbr_table_data",
+    "heaac_sbr_stream_init", "heaac_sbr_stream_bytes", "heaac_sbr_parse_payload", "heaac_sbr_no_payload",
+    "heaac_heaac_parse_frame", "heaac_heaac_parse_batch", "heaac_sbr_tables_fingerprint",
 ]
 
 
@@ -414,5 +417,95 @@ def aac_parse_batch(cfg, streams, aus, threads=0):
                                          out["coeffs"].ctypes.data_as(C.c_void_p), out["ics"].ctypes.data_as(C.c_void_p),
                                          out["tools"].ctypes.data_as(C.c_void_p), out["info"].ctypes.data_as(C.c_void_p),
                                          out["status"].ctypes.data_as(C.c_void_p), C.c_int(threads))
+    out["failed"] = failed
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# heaac_parse.h, second slice: SBR / PS payloads
+# ---------------------------------------------------------------------------------------------
+SBR_PARSE_INFO_DT = np.dtype([("sbr_bits", "<i4"), ("header", "<i4"), ("ps_present", "<i4"), ("ps_status", "<i4")])
+PARSE_NO_SBR = 1
+
+
+class SbrHeaderTable:
+    """heaac_sbr_table_*: the batch's table of derived SBR headers (entry 0 = the null header)."""
+
+    def __init__(self, capacity=256):
+        L = lib()
+        L.heaac_sbr_table_create.restype = C.c_void_p
+        L.heaac_sbr_table_count.restype = C.c_size_t
+        L.heaac_sbr_table_data.restype = C.c_void_p
+        self._h = L.heaac_sbr_table_create(C.c_size_t(capacity))
+        if not self._h:
+            raise HeaacError("heaac_sbr_table_create failed")
+
+    def __len__(self):
+        return int(lib().heaac_sbr_table_count(C.c_void_p(self._h)))
+
+    def headers(self):
+        """Copy of the entries so far as an SBR_HDR_DT array (what he_decode takes as `hdr`)."""
+        n = len(self)
+        addr = lib().heaac_sbr_table_data(C.c_void_p(self._h))
+        buf = (C.c_uint8 * (n * SBR_HDR_DT.itemsize)).from_address(addr)
+        return np.frombuffer(bytes(buf), dtype=SBR_HDR_DT).copy()
+
+    def close(self):
+        if self._h:
+            lib().heaac_sbr_table_destroy(C.c_void_p(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sbr_streams(n):
+    """n fresh HeaacSbrStream records (opaque bytes, heaac_sbr_stream_init)."""
+    L = lib()
+    L.heaac_sbr_stream_bytes.restype = C.c_size_t
+    st = np.zeros((n, int(L.heaac_sbr_stream_bytes())), np.uint8)
+    L.heaac_sbr_stream_init(st.ctypes.data_as(C.c_void_p), C.c_size_t(n))
+    return st
+
+
+def sbr_parse_payload(stream, table, sample_rate, payload, channels, allow_ps, crc=False, bit=0, cnt=None):
+    """heaac_sbr_parse_payload on ONE stream record (a row of sbr_streams()).  `payload`: the bytes that
+    follow the 4-bit extension type when bit = 0 (tests), or a whole access unit with `bit` set.
+    Returns (status, sbr record, ps record, info)."""
+    assert stream.dtype == np.uint8 and stream.flags["C_CONTIGUOUS"]
+    payload = bytes(payload)
+    sbr = np.zeros(1, SBR_FRAME_DT)
+    ps = np.zeros(1, PS_FRAME_DT)
+    info = np.zeros(1, SBR_PARSE_INFO_DT)
+    r = lib().heaac_sbr_parse_payload(stream.ctypes.data_as(C.c_void_p), C.c_void_p(table._h), C.c_int(sample_rate),
+                                      payload, C.c_int(len(payload)), C.c_int(bit),
+                                      C.c_int(len(payload) if cnt is None else cnt), C.c_int(bool(crc)),
+                                      C.c_int(channels), C.c_int(bool(allow_ps)),
+                                      sbr.ctypes.data_as(C.c_void_p), ps.ctypes.data_as(C.c_void_p),
+                                      info.ctypes.data_as(C.c_void_p))
+    return r, sbr, ps, info[0]
+
+
+def heaac_parse_batch(cfg, streams, sbr_st, table, aus, threads=0, with_ps=False):
+    """heaac_heaac_parse_batch: whole HE-AAC access units, one per stream.  streams: AAC_STREAM_DT [n],
+    sbr_st: sbr_streams(n); both updated in place.  Returns the dict of aac_parse_batch plus sbr [n], ps [n]."""
+    n = len(aus)
+    keep = [C.create_string_buffer(bytes(a), len(a)) for a in aus]
+    ptrs = (C.c_char_p * n)(*[C.cast(k, C.c_char_p) for k in keep])
+    sizes = (C.c_int * n)(*[len(a) for a in aus])
+    out = dict(coeffs=np.zeros((n, 2, 1024), np.float32), ics=np.zeros((n, 2), ICS_DT),
+               tools=np.zeros(n, TOOLS_FRAME_DT), info=np.zeros(n, AAC_INFO_DT), status=np.zeros(n, np.int32),
+               sbr=np.zeros(n, SBR_FRAME_DT), ps=np.zeros(n, PS_FRAME_DT))
+    assert streams.dtype == AAC_STREAM_DT and streams.shape == (n,) and sbr_st.shape[0] == n
+    failed = lib().heaac_heaac_parse_batch(
+        C.byref(cfg), streams.ctypes.data_as(C.c_void_p), sbr_st.ctypes.data_as(C.c_void_p), C.c_void_p(table._h),
+        ptrs, sizes, C.c_size_t(n),
+        out["coeffs"].ctypes.data_as(C.c_void_p), out["ics"].ctypes.data_as(C.c_void_p),
+        out["tools"].ctypes.data_as(C.c_void_p), out["sbr"].ctypes.data_as(C.c_void_p),
+        out["ps"].ctypes.data_as(C.c_void_p) if with_ps else None,
+        out["info"].ctypes.data_as(C.c_void_p), out["status"].ctypes.data_as(C.c_void_p), C.c_int(threads))
     out["failed"] = failed
     return out

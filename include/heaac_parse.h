@@ -17,8 +17,8 @@
  * Output = exactly what heaac_spectral_tools_batch + heaac_lc_decode_batch (heaac_dsp.h) take: the
  * dequantised, scaled spectrum, the window info of this and the previous frame, and the side info of the
  * spectral tools.  The arithmetic of the dequantisation is the reference's (same products, same order).
- * SBR / PS payloads (fill elements of type EXT_SBR_DATA) are located but not parsed in this slice:
- * their position is reported so that a later SBR parser can take them.
+ * SBR / PS payloads (fill elements of type EXT_SBR_DATA) are located by this slice and parsed by the
+ * second one (heaac_sbr_parse_payload, below).
  */
 #ifndef HEAAC_PARSE_H
 #define HEAAC_PARSE_H
@@ -115,6 +115,130 @@ int heaac_aac_parse_batch(const HeaacAacConfig *cfg, HeaacAacStream *st,
 
 /* SHA-256-free integrity hook for tests: FNV-1a of the generated ISO tables (codes, lengths, band offsets). */
 uint64_t heaac_aac_tables_fingerprint(void);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Second slice: the SBR extension payload and the Parametric Stereo data inside it                   */
+/* ------------------------------------------------------------------------------------------------ */
+/*   heaac_sbr_parse_payload  ff_decode_sbr_extension             aacsbr.c:1044-1090
+ *                            read_sbr_header                     :207-262
+ *                            sbr_reset -> heaac_sbr_make_header  :1022-1033 (tables: sbr_header.c)
+ *                            read_sbr_data, read_sbr_single_channel_element,
+ *                            read_sbr_channel_pair_element       :928-1020
+ *                            read_sbr_grid, copy_sbr_grid, read_sbr_dtdf, read_sbr_invf,
+ *                            read_sbr_envelope, read_sbr_noise   :609-898
+ *                            read_sbr_extension                  :900-926
+ *                            ff_ps_read_data, read_iid/icc/ipdopd_data, ps_read_extension_data
+ *                                                                aacps.c:84-279
+ * Output = the records heaac_he_decode_batch takes (heaac_dsp.h): one HeaacSbrFrame (+ HeaacPsFrame) per
+ * access unit, frames referring by index to a table of derived header records.
+ *
+ * Where this parser is stricter than the reference (each case is malformed input on which the reference
+ * goes on with undefined or non-finite values; here the element is dropped the way the reference drops one
+ * after a grid error -- start = 0, "pure upsampling" -- and the call returns HEAAC_PARSE_ERR_DATA):
+ *   - two SBR time borders coincide (the reference accepts, then divides by zero in sbr_env_estimate);
+ *   - an accumulated envelope / noise scalefactor leaves 0..255 (the record's uint8);
+ *   - explicit PS borders that do not ascend, or an IID envelope carried over from a frame of the finer
+ *     quantiser into one of the coarser (the reference indexes its tables with it) (PS only: ps.start = 0);
+ *   - after a failed element the channel state is rolled back to the previous frame's (the reference keeps
+ *     a half-written one, bs_num_env = 8 included, and indexes with it on the next frame);
+ *   - after a failed sbr_reset the next header resets again (the reference would accept it as "unchanged"
+ *     and read data against half-built tables); the very first header of a stream always resets.
+ * An access unit WITHOUT an SBR payload (the reference re-applies the previous frame's already dequantised
+ * envelopes, i.e. garbage) is reported as HEAAC_PARSE_NO_SBR with a start = 0 record. */
+
+#define HEAAC_PARSE_NO_SBR 1      /* informational: no SBR payload in this access unit */
+
+/* Table of derived SBR headers shared by all streams of a batch: entry 0 is the null header (kx = 32,
+ * m = 0: the decoder before any header, aacsbr.c:130); identical headers share one entry.  Thread-safe;
+ * the storage never moves, so heaac_sbr_table_data() stays valid while entries are added. */
+typedef struct HeaacSbrHeaderTable HeaacSbrHeaderTable;
+HeaacSbrHeaderTable *heaac_sbr_table_create(size_t capacity);          /* capacity <= 65535 */
+void   heaac_sbr_table_destroy(HeaacSbrHeaderTable *t);
+size_t heaac_sbr_table_count(const HeaacSbrHeaderTable *t);
+const HeaacSbrHeader *heaac_sbr_table_data(const HeaacSbrHeaderTable *t);
+
+/* What SBRData (sbr.h:62-105) carries from frame to frame */
+typedef struct HeaacSbrChanState {
+    uint8_t bs_num_env;           /* of the last parsed frame; 0 before any */
+    uint8_t bs_num_noise;
+    uint8_t bs_amp_res;
+    uint8_t bs_frame_class;
+    int8_t  e_a[2];               /* e_a[1] = -1 in a new stream */
+    uint8_t bs_add_harmonic_flag;
+    uint8_t t_env_num_env_old;
+    uint8_t bs_freq_res[8];
+    uint8_t t_env[8];
+    uint8_t t_q[3];
+    uint8_t bs_df_env[5];
+    uint8_t bs_df_noise[2];
+    uint8_t bs_invf_mode[2][5];
+    uint8_t bs_add_harmonic[48];
+    int32_t env_facs[6][48];      /* accumulated integers; row 0 = the last envelope of the previous frame */
+    int32_t noise_facs[3][5];
+} HeaacSbrChanState;
+
+/* PSContext (aacps.h:41-61) bitstream side */
+typedef struct HeaacPsState {
+    uint8_t start, enable_iid, iid_quant, nr_iid_par, nr_ipdopd_par, enable_icc, icc_mode, nr_icc_par;
+    uint8_t enable_ext, frame_class, num_env_old, num_env, enable_ipdopd, is34bands, is34bands_old, pad;
+    int8_t  border_position[8];
+    int8_t  iid_par[5][34], icc_par[5][34], ipd_par[5][34], opd_par[5][34];
+} HeaacPsState;
+
+/* SpectralBandReplication (sbr.h:112-160) bitstream side.  heaac_sbr_stream_init() for a new stream. */
+typedef struct HeaacSbrStream {
+    uint8_t start, reset, have_spectrum, bs_coupling;
+    uint8_t bs_start_freq, bs_stop_freq, bs_xover_band, bs_freq_scale, bs_alter_scale, bs_noise_bands;
+    uint8_t bs_amp_res_header, bs_limiter_bands, bs_limiter_gains, bs_interpol_freq, bs_smoothing_mode;
+    uint8_t pad;
+    uint8_t kx[2], m[2];
+    uint32_t hdr;                 /* index of the current header in the table (0 = none yet) */
+    HeaacSbrChanState data[2];
+    HeaacPsState ps;
+} HeaacSbrStream;
+
+void   heaac_sbr_stream_init(HeaacSbrStream *st, size_t n);
+size_t heaac_sbr_stream_bytes(void);
+
+typedef struct HeaacSbrParseInfo {
+    int sbr_bits;                 /* num_sbr_bits of ff_decode_sbr_extension, crc and header included */
+    int header;                   /* 1: the payload carried a header */
+    int ps_present;               /* 1: a PS extension was read */
+    int ps_status;                /* HEAAC_PARSE_OK or the PS reader's error (then ps.start = 0) */
+} HeaacSbrParseInfo;
+
+/* One SBR payload: `bit` = position in `au` just after the 4-bit extension type (HeaacAacFrameInfo.
+ * sbr_payload_bit), cnt = the fill element's byte count, crc = EXT_SBR_DATA_CRC, channels = 1 (SCE) or
+ * 2 (CPE), allow_ps = m4ac.ps != 0.  `ps` may be NULL when allow_ps is 0.  sample_rate = the AAC core's
+ * (the SBR tables are built for twice that, aacsbr.c:1056).
+ * Returns HEAAC_PARSE_OK, or a negative error with the records written as described above. */
+int heaac_sbr_parse_payload(HeaacSbrStream *st, HeaacSbrHeaderTable *tab, int sample_rate,
+                            const uint8_t *au, int size, int bit, int cnt, int crc,
+                            int channels, int allow_ps,
+                            HeaacSbrFrame *sbr, HeaacPsFrame *ps, HeaacSbrParseInfo *info);
+
+/* The record of an access unit without an SBR payload (start = 0, header and "old" fields kept). */
+void heaac_sbr_no_payload(HeaacSbrStream *st, int channels, HeaacSbrFrame *sbr, HeaacPsFrame *ps);
+
+/* A whole HE-AAC access unit: heaac_aac_parse_frame, then the SBR payload it located.
+ * Returns the core parser's error if that fails (no SBR record then), else the SBR parser's result
+ * (HEAAC_PARSE_NO_SBR when the unit has none). */
+int heaac_heaac_parse_frame(const HeaacAacConfig *cfg, HeaacAacStream *st, HeaacSbrStream *sst,
+                            HeaacSbrHeaderTable *tab, const uint8_t *au, int size,
+                            float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
+                            HeaacSbrFrame *sbr, HeaacPsFrame *ps, HeaacAacFrameInfo *info);
+
+/* n independent streams, one access unit each, on host threads (see heaac_aac_parse_batch).
+ * sbr [n], ps [n] (NULL unless cfg->ps != 0 and the stream is mono). */
+int heaac_heaac_parse_batch(const HeaacAacConfig *cfg, HeaacAacStream *st, HeaacSbrStream *sst,
+                            HeaacSbrHeaderTable *tab,
+                            const uint8_t *const *au, const int *size, size_t n,
+                            float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
+                            HeaacSbrFrame *sbr, HeaacPsFrame *ps,
+                            HeaacAacFrameInfo *info, int *status, int threads);
+
+/* FNV-1a of the generated SBR / PS Huffman tables (sbr_iso_tables.h). */
+uint64_t heaac_sbr_tables_fingerprint(void);
 
 #ifdef __cplusplus
 }

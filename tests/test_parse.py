@@ -23,8 +23,9 @@ def _cfg(pkg, aot=2, si=3, ch=2):
     return c
 
 
-def _write_au(rng, si, aot, cpe, extras=True):
-    """One access unit + everything the parser must report for it."""
+def _write_au(rng, si, aot, cpe, extras=True, sbr=None):
+    """One access unit + everything the parser must report for it.  sbr = (payload bits, crc): carried in a
+    fill element behind the channel element (extension type 0xd / 0xe, aacdec.c:1655-1678)."""
     bw = W.BitWriter()
     exp = dict(channels=2 if cpe else 1)
     if extras and rng.random() < 0.5:
@@ -73,7 +74,19 @@ def _write_au(rng, si, aot, cpe, extras=True):
         bw.put(0, 3); bw.put(0, 4)
         exp["sf"] = [W.put_ics(bw, ch[0], si, aot, 0)]
     exp["sbr_bit"] = -1
-    if extras and rng.random() < 0.5:
+    if sbr is not None:
+        bits, crc = sbr
+        cnt = (4 + len(bits) + 7) // 8
+        bw.put(6, 3)
+        if cnt >= 15:
+            bw.put(15, 4); bw.put(cnt - 14, 8)
+        else:
+            bw.put(cnt, 4)
+        bw.put(0xe if crc else 0xd, 4)
+        exp["sbr_bit"], exp["sbr_bytes"] = len(bw.bits), cnt
+        bw.bits.extend(bits)
+        bw.bits.extend([0] * (8 * cnt - 4 - len(bits)))
+    elif extras and rng.random() < 0.5:
         # fill element carrying an SBR payload (type 0xd): located, not parsed
         cnt = int(rng.integers(1, 20))
         bw.put(6, 3)

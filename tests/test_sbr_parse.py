@@ -1,0 +1,358 @@
+"""SBR / PS payload parser (include/heaac_parse.h, second slice) against payloads written by
+tests/sbr_bitwriter.py: every record field a decoder must hold after a frame is stated by the writer's own
+model (absolute targets, the coded deltas derived from them) and compared with what the parser returns."""
+import ctypes as C
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import sbr_bitwriter as SW
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return importlib.import_module("ffmpeg-heaac_amd")
+
+
+def _same(a, b, what):
+    for name in a.dtype.names:
+        x, y = a[name], b[name]
+        if x.dtype.names:
+            _same(x, y, what + "." + name)
+        else:
+            assert np.array_equal(x, y), (what + "." + name, x.tolist(), y.tolist())
+
+
+def _run_stream(pkg, rng, channels, ps, frames, ps_modes="any", p_header=0.15, p_respec=0.4, crc=False):
+    tab = pkg.SbrHeaderTable(64)
+    st = pkg.sbr_streams(1)
+    w = SW.SbrStreamWriter(pkg, channels, ps=ps, ps_modes=ps_modes)
+    seen = dict(classes=set(), coupled=set(), reset=0, ps_env=set(), headers=0)
+    for f in range(frames):
+        new = f > 0 and rng.random() < p_header
+        respec = bool(new and rng.random() < p_respec)
+        bits, exp = w.frame(rng, new_header=new, crc=crc, respec=respec)
+        r, sbr, psr, info = pkg.sbr_parse_payload(st[0], tab, 24000, SW.to_bytes(bits), channels, bool(ps), crc=crc,
+                                                  cnt=(len(bits) + 4 + 7) // 8)
+        assert r == 0, (f, r)
+        assert info["sbr_bits"] == len(bits), (f, info, len(bits))
+        got_hdr = tab.headers()[int(sbr["hdr"][0])]
+        assert got_hdr.tobytes() == exp["hdr"][0].tobytes(), f
+        exp["sbr"]["hdr"] = sbr["hdr"]
+        _same(sbr, exp["sbr"], "frame %d sbr" % f)
+        assert pkg.validate_frame(pkg.CFG_HEV2 if channels == 1 else pkg.CFG_HEV1, sbr, tab.headers(),
+                                  psr if ps else None) == "NONE", f
+        if ps:
+            _same(psr, exp["ps"], "frame %d ps" % f)
+            seen["ps_env"].add(int(psr["num_env"][0]))
+        seen["reset"] += exp["reset"]
+        seen["headers"] += int(info["header"])
+        for c in range(channels):
+            seen["classes"].add(w.ch[c].cls)
+        seen["coupled"].add(w.coupling)
+    seen["table"] = len(tab)
+    return seen
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_sce_payloads_with_parametric_stereo(pkg, seed):
+    rng = np.random.default_rng(seed)
+    seen = _run_stream(pkg, rng, 1, True, 120)
+    assert seen["classes"] == {0, 1, 2, 3}
+    assert seen["reset"] >= 2 and seen["headers"] > seen["reset"]
+    assert {1, 2, 3, 4, 5} <= seen["ps_env"]
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_cpe_payloads_coupled_and_not(pkg, seed):
+    rng = np.random.default_rng(seed)
+    seen = _run_stream(pkg, rng, 2, False, 120, crc=seed == 12)
+    assert seen["classes"] == {0, 1, 2, 3} and seen["coupled"] == {0, 1}
+    assert seen["table"] > 2
+
+
+def test_ps_modes_20_and_34(pkg):
+    for modes in ("20", "34"):
+        _run_stream(pkg, np.random.default_rng(5), 1, True, 40, ps_modes=modes)
+
+
+def test_ps_is_stepped_over_when_signalled_absent(pkg):
+    """read_sbr_extension with m4ac.ps == 0 (aacsbr.c:905-909): the PS bits are skipped, the SBR record is
+    unaffected and the PS record says `copy mono`."""
+    rng = np.random.default_rng(9)
+    tab = pkg.SbrHeaderTable(8)
+    st = pkg.sbr_streams(1)
+    w = SW.SbrStreamWriter(pkg, 1, ps=True)
+    for f in range(10):
+        bits, exp = w.frame(rng)
+        r, sbr, psr, info = pkg.sbr_parse_payload(st[0], tab, 24000, SW.to_bytes(bits), 1, False)
+        assert r == 0 and info["ps_present"] == 0 and psr["start"][0] == 0
+        exp["sbr"]["hdr"] = sbr["hdr"]
+        _same(sbr, exp["sbr"], "frame %d" % f)
+
+
+def test_frames_before_the_first_header_and_without_payload(pkg):
+    rng = np.random.default_rng(3)
+    tab = pkg.SbrHeaderTable(8)
+    st = pkg.sbr_streams(1)
+    # a payload without a header on a fresh stream: bs_header_flag = 0, nothing else is read
+    r, sbr, psr, info = pkg.sbr_parse_payload(st[0], tab, 24000, bytes(16), 1, True)
+    assert r == 0 and sbr["start"][0] == 0 and sbr["hdr"][0] == 0 and sbr["kx_old"][0] == 32 and info["sbr_bits"] == 1
+    assert pkg.validate_frame(pkg.CFG_HEV2, sbr, tab.headers(), psr) == "NONE"
+    w = SW.SbrStreamWriter(pkg, 1, ps=True)
+    bits, exp = w.frame(rng)
+    r, sbr, psr, info = pkg.sbr_parse_payload(st[0], tab, 24000, SW.to_bytes(bits), 1, True)
+    assert r == 0 and sbr["start"][0] == 1 and sbr["reset"][0] == 1 and sbr["kx_old"][0] == 32 and sbr["m_old"][0] == 0
+    kx, m = int(tab.headers()[1]["kx"]), int(tab.headers()[1]["m"])
+    # an access unit without payload: start = 0 on the same header, old range = this header's
+    s2 = np.zeros(1, pkg.SBR_FRAME_DT)
+    p2 = np.zeros(1, pkg.PS_FRAME_DT)
+    pkg.lib().heaac_sbr_no_payload(st[0].ctypes.data_as(C.c_void_p), 1, s2.ctypes.data_as(C.c_void_p),
+                                   p2.ctypes.data_as(C.c_void_p))
+    assert s2["start"][0] == 0 and s2["hdr"][0] == 1 and (s2["kx_old"][0], s2["m_old"][0]) == (kx, m)
+    assert pkg.validate_frame(pkg.CFG_HEV2, s2, tab.headers(), p2) == "NONE"
+    # and the stream goes on
+    bits, exp = w.frame(rng)
+    r, sbr, psr, info = pkg.sbr_parse_payload(st[0], tab, 24000, SW.to_bytes(bits), 1, True)
+    assert r == 0 and sbr["start"][0] == 1 and sbr["reset"][0] == 0
+    exp["sbr"]["hdr"] = sbr["hdr"]
+    _same(sbr, exp["sbr"], "after the gap")
+
+
+BAD_GRIDS = [
+    [(0, 2), (3, 2)],                                             # FIXFIX with 8 envelopes (aacsbr.c:633-637)
+    [(3, 2), (0, 2), (0, 2), (3, 2), (3, 2)],                     # VARVAR with 7 envelopes (:690-695)
+    [(1, 2), (0, 2), (3, 2), (3, 2), (3, 2), (3, 2)],             # FIXVAR walking below zero: not monotone (:715-720)
+    [(1, 2), (0, 2), (3, 2), (0, 2), (0, 2), (0, 2), (7, 3)],     # FIXVAR, 4 envelopes, bs_pointer = 7 > 5 (:708-713)
+]
+
+
+@pytest.mark.parametrize("case", range(len(BAD_GRIDS)))
+def test_malformed_grids_drop_the_element_and_keep_the_stream(pkg, case):
+    """read_sbr_grid's rejections end in start = 0 for the frame (read_sbr_data, :989-992); here the channel
+    state is rolled back, so the next frame decodes as if the bad one had carried nothing."""
+    rng = np.random.default_rng(21 + case)
+    tab = pkg.SbrHeaderTable(8)
+    st = pkg.sbr_streams(1)
+    w = SW.SbrStreamWriter(pkg, 1, ps=False)
+    bits, exp = w.frame(rng)
+    assert pkg.sbr_parse_payload(st[0], tab, 24000, SW.to_bytes(bits), 1, False)[0] == 0
+    before = st.copy()
+    b = SW.Bits()
+    b.put(0, 1); b.put(0, 1)                                      # no header, no bs_data_extra
+    for v, n in BAD_GRIDS[case]:
+        b.put(v, n)
+    r, sbr, _, _ = pkg.sbr_parse_payload(st[0], tab, 24000, SW.to_bytes(b.bits, 64), 1, False)
+    assert r == -1 and sbr["start"][0] == 0 and sbr["hdr"][0] == 1
+    assert pkg.validate_frame(pkg.CFG_HEV2, sbr, tab.headers(), np.zeros(1, pkg.PS_FRAME_DT)) == "NONE"
+    assert (st != before).sum() <= 4                              # start, reset and the "old" range: no channel data
+    # a header restarts the stream; the data continues from the frame before the bad one
+    bits, exp = w.frame(rng, new_header=True)
+    r, sbr, _, _ = pkg.sbr_parse_payload(st[0], tab, 24000, SW.to_bytes(bits), 1, False)
+    assert r == 0 and sbr["start"][0] == 1
+    exp["sbr"]["hdr"] = sbr["hdr"]
+    _same(sbr, exp["sbr"], "after the bad frame")
+
+
+def test_header_that_cannot_build_tables_switches_to_upsampling(pkg):
+    """sbr_reset failing (aacsbr.c:1022-1033): start = 0, no table entry is made."""
+    tab = pkg.SbrHeaderTable(8)
+    st = pkg.sbr_streams(1)
+    bad = dict(start_freq=15, stop_freq=0, xover=0, freq_scale=2, alter_scale=1, noise_bands=2, amp_res=1,
+               extra_2=0, limiter_bands=2, limiter_gains=2, interpol_freq=1, smoothing_mode=1)
+    with pytest.raises(ValueError):
+        pkg.sbr_make_header(**SW.header_args(bad))
+    b = SW.Bits()
+    b.put(1, 1)
+    SW.put_header(b, bad)
+    r, sbr, _, info = pkg.sbr_parse_payload(st[0], tab, 24000, SW.to_bytes(b.bits), 1, False)
+    assert r == -1 and sbr["start"][0] == 0 and sbr["hdr"][0] == 0 and len(tab) == 1 and info["header"] == 1
+    # the same header again is not taken for "unchanged"
+    r, sbr, _, info = pkg.sbr_parse_payload(st[0], tab, 24000, SW.to_bytes(b.bits), 1, False)
+    assert r == -1 and sbr["start"][0] == 0
+
+
+def test_illegal_ps_data_switches_ps_off_only(pkg):
+    """ff_ps_read_data's err path (aacps.c:275-279): ps->start = 0, the rest of the extension is skipped,
+    the SBR frame stands."""
+    rng = np.random.default_rng(4)
+    while True:                                                   # a frame that ends in bs_extended_data = 0
+        w = SW.SbrStreamWriter(pkg, 1, ps=False)
+        bits, exp = w.frame(rng)
+        info = pkg.sbr_parse_payload(pkg.sbr_streams(1)[0], pkg.SbrHeaderTable(8), 24000, SW.to_bytes(bits), 1, False)[3]
+        if bits[-1] == 0 and info["sbr_bits"] == len(bits):
+            # a junk extension also may end in a 0 bit: then flipping that bit changes the junk, not the flag
+            flipped = pkg.sbr_parse_payload(pkg.sbr_streams(1)[0], pkg.SbrHeaderTable(8), 24000,
+                                            SW.to_bytes(bits[:-1] + [1]), 1, False)[3]
+            if flipped["sbr_bits"] > len(bits):
+                break
+    tab = pkg.SbrHeaderTable(8)
+    st = pkg.sbr_streams(1)
+    x = SW.Bits()
+    x.put(2, 2)                                                   # EXTENSION_ID_PS
+    x.put(1, 1); x.put(1, 1); x.put(7, 3)                         # header, enable_iid, iid_mode 7: reserved
+    x.bits.extend([1] * 17)
+    cnt = (len(x) + 7) // 8
+    size = SW.Bits(); size.put(cnt, 4)
+    x.bits.extend([0] * (8 * cnt - len(x)))
+    body = bits[:-1] + [1]
+    r, sbr, psr, info = pkg.sbr_parse_payload(st[0], tab, 24000, SW.to_bytes(body + size.bits + x.bits), 1, True)
+    assert r == -1 and info["ps_present"] == 1 and info["ps_status"] == -1
+    assert sbr["start"][0] == 1 and psr["start"][0] == 0
+    assert info["sbr_bits"] == len(body) + 4 + 8 * cnt
+    exp["sbr"]["hdr"] = sbr["hdr"]
+    _same(sbr, exp["sbr"], "sbr frame")
+
+
+def test_parallel_streams_share_one_header_table(pkg):
+    """heaac_sbr_parse_payload from many threads on one table: every stream finds its headers, identical
+    headers share an entry."""
+    import threading
+    tab = pkg.SbrHeaderTable(64)
+    n = 8
+    st = pkg.sbr_streams(n)
+    errs = []
+
+    def run(i):
+        try:
+            rng = np.random.default_rng(100 + i)
+            w = SW.SbrStreamWriter(pkg, 2, ps=False)
+            for f in range(25):
+                bits, exp = w.frame(rng, new_header=f % 5 == 4, respec=True)
+                r, sbr, _, _ = pkg.sbr_parse_payload(st[i], tab, 24000, SW.to_bytes(bits), 2, False)
+                assert r == 0
+                assert tab.headers()[int(sbr["hdr"][0])].tobytes() == exp["hdr"][0].tobytes()
+        except Exception as e:                                    # noqa: BLE001
+            errs.append((i, repr(e)))
+    th = [threading.Thread(target=run, args=(i,)) for i in range(n)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    hs = tab.headers()
+    assert len({h.tobytes() for h in hs}) == len(hs)
+
+
+def test_sbr_tables_fingerprint(pkg):
+    """The generated Huffman tables are the ones this suite was written against (sha256 of the header file
+    as generated from the reference's text by tools/extract_aac_tables.py)."""
+    import hashlib
+    h = hashlib.sha256(open(os.path.join(ROOT, "ffmpeg-heaac_amd", "csrc", "sbr_iso_tables.h"), "rb").read()).hexdigest()
+    want = open(os.path.join(ROOT, "tests", "golden", "sbr_iso_tables.sha256")).read().split()[0]
+    assert h == want
+    L = pkg.lib()
+    L.heaac_sbr_tables_fingerprint.restype = C.c_uint64
+    want_fnv = int(open(os.path.join(ROOT, "tests", "golden", "sbr_iso_tables.fnv")).read().split()[0], 16)
+    assert L.heaac_sbr_tables_fingerprint() == want_fnv
+    # every table is a complete prefix code (Kraft sum exactly 1): no bit pattern is undecodable
+    for name in SW.SBR_T + SW.PS_T:
+        code, bits = SW.T[name]
+        assert sum(2.0 ** -b for b in bits) == 1.0, name
+        assert len({(c, b) for c, b in zip(code, bits)}) == len(code)
+
+
+# ---------------------------------------------------------------------------------------------
+# whole access units: AAC core element + fill element with the SBR payload
+# ---------------------------------------------------------------------------------------------
+def _he_cfg(pkg, ch, ps):
+    c = pkg.AacConfig()
+    c.object_type, c.sampling_index, c.sample_rate, c.chan_config = 2, 6, 24000, ch
+    c.sbr, c.ps = 1, (1 if ps else 0)
+    c.ext_object_type, c.ext_sampling_index, c.ext_sample_rate = 5, 3, 48000
+    return c
+
+
+def _he_units(pkg, rng, writers, cpe, new_header=False):
+    import test_parse as TP
+    aus, exps = [], []
+    for w in writers:
+        while True:
+            import copy
+            keep = copy.deepcopy((w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling))
+            bits, exp = w.frame(rng, new_header=new_header, respec=new_header)
+            if (4 + len(bits) + 7) // 8 <= 269:                   # one fill element: count + esc_count - 1
+                break
+            w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling = keep
+        au, core = TP._write_au(rng, 6, 2, cpe, extras=False, sbr=(bits, False))
+        aus.append(au)
+        exps.append(exp)
+    return aus, exps
+
+
+@pytest.mark.parametrize("cpe", [False, True])
+def test_whole_access_units_on_host_threads(pkg, cpe):
+    rng = np.random.default_rng(61 + cpe)
+    n = 24
+    cfg = _he_cfg(pkg, 2 if cpe else 1, not cpe)
+    tab = pkg.SbrHeaderTable(64)
+    st = np.zeros(n, pkg.AAC_STREAM_DT)
+    sst = pkg.sbr_streams(n)
+    writers = [SW.SbrStreamWriter(pkg, 2 if cpe else 1, ps=not cpe) for _ in range(n)]
+    for step in range(6):
+        aus, exps = _he_units(pkg, rng, writers, cpe, new_header=step == 3)
+        out = pkg.heaac_parse_batch(cfg, st, sst, tab, aus, threads=4, with_ps=not cpe)
+        assert out["failed"] == 0 and not out["status"].any(), out["status"]
+        hs = tab.headers()
+        for i in range(n):
+            assert hs[int(out["sbr"][i]["hdr"])].tobytes() == exps[i]["hdr"][0].tobytes()
+            exps[i]["sbr"]["hdr"] = out["sbr"][i]["hdr"]
+            _same(out["sbr"][i:i + 1], exps[i]["sbr"], "step %d stream %d" % (step, i))
+            if not cpe:
+                _same(out["ps"][i:i + 1], exps[i]["ps"], "step %d stream %d ps" % (step, i))
+    # an access unit without a fill element
+    import test_parse as TP
+    aus = [TP._write_au(rng, 6, 2, cpe, extras=False)[0] for _ in range(n)]
+    out = pkg.heaac_parse_batch(cfg, st, sst, tab, aus, threads=2, with_ps=not cpe)
+    assert out["failed"] == 0 and (out["status"] == pkg.PARSE_NO_SBR).all()
+    assert (out["sbr"]["start"] == 0).all() and (out["sbr"]["hdr"] > 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cpe", [False, True])
+def test_he_bitstream_to_pcm_on_the_gpu(pkg, oracle, dev, cpe):
+    """HE-AAC access units end to end the way a host would drive it: heaac_heaac_parse_batch ->
+    heaac_spectral_tools_batch -> heaac_he_check_batch -> heaac_he_decode_batch, state chained over frames with
+    a header change in the middle; against the oracle fed with the records the WRITER states (not the parsed
+    ones) and the parsed spectrum."""
+    import torch
+    rng = np.random.default_rng(71 + cpe)
+    n = 32
+    ch = 2 if cpe else 1
+    hcfg = pkg.CFG_HEV1 if cpe else pkg.CFG_HEV2
+    cfg = _he_cfg(pkg, ch, not cpe)
+    tab = pkg.SbrHeaderTable(64)
+    st = np.zeros(n, pkg.AAC_STREAM_DT)
+    sst = pkg.sbr_streams(n)
+    writers = [SW.SbrStreamWriter(pkg, ch, ps=not cpe) for _ in range(n)]
+    state = np.zeros((n, pkg.STATE_WORDS[hcfg]), np.float32)
+    d_state = torch.from_numpy(state).cuda()
+    d_rng = torch.full((n,), 0x1f2e3d4c, dtype=torch.int32, device="cuda")
+    ref_rng = np.full(n, 0x1f2e3d4c, np.int32)
+    for step in range(5):
+        aus, exps = _he_units(pkg, rng, writers, cpe, new_header=step == 2)
+        out = pkg.heaac_parse_batch(cfg, st, sst, tab, aus, with_ps=not cpe)
+        assert out["failed"] == 0
+        hdr = tab.headers()
+        # expected records, with the parser's header indices (the table is the parser's)
+        exp_sbr = np.concatenate([e["sbr"] for e in exps])
+        exp_sbr["hdr"] = out["sbr"]["hdr"]
+        exp_ps = np.concatenate([e["ps"] for e in exps]) if not cpe else None
+        coeffs = np.ascontiguousarray(out["coeffs"][:, :ch])
+        tools = out["tools"]
+        ref_c, ref_rng = oracle.spectral_tools_batch(ch, coeffs, tools, rng=ref_rng)
+        ref_pcm, state = oracle.he_decode_batch(hcfg, ref_c, np.ascontiguousarray(out["ics"][:, :ch]), exp_sbr, hdr,
+                                                exp_ps, state, pkg.PCM_F32)
+        d_c = torch.from_numpy(coeffs).cuda()
+        dev.spectral_tools(ch, d_c, pkg.to_device(tools), rng=d_rng)
+        d_sbr, d_hdr = pkg.to_device(out["sbr"]), pkg.to_device(hdr)
+        d_ps = pkg.to_device(out["ps"]) if not cpe else None
+        assert dev.he_check(hcfg, d_sbr, d_hdr, d_ps) is None
+        pcm, d_state = dev.he_decode(hcfg, d_c, pkg.to_device(np.ascontiguousarray(out["ics"][:, :ch])), d_sbr, d_hdr,
+                                     d_ps, d_state)
+        assert np.array_equal(d_c.cpu().numpy().view(np.uint32), ref_c.view(np.uint32)), step
+        got = pcm.cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), ref_pcm.view(np.uint32)), step
+        assert np.array_equal(d_state.cpu().numpy().view(np.uint32), state.view(np.uint32)), step
