@@ -587,7 +587,10 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
         if (e < p.num_env && b < nr_par) {
             iid = remap_idx(p.iid_par[e], p.nr_iid_par, is34, b);
             icc = remap_idx(p.icc_par[e], p.nr_icc_par, is34, b);
-            if (p.enable_ipdopd && b < 17) {
+            // remap34 / remap20 with full == 0 write 17 / 11 entries (aacps.c:461-499, 775-792).  With 17
+            // phase parameters on the 20-band grid the reference's mixing loop goes on to b = 16 and reads
+            // entries 11..16 of a local array it never wrote; they are 0 here (and in the oracle).
+            if (p.enable_ipdopd && b < (is34 ? 17 : 11)) {
                 ipd = remap_idx(p.ipd_par[e], p.nr_ipdopd_par, is34, b);
                 opd = remap_idx(p.opd_par[e], p.nr_ipdopd_par, is34, b);
             }

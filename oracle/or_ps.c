@@ -462,6 +462,10 @@ static void stereo_processing(const HeaacPsFrame *p, ps_ctx *ps, float (*l)[32][
 
     /* H[.][0] <- H[.][num_env_old]: the state record already holds that row in
      * row 0 (see or_ps_apply), so the copy at aacps.c:818-825 is a no-op here. */
+    /* The reference leaves these four arrays uninitialised (aacps.c:804-807).  One record reads entries it
+     * never wrote: 17 phase parameters on the 20-band grid (enable_iid off, nr_ipdopd_par left at 17 by an
+     * earlier header): remap20 with full == 0 writes entries 0..10, the mixing loop reads up to 16 (:863).
+     * Defined here -- and in the kernel -- as zero. */
     memset(ipd_mapped, 0, sizeof(ipd_mapped));
     memset(opd_mapped, 0, sizeof(opd_mapped));
     memset(iid_mapped, 0, sizeof(iid_mapped));

@@ -318,3 +318,40 @@ def test_downsampled_output_inside_the_decode_call(pkg, oracle, dev, cfgname, fm
     n = 40
     _run_chain(pkg, oracle, dev, getattr(pkg, cfgname), n, 4, 71, hdr, ps_mode="mix", hdr_choice=np.arange(n) % len(hdr),
                fmt=getattr(pkg, fmtname), in_place=in_place, downsampled=True)
+
+
+def test_hev2_phase_parameters_wider_than_the_grid(pkg, oracle, dev):
+    """A PS header that switches IID off leaves nr_iid_par / nr_ipdopd_par where an earlier header put them
+    (aacps.c:161-172): 17 phase parameters can then meet the 20-band grid.  The reference's mixing loop runs to
+    b < nr_ipdopd_par (:863) over mapped entries 11..16 that remap20 never wrote; both sides define them as 0."""
+    import torch
+    synth = _synth()
+    rng = np.random.default_rng(91)
+    hdr = synth.default_headers(pkg)
+    n, cfg = 24, pkg.CFG_HEV2
+    state = np.zeros((n, pkg.STATE_WORDS[cfg]), np.float32)
+    d_state = torch.from_numpy(state).cuda()
+    d_hdr = pkg.to_device(hdr)
+    was34 = np.zeros(n, np.uint8)
+    hit = 0
+    for step, fr in enumerate(synth.he_stream(rng, cfg, n, 5, hdr, ps_mode="mix")):
+        ps = fr["ps"]
+        for s in range(n):
+            if ps[s]["nr_icc_par"] != 34 and s % 3 != 2:
+                ps[s]["iid_par"] = 0
+                ps[s]["nr_iid_par"], ps[s]["nr_ipdopd_par"], ps[s]["enable_ipdopd"] = 34, 17, 1
+                ps[s]["ipd_par"] = rng.integers(0, 8, (5, 17))
+                ps[s]["opd_par"] = rng.integers(0, 8, (5, 17))
+                ps[s]["is34bands"] = 0
+                hit += 1
+            ps[s]["is34bands_old"] = was34[s]
+            was34[s] = ps[s]["is34bands"]
+        assert pkg.validate_frame(cfg, fr["sbr"][:1], hdr, ps[:1]) == "NONE"
+        ref_pcm, state = oracle.he_decode_batch(cfg, fr["coeffs"], fr["ics"], fr["sbr"], hdr, ps, state, pkg.PCM_F32)
+        pcm, d_state = dev.he_decode(cfg, torch.from_numpy(fr["coeffs"]).cuda(), pkg.to_device(fr["ics"]),
+                                     pkg.to_device(fr["sbr"]), d_hdr, pkg.to_device(ps), d_state)
+        nbad, where = _mismatch(pcm.cpu().numpy(), ref_pcm)
+        assert nbad == 0, "step %d: %d PCM words differ, first at %s" % (step, nbad, where)
+        nbad, where = _mismatch(d_state.cpu().numpy(), state)
+        assert nbad == 0, "step %d: %d state words differ, first at %s" % (step, nbad, where)
+    assert hit > 20
