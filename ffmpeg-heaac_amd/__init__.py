@@ -103,7 +103,7 @@ EXPORTED = [
     "heaac_he_decode_batch", "heaac_he_decode_batch_ex", "heaac_qmf_analysis_batch", "heaac_qmf_synthesis_batch",
     "heaac_qmf_synthesis_ds_batch",
     "heaac_sbr_make_header", "heaac_build_info", "heaac_spectral_tools_batch",
-    "heaac_validate_frame", "heaac_he_check_batch",
+    "heaac_validate_frame", "heaac_he_check_batch", "heaac_couple_after_imdct_batch",
     # heaac_fft.h
     "ff_fft_init", "ff_fft_end", "ff_fft_permute", "ff_fft_calc",
     "ff_mdct_init", "ff_mdct_end", "ff_imdct_half", "ff_imdct_calc",
@@ -286,6 +286,20 @@ class Device:
         return coeffs
 
     # -- HE-AAC --
+    def couple_after_imdct(self, channels, pcm, cce, coupling, s16=False):
+        """heaac_couple_after_imdct_batch: pcm [n][channels][1024] f32 updated in place; returns the int16
+        interleave of the result when s16."""
+        import torch
+        n = pcm.shape[0]
+        assert pcm.dtype == torch.float32 and pcm.numel() == n * channels * 1024, "pcm"
+        assert cce.dtype == torch.float32 and cce.numel() == n * 1024, "cce"
+        assert coupling.numel() * coupling.element_size() == n * COUPLING_DT.itemsize, "coupling"
+        out = torch.empty((n, 1024, channels), dtype=torch.int16, device=pcm.device) if s16 else None
+        _check(lib().heaac_couple_after_imdct_batch(self._h, channels, _ptr(pcm), _ptr(cce), _ptr(coupling),
+                                                    _ptr(out), C.c_size_t(n), _stream()),
+               "heaac_couple_after_imdct_batch")
+        return out
+
     def he_check(self, cfg, sbr, hdr, ps=None):
         """heaac_he_check_batch on device-resident records (byte tensors as he_decode takes them):
         returns None if every frame is valid, else (first bad frame index, rule name)."""
@@ -383,6 +397,7 @@ class AdtsHeader(C.Structure):
                                        "chan_config", "crc_absent", "num_aac_frames", "frame_length")]
 
 
+COUPLING_DT = np.dtype([("gain", "<f4", (2,)), ("on", "u1", (2,)), ("pad", "u1", (2,))])
 AAC_STREAM_DT = np.dtype([("window_sequence", "u1", (2,)), ("use_kb_window", "u1", (2,)), ("pad", "u1", (4,))])
 AAC_INFO_DT = np.dtype([("channels", "<i4"), ("bits_consumed", "<i4"), ("sbr_payload_bit", "<i4"),
                         ("sbr_payload_bytes", "<i4"), ("sbr_crc", "<i4")])

@@ -308,6 +308,16 @@ extern "C" int heaac_qmf_synthesis_ds_batch(HeaacDevice *dev, const float *d_X,
                                          (hipStream_t)stream);
 }
 
+extern "C" int heaac_couple_after_imdct_batch(HeaacDevice *dev, int channels, float *d_pcm, const float *d_cce,
+                                              const HeaacCoupling *d_coupling, int16_t *d_s16,
+                                              size_t n, void *stream)
+{
+    if (!dev || (channels != 1 && channels != 2)) return HEAAC_ERR_ARG;
+    if (n == 0) return HEAAC_OK;
+    if (!d_pcm || !d_cce || !d_coupling || n > 0x7fffffffu) return HEAAC_ERR_ARG;
+    return heaac_launch_couple(channels, d_pcm, d_cce, d_coupling, d_s16, n, (hipStream_t)stream);
+}
+
 // Debug/test hook: device pointers of the stage workspace of the LAST chunk
 // (W[chunk][2][32][32][2], X[chunk][2][2][38][64]).  Not part of include/*.h.
 extern "C" int heaac_debug_workspace(HeaacDevice *dev, float **d_W, float **d_X, size_t *chunk)

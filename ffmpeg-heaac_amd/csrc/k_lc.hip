@@ -286,3 +286,57 @@ extern "C" int heaac_launch_imdct_mirror(float *d_out, int n, size_t count, hipS
     hipLaunchKernelGGL(k_imdct_mirror, dim3(grid), dim3(256), 0, s, d_out, n, (unsigned long long)count);
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
 }
+
+// ---------------------------------------------------------------------------
+// k_couple: apply_independent_coupling (aacdec.c:1849-1862) over a batch, elementwise and HBM-bound:
+// one lane = four consecutive samples of one frame, both target channels (the coupling element's
+// samples are read once).  dest + gain * (src - bias): two roundings of the product term, then the add,
+// as the reference's expression (no contraction: -ffp-contract=off).
+// ---------------------------------------------------------------------------
+template <int CH, bool S16>
+__global__ __launch_bounds__(256)
+void k_couple(float *__restrict__ g_pcm, const float *__restrict__ g_cce, const HeaacCoupling *__restrict__ g_cpl,
+              int16_t *__restrict__ g_s16, unsigned long long n)
+{
+    const unsigned long long t = (unsigned long long)blockIdx.x * 256 + threadIdx.x;   // 256 lanes per frame
+    const unsigned long long f = t >> 8;
+    if (f >= n) return;
+    const int q = (int)(t & 255);
+    const HeaacCoupling c = g_cpl[f];
+    const float4 s = *reinterpret_cast<const float4 *>(g_cce + f * 1024 + 4 * q);
+    const float sv[4] = { s.x, s.y, s.z, s.w };
+    float out[CH][4];
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) {
+        float4 *d = reinterpret_cast<float4 *>(g_pcm + (f * CH + ch) * 1024 + 4 * q);
+        const float4 v = *d;
+        out[ch][0] = v.x; out[ch][1] = v.y; out[ch][2] = v.z; out[ch][3] = v.w;
+        if (c.on[ch]) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) out[ch][i] = out[ch][i] + c.gain[ch] * (sv[i] - HEAAC_ADD_BIAS);
+            *d = make_float4(out[ch][0], out[ch][1], out[ch][2], out[ch][3]);
+        }
+    }
+    if constexpr (S16) {
+        // float_to_int16_interleave (dsputil.c:3989-4001)
+        int16_t *o = g_s16 + (f * 1024 + 4 * q) * CH;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int ch = 0; ch < CH; ch++) o[i * CH + ch] = (int16_t)float_to_int16_one(out[ch][i]);
+    }
+}
+
+extern "C" int heaac_launch_couple(int channels, float *d_pcm, const float *d_cce, const HeaacCoupling *d_cpl,
+                        int16_t *d_s16, size_t n, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)n;                 // 256 lanes = one frame
+    if (channels == 2) {
+        if (d_s16) k_couple<2, true><<<grid, 256, 0, stream>>>(d_pcm, d_cce, d_cpl, d_s16, n);
+        else       k_couple<2, false><<<grid, 256, 0, stream>>>(d_pcm, d_cce, d_cpl, d_s16, n);
+    } else {
+        if (d_s16) k_couple<1, true><<<grid, 256, 0, stream>>>(d_pcm, d_cce, d_cpl, d_s16, n);
+        else       k_couple<1, false><<<grid, 256, 0, stream>>>(d_pcm, d_cce, d_cpl, d_s16, n);
+    }
+    return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
+}

@@ -14,6 +14,9 @@ int heaac_launch_lc(const float *d_tab, const uint16_t *d_rev, int channels,
 
 int heaac_launch_imdct_half(const float *d_tab, const uint16_t *d_rev, int which,
                             float *d_out, const float *d_in, size_t n, hipStream_t s);
+
+int heaac_launch_couple(int channels, float *d_pcm, const float *d_cce, const HeaacCoupling *d_cpl,
+                        int16_t *d_s16, size_t n, hipStream_t s);
 }
 
 extern "C" {

@@ -266,6 +266,25 @@ int heaac_lc_decode_batch(HeaacDevice *dev, int channels,
                           void *d_pcm, int pcm_format,
                           size_t n, void *stream);
 
+/* AFTER_IMDCT independent channel coupling: apply_independent_coupling()
+ * (aacdec.c:1849-1862) the way spectral_to_sample() applies it to an SCE / CPE once the element's own
+ * IMDCT is done (:1929-1930, apply_channel_coupling :1870-1898), AAC-LC (no SBR: len = 1024):
+ *     dest[i] += gain * (src[i] - bias)          bias = HEAAC_ADD_BIAS
+ *   d_pcm      [n][channels][1024]  target->ret: heaac_lc_decode_batch's F32 output, updated in place
+ *   d_cce      [n][1024]            the coupling element's ret: heaac_lc_decode_batch, channels = 1, F32
+ *   d_coupling [n]                  per target channel: coupled or not, cce->coup.gain[index][0]
+ *   d_s16      NULL, or [n][1024][channels] int16: float_to_int16_interleave of the result
+ * Several coupling elements on one target = several calls, in element order. */
+typedef struct HeaacCoupling {
+    float   gain[2];
+    uint8_t on[2];
+    uint8_t pad[2];
+} HeaacCoupling;                  /* 12 bytes */
+
+int heaac_couple_after_imdct_batch(HeaacDevice *dev, int channels, float *d_pcm, const float *d_cce,
+                                   const HeaacCoupling *d_coupling, int16_t *d_s16,
+                                   size_t n, void *stream);
+
 /* Batched HE-AAC channel-element synthesis = imdct_and_windowing() (bias 0)
  * + ff_sbr_apply() (+ ff_ps_apply()) (+ float_to_int16_interleave).
  *   cfg        HEAAC_CFG_HEV1 (CPE), HEAAC_CFG_HEV1_MONO (SCE) or HEAAC_CFG_HEV2 (SCE+PS)

@@ -575,3 +575,29 @@ int oracle_lc_decode_batch(int channels, const float *coeffs, const HeaacIcs *ic
     }
     return 0;
 }
+
+/* apply_independent_coupling, aacdec.c:1849-1862 (len = 1024: no SBR), for the target channels whose
+ * `on` flag is set, then (optionally) float_to_int16_interleave of the targets, dsputil.c:3989-4001 */
+int oracle_couple_after_imdct_batch(int channels, float *pcm, const float *cce, const HeaacCoupling *cpl,
+                                    int16_t *s16, size_t n)
+{
+    size_t f;
+    int c, i;
+    if (channels < 1 || channels > 2)
+        return HEAAC_ERR_ARG;
+    for (f = 0; f < n; f++) {
+        const float *src = cce + f * 1024;
+        for (c = 0; c < channels; c++) {
+            float *dest = pcm + (f * channels + c) * 1024;
+            const float gain = cpl[f].gain[c];
+            const float bias = HEAAC_ADD_BIAS;
+            if (cpl[f].on[c])
+                for (i = 0; i < 1024; i++)
+                    dest[i] += gain * (src[i] - bias);
+            if (s16)
+                for (i = 0; i < 1024; i++)
+                    s16[(f * 1024 + i) * channels + c] = (int16_t)oracle_float_to_int16_one(dest[i]);
+        }
+    }
+    return 0;
+}

@@ -96,6 +96,9 @@ void oracle_spectral_tools_batch(int channels, float *coeffs, const HeaacToolsFr
                                  const int32_t *rng_in, int32_t *rng_out,
                                  const HeaacPredictorState *pred_in, HeaacPredictorState *pred_out, size_t n);
 
+int oracle_couple_after_imdct_batch(int channels, float *pcm, const float *cce, const HeaacCoupling *cpl,
+                                    int16_t *s16, size_t n);                /* aacdec.c:1849-1862 */
+
 int oracle_he_decode_batch(int cfg, const float *coeffs, const HeaacIcs *ics,
                            const HeaacSbrFrame *sbr, const HeaacSbrHeader *hdr, size_t n_hdr,
                            const HeaacPsFrame *ps,

@@ -188,6 +188,23 @@ def lc_decode_batch(channels, coeffs, ics, state_in, pcm_format=PCM_F32):
     return pcm, state_out
 
 
+COUPLING_DT = np.dtype([("gain", "<f4", (2,)), ("on", "u1", (2,)), ("pad", "u1", (2,))])
+
+
+def couple_after_imdct_batch(channels, pcm, cce, coupling, s16=False):
+    """apply_independent_coupling on a copy of pcm [n][channels][1024]; returns (pcm, int16 [n][1024][channels] or None)."""
+    out = _f32(pcm).copy()
+    n = out.shape[0]
+    cce = _f32(cce)
+    coupling = np.ascontiguousarray(coupling, dtype=COUPLING_DT)
+    o16 = np.zeros((n, 1024, channels), np.int16) if s16 else None
+    r = lib().oracle_couple_after_imdct_batch(C.c_int(channels), _p(out), _p(cce), _p(coupling),
+                                              _p(o16) if s16 else None, C.c_size_t(n))
+    if r:
+        raise RuntimeError("oracle_couple_after_imdct_batch -> %d" % r)
+    return out, o16
+
+
 def spectral_tools_batch(channels, coeffs, tools, rng=None, pred=None):
     """(PNS if rng, AAC-Main prediction if pred,) M/S + intensity + TNS on a copy of coeffs.
     Returns coeffs, followed by rng_out and / or pred_out when those were given."""

@@ -133,3 +133,43 @@ def test_lc_full_size_batch_position_independent(pkg, oracle, dev):
     want_st = torch.from_numpy(ref_state).cuda()
     assert bool((pcm == want_pcm[None]).all())
     assert bool((st.view(torch.int32) == want_st.view(torch.int32)[None]).all())
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_independent_coupling_after_the_imdct(pkg, oracle, dev, channels):
+    """spectral_to_sample with a coupling element at AFTER_IMDCT (aacdec.c:1907-1931): the coupling channel's own
+    IMDCT, the target element's IMDCT, dest += gain * (src - bias), float_to_int16_interleave -- chained over
+    frames, some targets not coupled, two coupling elements on one target applied in order."""
+    import torch
+    synth = _synth(pkg)
+    rng = np.random.default_rng(41 + channels)
+    n, steps = 50, 4
+    state = np.zeros((n, channels * 512), np.float32)
+    cstate = np.zeros((2, n, 512), np.float32)
+    d_state, d_cstate = torch.from_numpy(state).cuda(), torch.from_numpy(cstate).cuda()
+    tgt = synth.lc_stream(rng, n, steps, channels)
+    cc = [synth.lc_stream(rng, n, steps, 1), synth.lc_stream(rng, n, steps, 1)]
+    for step in range(steps):
+        coeffs, ics = next(tgt)
+        coeffs[::7] *= 1000.0                                 # loud: the int16 clip runs on coupled sums too
+        ref, state = oracle.lc_decode_batch(channels, coeffs, ics, state, pkg.PCM_F32)
+        pcm, d_state = dev.lc_decode(channels, torch.from_numpy(coeffs).cuda(), pkg.to_device(ics), d_state,
+                                     pcm_format=pkg.PCM_F32)
+        ref16 = got16 = None
+        for e in range(2):
+            ccoef, cics = next(cc[e])
+            cref, cstate[e] = oracle.lc_decode_batch(1, ccoef, cics, cstate[e], pkg.PCM_F32)
+            cpcm, cs = dev.lc_decode(1, torch.from_numpy(ccoef).cuda(), pkg.to_device(cics), d_cstate[e],
+                                     pcm_format=pkg.PCM_F32)
+            d_cstate[e] = cs
+            cpl = np.zeros(n, pkg.COUPLING_DT)
+            cpl["gain"] = (2.0 ** (rng.integers(-12, 5, (n, 2)) / 4.0)).astype(np.float32)    # pow(scale, -gain)
+            cpl["on"] = rng.random((n, 2)) < 0.7
+            cpl["on"][0] = 0
+            cpl["gain"][0] = np.nan                            # an uncoupled channel's gain is never read
+            ref, ref16 = oracle.couple_after_imdct_batch(channels, ref, cref.reshape(n, 1024), cpl, s16=e == 1)
+            got16 = dev.couple_after_imdct(channels, pcm, cpcm, pkg.to_device(cpl), s16=e == 1)
+        assert np.array_equal(_bits(pcm.cpu().numpy()), _bits(ref)), step
+        assert np.array_equal(got16.cpu().numpy(), ref16), step
+        assert (np.abs(ref16.astype(int)) == 32767).any() or (ref16 == -32768).any()
+        assert np.array_equal(_bits(d_state.cpu().numpy()), _bits(state))

@@ -168,3 +168,28 @@ def test_downsampled_synthesis_is_the_decimated_bank(oracle):
     a, b = x[2048:6000], y[2048 + best:6000 + best]
     corr = np.dot(a, b) / np.sqrt(np.dot(a, a) * np.dot(b, b))
     assert abs(corr) > 0.9999, (best, corr)
+
+
+def test_independent_coupling_is_the_reference_expression(pkg, oracle):
+    """apply_independent_coupling (aacdec.c:1849-1862): dest[i] += gain * (src[i] - bias) in float32, product
+    rounded before the add; channels whose flag is off are untouched; the int16 view is
+    float_to_int16_interleave of the result."""
+    rng = np.random.default_rng(17)
+    n = 9
+    pcm = (385.0 + rng.standard_normal((n, 2, 1024)) * 0.3).astype(np.float32)
+    cce = (385.0 + rng.standard_normal((n, 1024)) * 0.3).astype(np.float32)
+    cpl = np.zeros(n, oracle.COUPLING_DT)
+    cpl["gain"] = rng.uniform(0.1, 4.0, (n, 2)).astype(np.float32)
+    cpl["on"] = rng.random((n, 2)) < 0.6
+    cpl["on"][0] = [1, 0]
+    out, s16 = oracle.couple_after_imdct_batch(2, pcm, cce, cpl, s16=True)
+    bias = np.float32(385.0)
+    want = pcm.copy()
+    for f in range(n):
+        for c in range(2):
+            if cpl["on"][f, c]:
+                prod = (cpl["gain"][f, c] * (cce[f] - bias)).astype(np.float32)
+                want[f, c] = pcm[f, c] + prod
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(out[0, 1], pcm[0, 1])
+    assert np.array_equal(s16[:2].transpose(0, 2, 1), oracle.float_to_int16(out[:2]))
