@@ -776,10 +776,12 @@ int heaac_heaac_parse_frame(const HeaacAacConfig *cfg, HeaacAacStream *st, Heaac
                             HeaacSbrFrame *sbr, HeaacPsFrame *ps, HeaacAacFrameInfo *info)
 {
     HeaacAacFrameInfo fi;
+    memset(&fi, 0, sizeof(fi));
+    if (info) *info = fi;
     if (!cfg || !sst || !tab || !sbr) return HEAAC_PARSE_ERR_ARG;
     const int r = heaac_aac_parse_frame(cfg, st, au, size, coeffs, ics, tools, &fi);
+    if (r) return r;                                   /* info->channels = 0: the core element failed */
     if (info) *info = fi;
-    if (r) return r;
     const int allow_ps = cfg->ps != 0 && fi.channels == 1 && ps != NULL;
     if (fi.sbr_payload_bit < 0 || cfg->sbr == 0) {
         heaac_sbr_no_payload(sst, fi.channels, sbr, ps);

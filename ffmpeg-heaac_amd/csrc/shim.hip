@@ -14,6 +14,7 @@
 #include "tables.h"
 #include "kernels.h"
 #include "validate.h"
+#include "heaac_parse.h"
 
 // capi.hip
 extern "C" const float *heaac_device_tables(HeaacDevice *dev, const uint16_t **rev);
@@ -313,20 +314,174 @@ typedef struct HeaacDecoderPriv {
     HeaacSbrHeader *d_hdr;
     int16_t *d_pcm;
     HeaacSbrHeader hdr[MAX_HDRS];
+    // cfg = HEAAC_CFG_FROM_STREAM: the packets are access units
+    int bitstream, configured, have_m4ac;
+    HeaacAacConfig m4ac;
+    HeaacAacStream ast;
+    HeaacSbrStream sst;
+    HeaacSbrHeaderTable *tab;
+    size_t hdr_uploaded;
+    HeaacToolsFrame *d_tools;
+    int32_t *d_rng;
+    HeaacPredictorState *d_pred;
+    float *h_coeffs;
+    HeaacToolsFrame *h_tools;
 } HeaacDecoderPriv;
 
-static int dec_init(HeaacCodecContext *avctx)
+static void set_cfg(HeaacDecoderPriv *p, int cfg)
 {
-    HeaacDecoderPriv *p = (HeaacDecoderPriv *)avctx->priv_data;
-    p->cfg = avctx->cfg;
-    switch (p->cfg) {
+    p->cfg = cfg;
+    switch (cfg) {
     case HEAAC_CFG_LC_MONO:   p->ncore = 1; p->nout = 1; p->out_len = 1024; p->words = HEAAC_STATE_WORDS_LC_MONO; break;
     case HEAAC_CFG_LC_STEREO: p->ncore = 2; p->nout = 2; p->out_len = 1024; p->words = HEAAC_STATE_WORDS_LC_STEREO; break;
     case HEAAC_CFG_HEV1:      p->ncore = 2; p->nout = 2; p->out_len = 2048; p->words = HEAAC_STATE_WORDS_HEV1; break;
     case HEAAC_CFG_HEV1_MONO: p->ncore = 1; p->nout = 1; p->out_len = 2048; p->words = HEAAC_STATE_WORDS_HEV1_MONO; break;
     case HEAAC_CFG_HEV2:      p->ncore = 1; p->nout = 2; p->out_len = 2048; p->words = HEAAC_STATE_WORDS_HEV2; break;
-    default: return -1;
+    default:                  p->ncore = 0; break;
     }
+}
+
+// what the stream says so far -> the caller-visible fields (aacdec.c:2080-2094: samples = 1024 << multiplier)
+static void publish_cfg(HeaacCodecContext *avctx, const HeaacDecoderPriv *p)
+{
+    const int he = p->out_len == 2048;
+    avctx->channels = p->nout;
+    avctx->frame_size = p->out_len;
+    avctx->sample_rate = he ? 2 * p->m4ac.sample_rate : p->m4ac.sample_rate;
+}
+
+static int dec_init_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p)
+{
+    p->bitstream = 1;
+    if (avctx->extradata && avctx->extradata_size > 0) {
+        if (heaac_asc_parse(&p->m4ac, avctx->extradata, avctx->extradata_size) < 0) return -1;
+        if (p->m4ac.chan_config != 1 && p->m4ac.chan_config != 2) return -1;      // this slice: one SCE or one CPE
+        if (p->m4ac.object_type != HEAAC_AOT_AAC_LC && p->m4ac.object_type != HEAAC_AOT_AAC_MAIN) return -1;
+        p->have_m4ac = 1;
+    }
+    const size_t words = HEAAC_STATE_WORDS_HEV2 > HEAAC_STATE_WORDS_HEV1 ? HEAAC_STATE_WORDS_HEV2 : HEAAC_STATE_WORDS_HEV1;
+    p->tab = heaac_sbr_table_create(MAX_HDRS);
+    p->h_coeffs = (float *)calloc(2 * 1024, sizeof(float));
+    p->h_tools = (HeaacToolsFrame *)calloc(1, sizeof(HeaacToolsFrame));
+    if (!p->tab || !p->h_coeffs || !p->h_tools) return -1;
+    heaac_sbr_stream_init(&p->sst, 1);
+    if (heaac_device_create(&p->dev, 64) != HEAAC_OK) return -1;
+    if (hipMalloc((void **)&p->d_state, words * 4) != hipSuccess ||
+        hipMalloc((void **)&p->d_coeffs, 2 * 1024 * 4) != hipSuccess ||
+        hipMalloc((void **)&p->d_side, 2048) != hipSuccess ||
+        hipMalloc((void **)&p->d_hdr, sizeof(p->hdr)) != hipSuccess ||
+        hipMalloc((void **)&p->d_pcm, 2 * 2048 * 2) != hipSuccess ||
+        hipMalloc((void **)&p->d_tools, sizeof(HeaacToolsFrame)) != hipSuccess ||
+        hipMalloc((void **)&p->d_rng, 4) != hipSuccess ||
+        hipMalloc((void **)&p->d_pred, 2 * HEAAC_MAX_PREDICTORS * sizeof(HeaacPredictorState)) != hipSuccess)
+        return -1;
+    if (hipMemset(p->d_state, 0, words * 4) != hipSuccess) return -1;
+    const int32_t seed = 0x1f2e3d4c;                                   // ac->random_state, aacdec.c:558
+    if (hipMemcpy(p->d_rng, &seed, 4, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    HeaacPredictorState *ps = (HeaacPredictorState *)calloc(2 * HEAAC_MAX_PREDICTORS, sizeof(*ps));
+    if (!ps) return -1;
+    for (int i = 0; i < 2 * HEAAC_MAX_PREDICTORS; i++) ps[i].var0 = ps[i].var1 = 1.0f;   // reset_predict_state, :507-515
+    const hipError_t e = hipMemcpy(p->d_pred, ps, 2 * HEAAC_MAX_PREDICTORS * sizeof(*ps), hipMemcpyHostToDevice);
+    free(ps);
+    if (e != hipSuccess) return -1;
+    if (p->have_m4ac) {
+        // tentative, as decode_audio_specific_config leaves it; the first access unit settles implicit SBR
+        const int he = p->m4ac.sbr == 1;
+        set_cfg(p, he ? (p->m4ac.chan_config == 2 ? HEAAC_CFG_HEV1 : HEAAC_CFG_HEV2)
+                      : (p->m4ac.chan_config == 2 ? HEAAC_CFG_LC_STEREO : HEAAC_CFG_LC_MONO));
+        publish_cfg(avctx, p);
+    }
+    return 0;
+}
+
+static int dec_frame_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p, void *data, int *data_size,
+                               HeaacPacket *avpkt)
+{
+    const uint8_t *buf = avpkt->data;
+    const int size = avpkt->size;
+    if (!buf || size < 2) return -1;
+    if (!p->have_m4ac) {
+        // parse_adts_frame_header (aacdec.c:1935-1971): the stream configures itself
+        HeaacAdtsHeader ah;
+        if (heaac_adts_parse_header(&ah, buf, size) < 0) return -1;
+        if (ah.chan_config != 1 && ah.chan_config != 2) return -1;
+        memset(&p->m4ac, 0, sizeof(p->m4ac));
+        p->m4ac.object_type = ah.object_type;
+        p->m4ac.sampling_index = ah.sampling_index;
+        p->m4ac.sample_rate = ah.sample_rate;
+        p->m4ac.chan_config = ah.chan_config;
+        p->m4ac.sbr = -1;
+        p->m4ac.ps = -1;
+        if (p->m4ac.object_type != HEAAC_AOT_AAC_LC && p->m4ac.object_type != HEAAC_AOT_AAC_MAIN) return -1;
+        p->have_m4ac = 1;
+    }
+    HeaacIcs ics[2];
+    HeaacSbrFrame sbr;
+    HeaacPsFrame ps;
+    HeaacAacFrameInfo fi;
+    memset(ics, 0, sizeof(ics));
+    const int r = heaac_heaac_parse_frame(&p->m4ac, &p->ast, &p->sst, p->tab, buf, size, p->h_coeffs, ics, p->h_tools,
+                                          &sbr, &ps, &fi);
+    if (r == HEAAC_PARSE_ERR_ARG || r == HEAAC_PARSE_ERR_UNSUPPORTED) return -1;
+    if (r < 0 && fi.channels == 0) return -1;          // the core element failed (aacdec.c:2046-2049)
+    if (fi.channels != p->m4ac.chan_config) return -1;
+    if (!p->configured) {
+        // implicit SBR counts only when the first access unit carries it (aacdec.c:1666-1675)
+        if (p->m4ac.sbr == -1) p->m4ac.sbr = fi.sbr_payload_bit >= 0 ? 1 : 0;
+        const int he = p->m4ac.sbr == 1;
+        set_cfg(p, he ? (fi.channels == 2 ? HEAAC_CFG_HEV1 : (p->m4ac.ps != 0 ? HEAAC_CFG_HEV2 : HEAAC_CFG_HEV1_MONO))
+                      : (fi.channels == 2 ? HEAAC_CFG_LC_STEREO : HEAAC_CFG_LC_MONO));
+        publish_cfg(avctx, p);
+        p->configured = 1;
+    }
+    const int he = p->out_len == 2048;
+    const int ch = fi.channels;
+    uint8_t *d_ics = p->d_side, *d_sbr = p->d_side + 16, *d_ps = p->d_side + 16 + 688;
+    if (hipMemcpy(p->d_coeffs, p->h_coeffs, (size_t)ch * 4096, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_ics, ics, sizeof(ics), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(p->d_tools, p->h_tools, sizeof(HeaacToolsFrame), hipMemcpyHostToDevice) != hipSuccess)
+        return -1;
+    const int main_profile = p->m4ac.object_type == HEAAC_AOT_AAC_MAIN;
+    int rc = heaac_spectral_tools_batch(p->dev, ch, p->d_coeffs, p->d_tools, p->d_rng, p->d_rng,
+                                        main_profile ? p->d_pred : NULL, main_profile ? p->d_pred : NULL, 1, NULL);
+    if (rc != HEAAC_OK) return -1;
+    if (!he) {
+        rc = heaac_lc_decode_batch(p->dev, ch, p->d_coeffs, (const HeaacIcs *)d_ics, p->d_state, p->d_state,
+                                   p->d_pcm, HEAAC_PCM_S16_INTERLEAVED, 1, NULL);
+    } else {
+        const size_t have = heaac_sbr_table_count(p->tab);
+        if (have > p->hdr_uploaded) {
+            memcpy(p->hdr + p->hdr_uploaded, heaac_sbr_table_data(p->tab) + p->hdr_uploaded,
+                   (have - p->hdr_uploaded) * sizeof(HeaacSbrHeader));
+            if (hipMemcpy(p->d_hdr + p->hdr_uploaded, p->hdr + p->hdr_uploaded,
+                          (have - p->hdr_uploaded) * sizeof(HeaacSbrHeader), hipMemcpyHostToDevice) != hipSuccess)
+                return -1;
+            p->hdr_uploaded = have;
+        }
+        if (heaac_validate_frame(p->cfg, &sbr, p->hdr, MAX_HDRS, p->cfg == HEAAC_CFG_HEV2 ? &ps : NULL)) return -1;
+        if (hipMemcpy(d_sbr, &sbr, sizeof(sbr), hipMemcpyHostToDevice) != hipSuccess) return -1;
+        if (p->cfg == HEAAC_CFG_HEV2 && hipMemcpy(d_ps, &ps, sizeof(ps), hipMemcpyHostToDevice) != hipSuccess) return -1;
+        rc = heaac_he_decode_batch(p->dev, p->cfg, p->d_coeffs, (const HeaacIcs *)d_ics, (const HeaacSbrFrame *)d_sbr,
+                                   p->d_hdr, MAX_HDRS, p->cfg == HEAAC_CFG_HEV2 ? (const HeaacPsFrame *)d_ps : NULL,
+                                   p->d_state, p->d_state, p->d_pcm, HEAAC_PCM_S16_INTERLEAVED, 1, NULL);
+    }
+    if (rc != HEAAC_OK) return -1;
+    const int bytes = p->out_len * p->nout * 2;
+    if (hipMemcpy(data, p->d_pcm, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    *data_size = bytes;
+    // aacdec.c:2102-2107: bytes consumed, or the whole packet when only zero padding follows
+    const int consumed = (fi.bits_consumed + 7) >> 3;
+    int off = consumed;
+    while (off < size && !buf[off]) off++;
+    return size > off ? consumed : size;
+}
+
+static int dec_init(HeaacCodecContext *avctx)
+{
+    HeaacDecoderPriv *p = (HeaacDecoderPriv *)avctx->priv_data;
+    if (avctx->cfg == HEAAC_CFG_FROM_STREAM) return dec_init_bitstream(avctx, p);
+    set_cfg(p, avctx->cfg);
+    if (!p->ncore) return -1;
     if (heaac_device_create(&p->dev, 64) != HEAAC_OK) return -1;
     if (hipMalloc((void **)&p->d_state, p->words * 4) != hipSuccess ||
         hipMalloc((void **)&p->d_coeffs, 2 * 1024 * 4) != hipSuccess ||
@@ -353,6 +508,12 @@ static int dec_close(HeaacCodecContext *avctx)
     if (p->d_side) (void)hipFree(p->d_side);
     if (p->d_hdr) (void)hipFree(p->d_hdr);
     if (p->d_pcm) (void)hipFree(p->d_pcm);
+    if (p->d_tools) (void)hipFree(p->d_tools);
+    if (p->d_rng) (void)hipFree(p->d_rng);
+    if (p->d_pred) (void)hipFree(p->d_pred);
+    heaac_sbr_table_destroy(p->tab);
+    free(p->h_coeffs);
+    free(p->h_tools);
     heaac_device_destroy(p->dev);
     memset(p, 0, sizeof(*p));
     return 0;
@@ -361,6 +522,7 @@ static int dec_close(HeaacCodecContext *avctx)
 static int dec_frame(HeaacCodecContext *avctx, void *data, int *data_size, HeaacPacket *avpkt)
 {
     HeaacDecoderPriv *p = (HeaacDecoderPriv *)avctx->priv_data;
+    if (p->bitstream) return dec_frame_bitstream(avctx, p, data, data_size, avpkt);
     const uint8_t *buf = avpkt->data;
     const int he = p->cfg == HEAAC_CFG_HEV1 || p->cfg == HEAAC_CFG_HEV1_MONO || p->cfg == HEAAC_CFG_HEV2;
     size_t need = sizeof(HeaacFramePacket) + (size_t)p->ncore * 4096 + (he ? sizeof(HeaacSbrFrame) : 0) +

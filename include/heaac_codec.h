@@ -11,13 +11,13 @@
  *   avcodec_open / avcodec_decode_audio3 / avcodec_close
  *                                             libavcodec/utils.c:462-531, :638-663
  *
- * Scope: the reference's packet is an AAC bitstream; bitstream parsing is host
- * work outside this library.  A packet HERE is the parser's
- * output for one access unit -- dequantised spectrum plus side info -- in the
- * HeaacFramePacket layout below.  decode() then does what aac_decode_frame()
- * does from spectral_to_sample() on (aacdec.c:2078-2107): float DSP on the GPU,
- * int16 interleaved PCM into the caller's buffer, *data_size = bytes written,
- * return value = bytes consumed (negative on error).
+ * Two kinds of packet.  With cfg = HEAAC_CFG_FROM_STREAM a packet is what the reference's is: an AAC access
+ * unit; decode() parses it on the host (heaac_parse.h) and runs spectral tools + spectral_to_sample() on the GPU.
+ * With an explicit cfg a packet is a parser's OUTPUT for one access unit -- dequantised spectrum plus side
+ * info -- in the HeaacFramePacket layout below, for hosts that keep their own parser; decode() then does what
+ * aac_decode_frame() does from spectral_to_sample() on (aacdec.c:2078-2107).  Either way: float DSP on the
+ * GPU, int16 interleaved PCM into the caller's buffer, *data_size = bytes written, return value = bytes
+ * consumed (negative on error).
  *
  * One context = one stream = one thread, as in the reference.  Inter-frame
  * state lives in device memory owned by the context.  For throughput use the
@@ -63,10 +63,22 @@ typedef struct HeaacCodecContext {
     int sample_rate;              /* output rate (set by init from cfg)      */
     int channels;                 /* output channels                         */
     int frame_size;               /* samples per channel per frame           */
-    int cfg;                      /* HEAAC_CFG_*, chosen by the caller       */
+    int cfg;                      /* HEAAC_CFG_* chosen by the caller, or HEAAC_CFG_FROM_STREAM */
     const struct HeaacCodec *codec;
     void *priv_data;
+    const uint8_t *extradata;     /* AudioSpecificConfig (avctx->extradata, aacdec.c:563-566); NULL: ADTS */
+    int extradata_size;
 } HeaacCodecContext;
+
+/* cfg = HEAAC_CFG_FROM_STREAM: packets are AAC access units (raw_data_block, or an ADTS frame), as
+ * avcodec_decode_audio3() hands them to aac_decode_frame() (aacdec.c:1973-2107).  The library then parses them
+ * itself (heaac_parse.h) and the configuration comes from the stream the way the reference takes it:
+ * object type, rate and channel configuration from extradata (decode_audio_specific_config, aacdec.c:432-491)
+ * or from the first ADTS header (parse_adts_frame_header, :1935-1971); SBR from the AudioSpecificConfig or,
+ * signalled implicitly, from a payload in the FIRST access unit (a first occurrence later is refused,
+ * :1666-1669); a mono stream with SBR decodes as Parametric Stereo (:1670-1673, two output channels).
+ * Scope of the parser slices: one SCE or one CPE per access unit, AAC-LC / AAC-Main. */
+#define HEAAC_CFG_FROM_STREAM (-1)
 
 /* Field for field `struct AVCodec` of libavcodec/avcodec.h:2675-2711 (same order, same types up to
  * the names of the context / packet structs), so that the record can sit in libavcodec's codec list

@@ -90,8 +90,10 @@ def put_sf(bw, delta):
     bw.put(T["aac_sf_code"][delta + 60], T["aac_sf_bits"][delta + 60])
 
 
-def random_ics(rng, si, aot, allow_intensity):
-    """Side info + quantised spectrum of one channel, everything the syntax can carry in this slice."""
+def random_ics(rng, si, aot, allow_intensity, quiet=False):
+    """Side info + quantised spectrum of one channel, everything the syntax can carry in this slice.
+    quiet: levels of real audio (peaks around 1e-2 of full scale) instead of the syntax's extremes, for tests
+    that run the SBR stage behind the parser (its energy arithmetic overflows on 1e5 x full scale)."""
     eight = rng.random() < 0.3
     off = swb(si, eight)
     num_swb = len(off) - 1
@@ -124,9 +126,10 @@ def random_ics(rng, si, aot, allow_intensity):
             choices = [0] + list(range(1, 12)) + [13] + ([14, 15] if allow_intensity else [])
             bt[g, k:k + ln] = int(rng.choice(choices)); k += ln
     d["band_type"] = bt
-    d["global_gain"] = int(rng.integers(100, 180))
-    d["sf_delta"] = rng.integers(-6, 7, (ng, ms))
-    d["noise_level"] = int(rng.integers(60, 200))         # noise gain of the first noise band (sent as 9 bits)
+    d["global_gain"] = int(rng.integers(140, 157)) if quiet else int(rng.integers(100, 180))
+    d["sf_delta"] = rng.integers(-2, 3, (ng, ms)) if quiet else rng.integers(-6, 7, (ng, ms))
+    # noise gain of the first noise band (sent as 9 bits)
+    d["noise_level"] = int(rng.integers(60, 150)) if quiet else int(rng.integers(60, 200))
     # quantised lines per (group, band): [group_len][width]
     q = {}
     for g in range(ng):
@@ -134,7 +137,7 @@ def random_ics(rng, si, aot, allow_intensity):
             w = off[i + 1] - off[i]
             b = bt[g, i]
             if 1 <= b <= 11:
-                lav = LAV[b] if b < 11 else (15 if rng.random() < 0.5 else int(rng.choice([40, 300, 5000])))
+                lav = LAV[b] if b < 11 else (15 if rng.random() < 0.5 else int(rng.choice([40] if quiet else [40, 300, 5000])))
                 v = rng.integers(-lav, lav + 1, (d["group_len"][g], w))
                 if b == 11 and lav > 15:
                     v[rng.random(v.shape) < 0.7] = 0
@@ -159,7 +162,7 @@ def random_ics(rng, si, aot, allow_intensity):
             t["n_filt"].append(nf); t["coef_res"].append(int(rng.integers(0, 2)))
             fl = []
             for _ in range(nf):
-                order = int(rng.integers(0, 8 if eight else 13))
+                order = int(rng.integers(0, 4)) if quiet else int(rng.integers(0, 8 if eight else 13))
                 fl.append(dict(length=int(rng.integers(0, num_swb + 1)) if not eight else int(rng.integers(0, 16)),
                                order=order, direction=int(rng.integers(0, 2)), compress=int(rng.integers(0, 2)),
                                idx=None))

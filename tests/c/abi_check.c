@@ -181,6 +181,28 @@ static int gpu_checks(void)
         CHECK(heaac_codec_decode(&ctx[0], pcm[0], &size, &ap) < 0);
     }
     for (int k = 0; k < 2; k++) CHECK(heaac_codec_close(&ctx[k]) == 0);
+    { /* the reference's own packet: an AAC access unit, configuration from extradata (AAC-LC 48 kHz mono).
+         One SCE with max_sfb = 0 (silence), then END: 32 bits, zero padding behind. */
+        static const uint8_t asc[2] = { 0x11, 0x88 };
+        static const uint8_t au[12] = { 0x00, 0xc8, 0x00, 0x07 };
+        HeaacCodecContext bs; memset(&bs, 0, sizeof(bs));
+        bs.cfg = HEAAC_CFG_FROM_STREAM; bs.extradata = asc; bs.extradata_size = 2;
+        CHECK(heaac_codec_open(&bs, &heaac_aac_decoder) == 0);
+        CHECK(bs.channels == 1 && bs.frame_size == 1024 && bs.sample_rate == 48000);
+        for (int frame = 0; frame < 2; frame++) {
+            HeaacPacket ap = { au, (int)sizeof(au) };
+            int size = HEAAC_MAX_AUDIO_FRAME_SIZE;
+            CHECK(heaac_codec_decode(&bs, pcm[0], &size, &ap) == (int)sizeof(au));
+            CHECK(size == 1024 * 2);
+            int nz = 0;
+            for (int i = 0; i < 1024; i++) nz |= pcm[0][i];
+            CHECK(nz == 0);
+        }
+        HeaacPacket bad = { asc, 2 };                  /* not an access unit */
+        int size = HEAAC_MAX_AUDIO_FRAME_SIZE;
+        CHECK(heaac_codec_decode(&bs, pcm[0], &size, &bad) < 0);
+        CHECK(heaac_codec_close(&bs) == 0);
+    }
     free(pcm[0]); free(pcm[1]); free(pkt);
     return fails;
 }

@@ -23,7 +23,7 @@ def _cfg(pkg, aot=2, si=3, ch=2):
     return c
 
 
-def _write_au(rng, si, aot, cpe, extras=True, sbr=None):
+def _write_au(rng, si, aot, cpe, extras=True, sbr=None, quiet=False):
     """One access unit + everything the parser must report for it.  sbr = (payload bits, crc): carried in a
     fill element behind the channel element (extension type 0xd / 0xe, aacdec.c:1655-1678)."""
     bw = W.BitWriter()
@@ -37,14 +37,14 @@ def _write_au(rng, si, aot, cpe, extras=True, sbr=None):
             bw.align()
         for _ in range(cnt):
             bw.put(int(rng.integers(0, 256)), 8)
-    ch = [W.random_ics(rng, si, aot, allow_intensity=False)]
+    ch = [W.random_ics(rng, si, aot, allow_intensity=False, quiet=quiet)]
     if cpe:
         bw.put(1, 3); bw.put(0, 4)
         common = int(rng.integers(0, 2))
         bw.put(common, 1)
         exp["common_window"] = common
         if common:
-            second = W.random_ics(rng, si, aot, allow_intensity=True)
+            second = W.random_ics(rng, si, aot, allow_intensity=True, quiet=quiet)
             for k in ("window_sequence", "window_shape", "max_sfb", "eight", "off", "num_swb", "group_len",
                       "predictor_present"):
                 second[k] = ch[0][k]
@@ -52,7 +52,7 @@ def _write_au(rng, si, aot, cpe, extras=True, sbr=None):
                 if k in ch[0]:
                     second[k] = ch[0][k]
             # the second channel's own draws must fit the shared window: redraw with the shared layout
-            second = _redraw_like(rng, ch[0], si, aot)
+            second = _redraw_like(rng, ch[0], si, aot, quiet)
             ch.append(second)
             W.put_ics_info(bw, ch[0], si, aot)
             ms_present = int(rng.integers(0, 3))
@@ -67,7 +67,7 @@ def _write_au(rng, si, aot, cpe, extras=True, sbr=None):
                 mask[:nb] = 1
             exp["ms_present"], exp["ms_mask"] = ms_present, mask
         else:
-            ch.append(W.random_ics(rng, si, aot, allow_intensity=True))
+            ch.append(W.random_ics(rng, si, aot, allow_intensity=True, quiet=quiet))
             exp["ms_present"], exp["ms_mask"] = 0, np.zeros(128, np.uint8)
         exp["sf"] = [W.put_ics(bw, ch[0], si, aot, common), W.put_ics(bw, ch[1], si, aot, common)]
     else:
@@ -104,10 +104,10 @@ def _write_au(rng, si, aot, cpe, extras=True, sbr=None):
     return bw.bytes(), exp
 
 
-def _redraw_like(rng, first, si, aot):
+def _redraw_like(rng, first, si, aot, quiet=False):
     """A second channel for a common-window pair: same ics_info, own sections / scalefactors / spectrum."""
     for _ in range(200):
-        d = W.random_ics(rng, si, aot, allow_intensity=True)
+        d = W.random_ics(rng, si, aot, allow_intensity=True, quiet=quiet)
         if d["eight"] == first["eight"]:
             break
     for k in ("window_sequence", "window_shape", "max_sfb", "group_len", "predictor_present"):
@@ -126,7 +126,7 @@ def _redraw_like(rng, first, si, aot):
             ln = int(rng.integers(1, ms - k + 1))
             bt[g, k:k + ln] = int(rng.choice([0] + list(range(1, 12)) + [13, 14, 15])); k += ln
     d["band_type"] = bt
-    d["sf_delta"] = rng.integers(-6, 7, (ng, ms))
+    d["sf_delta"] = rng.integers(-2, 3, (ng, ms)) if quiet else rng.integers(-6, 7, (ng, ms))
     q = {}
     for g in range(ng):
         for i in range(ms):

@@ -89,7 +89,7 @@ class HeaacPacket(C.Structure):
 
 class HeaacCodecContext(C.Structure):
     _fields_ = [("sample_rate", C.c_int), ("channels", C.c_int), ("frame_size", C.c_int), ("cfg", C.c_int),
-                ("codec", C.c_void_p), ("priv_data", C.c_void_p)]
+                ("codec", C.c_void_p), ("priv_data", C.c_void_p), ("extradata", C.c_char_p), ("extradata_size", C.c_int)]
 
 
 @pytest.mark.parametrize("cfgname", ["CFG_LC_STEREO", "CFG_HEV1", "CFG_HEV2"])
@@ -138,4 +138,95 @@ def test_codec_surface_decodes_a_stream(pkg, oracle, dev, cfgname):
     # too-small output buffer is refused like avcodec_decode_audio3 does (utils.c:645-651)
     small = C.c_int(1000)
     assert lib.heaac_codec_decode(C.byref(ctx), out, C.byref(small), C.byref(pkt)) == -1
+    assert lib.heaac_codec_close(C.byref(ctx)) == 0
+
+
+def _adts(au, aot, si, chan):
+    """ADTS frame around one raw_data_block (aac_parser.c:29-70)."""
+    import aac_bitwriter as W
+    bw = W.BitWriter()
+    for v, n in ((0xfff, 12), (0, 1), (0, 2), (1, 1), (aot - 1, 2), (si, 4), (0, 1), (chan, 3), (0, 4),
+                 (7 + len(au), 13), (0x7ff, 11), (0, 2)):
+        bw.put(v, n)
+    return bw.bytes(pad=0) + au
+
+
+@pytest.mark.parametrize("mode", ["lc_asc", "lc_adts_mono", "hev1_asc", "hev2_asc", "hev2_implicit", "sbr_too_late"])
+def test_codec_decodes_access_units(pkg, oracle, dev, mode):
+    """cfg = HEAAC_CFG_FROM_STREAM: the packets are AAC access units, as avcodec_decode_audio3 hands them to the
+    reference's aac_decode_frame.  Configuration from extradata or the first ADTS header, SBR explicit or implicit
+    (first access unit only), mono + SBR decoded as Parametric Stereo.  int16 PCM against the oracle's spectral tools
+    + decode on the separately parsed records, state chained over six frames."""
+    import test_parse as TP
+    import sbr_bitwriter as SW
+    lib = pkg.lib()
+    rng = np.random.default_rng(hash(mode) % 1000)
+    asc = dict(lc_asc=bytes([0x11, 0x90]), lc_adts_mono=None, hev1_asc=bytes([0x2B, 0x11, 0x88, 0x00]),
+               hev2_asc=bytes([0xEB, 0x09, 0x88, 0x00]), hev2_implicit=bytes([0x13, 0x08]),
+               sbr_too_late=bytes([0x13, 0x08]))[mode]
+    si = 3 if mode in ("lc_asc", "lc_adts_mono") else 6
+    cpe = mode in ("lc_asc", "hev1_asc")
+    ch = 2 if cpe else 1
+    he = mode.startswith("hev")
+    hcfg = {"lc_asc": pkg.CFG_LC_STEREO, "lc_adts_mono": pkg.CFG_LC_MONO, "hev1_asc": pkg.CFG_HEV1,
+            "hev2_asc": pkg.CFG_HEV2, "hev2_implicit": pkg.CFG_HEV2, "sbr_too_late": pkg.CFG_LC_MONO}[mode]
+    ctx = HeaacCodecContext(cfg=-1, extradata=asc, extradata_size=len(asc) if asc else 0)
+    codec = C.c_void_p.in_dll(lib, "heaac_aac_decoder")
+    assert lib.heaac_codec_open(C.byref(ctx), C.c_void_p(C.addressof(codec))) == 0
+    # the checker's own parse of the same units
+    m4 = pkg.AacConfig()
+    m4.object_type, m4.sampling_index, m4.sample_rate, m4.chan_config = 2, si, 48000 if si == 3 else 24000, ch
+    m4.sbr, m4.ps = (1 if he else 0), (1 if hcfg == pkg.CFG_HEV2 else 0)
+    tab = pkg.SbrHeaderTable(64)
+    st, sst = np.zeros(1, pkg.AAC_STREAM_DT), pkg.sbr_streams(1)
+    writer = SW.SbrStreamWriter(pkg, ch, ps=not cpe)
+    state = np.zeros((1, pkg.STATE_WORDS[hcfg]), np.float32)
+    ref_rng = np.full(1, 0x1f2e3d4c, np.int32)
+    out = (C.c_int16 * (192000 // 2))()
+    loud = 0
+    for t in range(6):
+        sbr_here = he or (mode == "sbr_too_late" and t >= 2)
+        if sbr_here:
+            import copy
+            while True:
+                keep = copy.deepcopy((writer.ch, writer.ps, writer.header, writer.hdr_rec, writer.kx_m, writer.coupling))
+                bits, exp = writer.frame(rng, new_header=(he and t == 3), respec=(he and t == 3))
+                if (4 + len(bits) + 7) // 8 <= 269:                    # one fill element
+                    break
+                writer.ch, writer.ps, writer.header, writer.hdr_rec, writer.kx_m, writer.coupling = keep
+            au, _ = TP._write_au(rng, si, 2, cpe, extras=False, sbr=(bits, False), quiet=True)
+        else:
+            au, _ = TP._write_au(rng, si, 2, cpe, extras=False, quiet=True)
+        pkt_bytes = _adts(au, 2, si, ch) if asc is None else au
+        buf = C.create_string_buffer(pkt_bytes, len(pkt_bytes))
+        pkt = HeaacPacket(C.cast(buf, C.c_void_p), len(pkt_bytes))
+        size = C.c_int(192000)
+        used = lib.heaac_codec_decode(C.byref(ctx), out, C.byref(size), C.byref(pkt))
+        assert used == len(pkt_bytes), (t, used)                       # only zero padding follows the END element
+        assert (ctx.channels, ctx.frame_size) == (pkg.OUT_CH[hcfg], pkg.OUT_LEN[hcfg]), t
+        assert ctx.sample_rate == (24000 if mode == "sbr_too_late" else 48000)
+        assert size.value == pkg.OUT_LEN[hcfg] * pkg.OUT_CH[hcfg] * 2
+        got = np.frombuffer(out, np.int16, size.value // 2).reshape(pkg.OUT_LEN[hcfg], pkg.OUT_CH[hcfg]).copy()
+        if he:
+            p = pkg.heaac_parse_batch(m4, st, sst, tab, [pkt_bytes], threads=1, with_ps=hcfg == pkg.CFG_HEV2)
+        else:
+            p = pkg.aac_parse_batch(m4, st, [pkt_bytes], threads=1)
+        assert p["failed"] == 0
+        coeffs = np.ascontiguousarray(p["coeffs"][:, :ch])
+        ref_c, ref_rng = oracle.spectral_tools_batch(ch, coeffs, p["tools"], rng=ref_rng)
+        ics = np.ascontiguousarray(p["ics"][:, :ch])
+        if he:
+            ref, state = oracle.he_decode_batch(hcfg, ref_c, ics, p["sbr"], tab.headers(), p["ps"] if hcfg == pkg.CFG_HEV2 else None,
+                                                state, oracle.PCM_S16)
+        else:
+            ref, state = oracle.lc_decode_batch(ch, ref_c, ics, state, oracle.PCM_S16)
+        assert np.array_equal(got, ref[0]), "frame %d" % t
+        loud = max(loud, int(np.abs(got.astype(int)).max()))
+    assert loud > 50                                                   # audible, not all zeros
+    # a packet that is not an access unit of this stream
+    junk = bytes([0xff] * 64)
+    jb = C.create_string_buffer(junk, len(junk))
+    pkt = HeaacPacket(C.cast(jb, C.c_void_p), len(junk))
+    size = C.c_int(192000)
+    assert lib.heaac_codec_decode(C.byref(ctx), out, C.byref(size), C.byref(pkt)) < 0
     assert lib.heaac_codec_close(C.byref(ctx)) == 0
