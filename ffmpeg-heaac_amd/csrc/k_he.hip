@@ -262,7 +262,7 @@ void k_hfadj(const float *__restrict__ g_tab,
 #define VB_STRIDE 129             // v slot row: 128 + 1 pad
 #define VB_ROWS   41              // 32 new slots (newest first) + 9 history slots
 
-#define SYN_WAVES_F32 7           // k_synth: the left int16 channel waits in registers, so 7 waves fit
+#define SYN_WAVES_F32 7           // k_synth (both PCM formats)
 struct SynWave {
     __attribute__((aligned(16))) float vb[VB_ROWS * VB_STRIDE + 3];
 };
@@ -440,7 +440,6 @@ void k_synth(const float *__restrict__ g_tab, const float *g_X,
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
     SynWave &w = S.w[wave];
-    uint32_t lpcm[16];          // left channel of an interleaved int16 pair: lane n, slots 2j | 2j + 1 << 16
     auto load_unit = [&](unsigned long long f, int ch, SynIn &d) {
         const float *X0 = g_X + (f * 2 + ch) * (2 * 38 * 64);
         syn_load(X0, X0 + 38 * 64, g_state_in + f * state_words + off_syn0 + ch * HEAAC_ST_SYNTH, lane, d);
@@ -457,48 +456,33 @@ void k_synth(const float *__restrict__ g_tab, const float *g_X,
         if (lane == 0) nxt = atomicAdd(g_queue, 1u) + gridDim.x * NW;
         float *st_out = g_state_out + f * state_words + off_syn0;
         // one channel: rows from `cur`, then the next unit's loads, then the polyphase sum
-        // (the int16 stereo path keeps its packed left channel in registers through a fully unrolled
-        // sum and has no room for loads in flight: it fetches the next unit afterwards)
-        auto channel = [&](int ch, auto unroll, auto emit) {
-            constexpr bool early = decltype(unroll)::value == 1;
+        auto channel = [&](int ch, auto emit) {
             SSTAMP(0);
             syn_rows(S, w, cur, lane);
             wave_sync();
-            const bool more = ch + 1 < nout;
-            if (early) {
-                if (more) load_unit(f, ch + 1, cur);
-                else if (f1 < n_frames) load_unit(f1, 0, cur);
-            }
-            syn_poly<decltype(unroll)::value>(S, w, scale, bias, lane, emit);
+            if (ch + 1 < nout) load_unit(f, ch + 1, cur);
+            else if (f1 < n_frames) load_unit(f1, 0, cur);
+            syn_poly<1>(S, w, scale, bias, lane, emit);
             syn_hist_out(w, st_out + ch * HEAAC_ST_SYNTH, lane);
             wave_sync();
-            if (!early) {
-                if (more) load_unit(f, ch + 1, cur);
-                else if (f1 < n_frames) load_unit(f1, 0, cur);
-            }
             SSTAMP(5);
         };
-        typedef std::integral_constant<int, 1> U1;
-        typedef std::integral_constant<int, 16> U16;
         if (FMT == HEAAC_PCM_F32_PLANAR) {
             for (int ch = 0; ch < nout; ch++) {
                 float *o = reinterpret_cast<float *>(g_pcm) + ((pcm_frame0 + f) * nout + ch) * 2048;
-                channel(ch, U1(), [&](int i, int n, float v) { o[64 * i + n] = v; });
+                channel(ch, [&](int i, int n, float v) { o[64 * i + n] = v; });
             }
-        } else if (nout == 1) {
-            int16_t *o = reinterpret_cast<int16_t *>(g_pcm) + (pcm_frame0 + f) * 2048;
-            channel(0, U1(), [&](int i, int n, float v) { o[64 * i + n] = (int16_t)float_to_int16_one(v); });
         } else {
-            channel(0, U16(), [&](int i, int n, float v) {
-                const uint32_t x = (uint32_t)float_to_int16_one(v) & 0xffff;
-                if (i & 1) lpcm[i >> 1] |= x << 16; else lpcm[i >> 1] = x;
-            });
-            uint32_t *o = reinterpret_cast<uint32_t *>(g_pcm) + (pcm_frame0 + f) * 2048;
-            channel(1, U16(), [&](int i, int n, float v) {
-                // float_to_int16_interleave (dsputil.c:3989-4001)
-                o[64 * i + n] = ((lpcm[i >> 1] >> (16 * (i & 1))) & 0xffff) |
-                                ((uint32_t)(float_to_int16_one(v) & 0xffff) << 16);
-            });
+            // float_to_int16_interleave (dsputil.c:3989-4001) as 2-byte stores, one pass per channel: the left
+            // samples of a frame land in L2 first, the right ones fill the other halves of the same lines a few
+            // microseconds later, so HBM sees whole lines.  Nothing of the left channel waits in registers or
+            // LDS, and the channel loop keeps ONE instance of the polyphase sum as the float path does (two
+            // inlined instances with different store code cost 152 spilled VGPRs and 40 % of this kernel's time).
+            int16_t *o = reinterpret_cast<int16_t *>(g_pcm) + (pcm_frame0 + f) * 2048 * nout;
+            for (int ch = 0; ch < nout; ch++)
+                channel(ch, [&](int i, int n, float v) {
+                    o[(64 * i + n) * nout + ch] = (int16_t)float_to_int16_one(v);
+                });
         }
         f = f1;
         f1 = (unsigned long long)__builtin_amdgcn_readfirstlane(nxt);
