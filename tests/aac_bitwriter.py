@@ -92,7 +92,7 @@ def put_sf(bw, delta):
 
 def random_ics(rng, si, aot, allow_intensity, quiet=False):
     """Side info + quantised spectrum of one channel, everything the syntax can carry in this slice.
-    quiet: levels of real audio (peaks around 1e-2 of full scale) instead of the syntax's extremes, for tests
+    quiet: levels of quiet audio (peaks around 1e-3 of full scale) instead of the syntax's extremes, for tests
     that run the SBR stage behind the parser (its energy arithmetic overflows on 1e5 x full scale)."""
     eight = rng.random() < 0.3
     off = swb(si, eight)
@@ -126,10 +126,10 @@ def random_ics(rng, si, aot, allow_intensity, quiet=False):
             choices = [0] + list(range(1, 12)) + [13] + ([14, 15] if allow_intensity else [])
             bt[g, k:k + ln] = int(rng.choice(choices)); k += ln
     d["band_type"] = bt
-    d["global_gain"] = int(rng.integers(140, 157)) if quiet else int(rng.integers(100, 180))
+    d["global_gain"] = int(rng.integers(128, 145)) if quiet else int(rng.integers(100, 180))
     d["sf_delta"] = rng.integers(-2, 3, (ng, ms)) if quiet else rng.integers(-6, 7, (ng, ms))
     # noise gain of the first noise band (sent as 9 bits)
-    d["noise_level"] = int(rng.integers(60, 150)) if quiet else int(rng.integers(60, 200))
+    d["noise_level"] = int(rng.integers(52, 72)) if quiet else int(rng.integers(60, 200))      # amplitude 2^((level - 100) / 4)
     # quantised lines per (group, band): [group_len][width]
     q = {}
     for g in range(ng):
@@ -168,6 +168,8 @@ def random_ics(rng, si, aot, allow_intensity, quiet=False):
                                idx=None))
                 clen = t["coef_res"][-1] + 3 - fl[-1]["compress"]
                 fl[-1]["idx"] = [int(x) for x in rng.integers(0, 1 << clen, order)]
+                if quiet:                                  # small reflection coefficients: a filter gain of a few
+                    fl[-1]["idx"] = [int(x) for x in rng.integers(0, 2, order)]
             t["filt"].append(fl)
         d["tns"] = t
     return d

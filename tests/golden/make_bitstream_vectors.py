@@ -1,0 +1,104 @@
+"""Mint tests/golden/bitstreams.json: short AAC / HE-AAC streams as BYTES (access units written by the test
+bit writers, hex), their AudioSpecificConfig, and what must come out of them -- SHA-256 of the parsed SBR / PS
+records per frame and of the int16 PCM of the whole stream (host parser -> oracle spectral tools -> oracle decode).
+The vectors are data: once minted they pin parser + decoder against drift without the writers' models, and
+`tests/test_golden.py` decodes the same bytes through the codec surface on the GPU.
+
+    python tests/golden/make_bitstream_vectors.py
+"""
+import hashlib, importlib, json, os, sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+STREAMS = {
+    # name: (asc bytes, sampling index, cpe, sbr writer?, ps?, frames, seed)
+    "lc_stereo_48k": (bytes([0x11, 0x90]), 3, True, False, False, 8, 801),
+    "hev1_stereo_24k": (bytes([0x2B, 0x11, 0x88, 0x00]), 6, True, True, False, 8, 802),
+    "hev2_mono_24k": (bytes([0xEB, 0x09, 0x88, 0x00]), 6, False, True, True, 10, 803),
+    "hev2_implicit_24k": (bytes([0x13, 0x08]), 6, False, True, True, 6, 804),
+}
+
+
+def write_stream(pkg, name):
+    import copy
+    import sbr_bitwriter as SW
+    import test_parse as TP
+    asc, si, cpe, sbr, ps, frames, seed = STREAMS[name]
+    rng = np.random.default_rng(seed)
+    w = SW.SbrStreamWriter(pkg, 2 if cpe else 1, ps=ps) if sbr else None
+    aus = []
+    for t in range(frames):
+        payload = None
+        if w is not None:
+            while True:
+                keep = copy.deepcopy((w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling))
+                bits, _ = w.frame(rng, new_header=t == frames // 2, respec=t == frames // 2)
+                if (4 + len(bits) + 7) // 8 <= 269:
+                    break
+                w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling = keep
+            payload = (bits, False)
+        aus.append(TP._write_au(rng, si, 2, cpe, extras=False, sbr=payload, quiet=True)[0])
+    return aus
+
+
+def decode_stream(pkg, oracle, name, aus):
+    """Parser + oracle; returns (per-frame record hashes, PCM hash, out shape)."""
+    asc, si, cpe, sbr, ps, frames, seed = STREAMS[name]
+    ch = 2 if cpe else 1
+    m4, _ = pkg.asc_parse(asc)
+    if sbr:
+        m4.sbr = 1
+    if ps:
+        m4.ps = 1
+    hcfg = (pkg.CFG_HEV1 if cpe else pkg.CFG_HEV2) if sbr else (pkg.CFG_LC_STEREO if cpe else pkg.CFG_LC_MONO)
+    tab = pkg.SbrHeaderTable(64)
+    st, sst = np.zeros(1, pkg.AAC_STREAM_DT), pkg.sbr_streams(1)
+    state = np.zeros((1, pkg.STATE_WORDS[hcfg]), np.float32)
+    rng_state = np.full(1, 0x1f2e3d4c, np.int32)
+    rec, pcm = [], hashlib.sha256()
+    for au in aus:
+        if sbr:
+            p = pkg.heaac_parse_batch(m4, st, sst, tab, [au], threads=1, with_ps=ps)
+            m = hashlib.sha256(p["sbr"].tobytes())
+            m.update(tab.headers()[int(p["sbr"]["hdr"][0])].tobytes())
+            if ps:
+                m.update(p["ps"].tobytes())
+            rec.append(m.hexdigest())
+        else:
+            p = pkg.aac_parse_batch(m4, st, [au], threads=1)
+            rec.append(hashlib.sha256(p["tools"].tobytes()).hexdigest())
+        assert p["failed"] == 0
+        coeffs = np.ascontiguousarray(p["coeffs"][:, :ch])
+        c, rng_state = oracle.spectral_tools_batch(ch, coeffs, p["tools"], rng=rng_state)
+        ics = np.ascontiguousarray(p["ics"][:, :ch])
+        if sbr:
+            f32, _ = oracle.he_decode_batch(hcfg, c, ics, p["sbr"], tab.headers(), p["ps"] if ps else None, state,
+                                            oracle.PCM_F32)
+            # a vector must not depend on how a machine encodes NaN: finite and inside the int16 range
+            assert np.isfinite(f32).all() and np.abs(f32 - 385.0).max() < 4.0, name
+            out, state = oracle.he_decode_batch(hcfg, c, ics, p["sbr"], tab.headers(), p["ps"] if ps else None, state,
+                                                oracle.PCM_S16)
+        else:
+            out, state = oracle.lc_decode_batch(ch, c, ics, state, oracle.PCM_S16)
+        pcm.update(out.tobytes())
+    return rec, pcm.hexdigest(), list(out.shape[1:])
+
+
+def main():
+    pkg = importlib.import_module("ffmpeg-heaac_amd")
+    import oracle_lib as oracle
+    out = {}
+    for name in STREAMS:
+        aus = write_stream(pkg, name)
+        rec, pcm, shape = decode_stream(pkg, oracle, name, aus)
+        out[name] = dict(asc=STREAMS[name][0].hex(), access_units=[a.hex() for a in aus], records_sha256=rec,
+                         pcm_s16_sha256=pcm, frame_shape=shape)
+        print(name, len(aus), "units,", sum(len(a) for a in aus), "bytes, pcm", pcm[:16])
+    json.dump(out, open(os.path.join(ROOT, "tests", "golden", "bitstreams.json"), "w"), indent=0)
+
+
+if __name__ == "__main__":
+    main()

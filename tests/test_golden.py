@@ -47,3 +47,50 @@ def test_hip_path_reproduces_golden(pkg, dev, name):
 
     want = json.load(open(PATH))
     assert G.run_case(name, pkg, _synth(), lc, he, tools) == want[name]
+
+
+# ---------------------------------------------------------------------------------------------
+# bitstream vectors: stored access units -> records and int16 PCM (tests/golden/bitstreams.json)
+# ---------------------------------------------------------------------------------------------
+import make_bitstream_vectors as B  # noqa: E402
+
+BPATH = os.path.join(os.path.dirname(__file__), "golden", "bitstreams.json")
+
+
+@pytest.mark.parametrize("name", sorted(B.STREAMS))
+def test_stored_bitstreams_parse_and_decode_to_the_stored_hashes(pkg, oracle, name):
+    """The committed access units go through the host parser and the oracle: per-frame record hashes and the
+    PCM hash are the stored ones; and the writers still produce these very bytes from their seeds."""
+    v = json.load(open(BPATH))[name]
+    aus = [bytes.fromhex(a) for a in v["access_units"]]
+    rec, pcm, shape = B.decode_stream(pkg, oracle, name, aus)
+    assert rec == v["records_sha256"] and pcm == v["pcm_s16_sha256"] and shape == v["frame_shape"]
+    assert [a.hex() for a in B.write_stream(pkg, name)] == v["access_units"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(B.STREAMS))
+def test_codec_decodes_stored_bitstreams_to_the_stored_pcm(pkg, name):
+    """heaac_codec_open / _decode on the committed bytes (cfg from the stream): the int16 PCM hashes to the
+    stored value.  No oracle in this test."""
+    import ctypes as C
+    import hashlib
+    from test_shim_gpu import HeaacCodecContext, HeaacPacket
+    lib = pkg.lib()
+    v = json.load(open(BPATH))[name]
+    asc = bytes.fromhex(v["asc"])
+    ctx = HeaacCodecContext(cfg=-1, extradata=asc, extradata_size=len(asc))
+    codec = C.c_void_p.in_dll(lib, "heaac_aac_decoder")
+    assert lib.heaac_codec_open(C.byref(ctx), C.c_void_p(C.addressof(codec))) == 0
+    out = (C.c_int16 * (192000 // 2))()
+    m = hashlib.sha256()
+    for a in v["access_units"]:
+        au = bytes.fromhex(a)
+        buf = C.create_string_buffer(au, len(au))
+        pkt = HeaacPacket(C.cast(buf, C.c_void_p), len(au))
+        size = C.c_int(192000)
+        assert lib.heaac_codec_decode(C.byref(ctx), out, C.byref(size), C.byref(pkt)) == len(au)
+        assert size.value == 2 * v["frame_shape"][0] * v["frame_shape"][1]
+        m.update(memoryview(out).cast("B")[: size.value])
+    assert m.hexdigest() == v["pcm_s16_sha256"]
+    assert lib.heaac_codec_close(C.byref(ctx)) == 0

@@ -5,5 +5,5 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 cd $root
 for lc in "$@"; do
     l=${lc%%:*}; c=${lc##*:}
-    HEAAC_LANES=$l HEAAC_CHUNK_FRAMES=$c python bench.py --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lanes %d chunk %7d  frames/s %.3fM frac %.4f' % ($l, $c, d['value']/1e6, d['roofline']['frac']))"
+    HEAAC_LANES=$l HEAAC_CHUNK_FRAMES=$c python bench.py $SWEEP_ARGS --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lanes %d chunk %7d  frames/s %.3fM frac %.4f' % ($l, $c, d['value']/1e6, d['roofline']['frac']))"
 done | tee gpurun_out/$tag.sweep.txt
