@@ -514,9 +514,10 @@ static int read_ps(Bits *host, HeaacPsState *ps, int bits_left_in_ext, int *stat
         }
         ps->enable_icc = (uint8_t)bit1(b);
         if (ps->enable_icc) {
-            ps->icc_mode = (uint8_t)bits(b, 3);
-            if (ps->icc_mode > 5) goto err;
-            ps->nr_icc_par = (uint8_t)k_nr_iidicc_par[ps->icc_mode];
+            const int icc_mode = (int)bits(b, 3);
+            if (icc_mode > 5) goto err;                /* (the reference stores the reserved value first) */
+            ps->icc_mode = (uint8_t)icc_mode;
+            ps->nr_icc_par = (uint8_t)k_nr_iidicc_par[icc_mode];
         }
         ps->enable_ext = (uint8_t)bit1(b);
     }
@@ -588,6 +589,11 @@ static int read_ps(Bits *host, HeaacPsState *ps, int bits_left_in_ext, int *stat
         for (int e = 0; e < ps->num_env; e++)
             for (int k = 0; k < ps->nr_iid_par; k++)
                 if (abs(ps->iid_par[e][k]) > 7 + 8 * ps->iid_quant) goto err;
+    /* (a borrowed ICC envelope can hold the value an earlier, refused frame stopped at) */
+    if (ps->enable_icc)
+        for (int e = 0; e < ps->num_env; e++)
+            for (int k = 0; k < ps->nr_icc_par; k++)
+                if (ps->icc_par[e][k] < 0 || ps->icc_par[e][k] > 7) goto err;
 
     {
         const int consumed = b->pos - at;

@@ -1,0 +1,90 @@
+/* fuzz_parse.c -- the host parsers under AddressSanitizer / UBSan on mutated access units (TEST harness).
+ *
+ * Built by tests/test_parse_fuzz.py from the parser SOURCES (aac_parse.c, sbr_parse.c, sbr_header.c) with
+ * -fsanitize=address,undefined, so every out-of-bounds access or undefined shift aborts the run.  Input: a file
+ * of seed access units (u32 kind, u32 length, bytes; kind 0 = AAC-LC CPE 48 kHz, 1 = HE-AACv1 CPE 24 kHz,
+ * 2 = HE-AACv2 SCE 24 kHz).  Each iteration mutates a seed (bit flips, byte noise, truncation, splice of two
+ * seeds, pure noise), parses it on a stream that keeps its state across iterations, and checks what the parser
+ * promises: whatever the status, the records it wrote pass validate.h.
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "heaac_parse.h"
+#include "validate.h"
+
+static uint64_t rs = 0x9e3779b97f4a7c15ull;
+static uint32_t rnd(void) { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (uint32_t)(rs >> 16); }
+
+typedef struct { uint32_t kind, len; uint8_t *data; } Seed;
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) { printf("usage: fuzz_parse seeds.bin iterations\n"); return 2; }
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    Seed seed[256];
+    int ns = 0;
+    while (ns < 256) {
+        uint32_t h[2];
+        if (fread(h, 4, 2, f) != 2) break;
+        seed[ns].kind = h[0]; seed[ns].len = h[1];
+        seed[ns].data = malloc(h[1] ? h[1] : 1);
+        if (fread(seed[ns].data, 1, h[1], f) != h[1]) return 2;
+        ns++;
+    }
+    fclose(f);
+    if (!ns) return 2;
+    const long iters = atol(argv[2]);
+    HeaacAacConfig cfg[3];
+    memset(cfg, 0, sizeof(cfg));
+    for (int k = 0; k < 3; k++) {
+        cfg[k].object_type = 2; cfg[k].sbr = k ? 1 : 0; cfg[k].ps = k == 2 ? 1 : 0;
+        cfg[k].sampling_index = k ? 6 : 3; cfg[k].sample_rate = k ? 24000 : 48000; cfg[k].chan_config = k == 2 ? 1 : 2;
+    }
+    HeaacSbrHeaderTable *tab = heaac_sbr_table_create(64);       /* small on purpose: the table fills up */
+    HeaacAacStream ast[3]; HeaacSbrStream *sst = malloc(3 * sizeof(*sst));
+    memset(ast, 0, sizeof(ast)); heaac_sbr_stream_init(sst, 3);
+    float *coeffs = malloc(2 * 1024 * sizeof(float));
+    HeaacIcs ics[2]; HeaacToolsFrame *tools = malloc(sizeof(*tools));
+    HeaacSbrFrame sbr; HeaacPsFrame ps; HeaacAacFrameInfo info;
+    long ok = 0, err = 0, bad_records = 0, started = 0;
+    for (long it = 0; it < iters; it++) {
+        const Seed *s = &seed[rnd() % ns];
+        const int k = (int)s->kind;
+        /* exact-size heap copy: ASan sees any read past the access unit */
+        uint32_t len = s->len;
+        const int mode = (int)(rnd() % 6);
+        if (mode == 2 && len > 1) len = 1 + rnd() % len;                      /* truncation */
+        if (mode == 5) len = 1 + rnd() % 400;                                  /* pure noise */
+        uint8_t *au = malloc(len);
+        for (uint32_t i = 0; i < len; i++) au[i] = i < s->len ? s->data[i] : 0;
+        if (mode == 0) { const int nf = 1 + (int)(rnd() % 8); for (int j = 0; j < nf; j++) au[rnd() % len] ^= (uint8_t)(1u << (rnd() % 8)); }
+        if (mode == 1) { const int nb = 1 + (int)(rnd() % 6); for (int j = 0; j < nb; j++) au[rnd() % len] = (uint8_t)rnd(); }
+        if (mode == 3) { const Seed *t = &seed[rnd() % ns]; const uint32_t at = rnd() % len;
+                         for (uint32_t i = at; i < len; i++) au[i] = t->data[i % t->len]; }
+        if (mode == 5) for (uint32_t i = 0; i < len; i++) au[i] = (uint8_t)rnd();
+        /* mode 4: the seed unchanged (keeps streams alive between the damaged frames) */
+        memset(&sbr, 0, sizeof(sbr)); memset(&ps, 0, sizeof(ps));
+        const int r = heaac_heaac_parse_frame(&cfg[k], &ast[k], &sst[k], tab, au, (int)len, coeffs, ics, tools,
+                                              &sbr, k == 2 ? &ps : NULL, &info);
+        free(au);
+        if (r >= 0) ok++; else err++;
+        if (info.channels) {                                                   /* the core element parsed: records were written */
+            int v = heaac_check_sbr_frame(&sbr, heaac_sbr_table_data(tab), heaac_sbr_table_count(tab), info.channels);
+            if (!v && k == 2) v = heaac_check_ps_frame(&ps);
+            if (v) { bad_records++; if (bad_records < 5) printf("iteration %ld: status %d, record breaks rule %d\n", it, r, v); }
+            started += sbr.start;
+        }
+        if (it % 4096 == 4095) heaac_sbr_stream_init(&sst[rnd() % 3], 1);      /* a stream now and then starts over */
+    }
+    printf("iterations %ld: parsed %ld, refused %ld, frames with start = 1: %ld, headers %zu, invalid records %ld\n",
+           iters, ok, err, started, heaac_sbr_table_count(tab), bad_records);
+    heaac_sbr_table_destroy(tab);
+    free(sst); free(coeffs); free(tools);
+    for (int i = 0; i < ns; i++) free(seed[i].data);
+    if (bad_records) return 1;
+    printf("ok\n");
+    return 0;
+}
