@@ -158,6 +158,12 @@ def lib():
             raise HeaacError(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(make -C ffmpeg-heaac_amd/csrc). There is no CPU fallback." % LIB_PATH)
+        # PyTorch ships its own HIP runtime.  If this library is loaded first it binds /opt/rocm's copy, torch then
+        # brings a second one into the process and whichever initialises later sees no device: load torch first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.heaac_strerror.restype = C.c_char_p
         _lib.heaac_build_info.restype = C.c_char_p
