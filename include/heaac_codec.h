@@ -77,7 +77,9 @@ typedef struct HeaacCodecContext {
  * or from the first ADTS header (parse_adts_frame_header, :1935-1971); SBR from the AudioSpecificConfig or,
  * signalled implicitly, from a payload in the FIRST access unit (a first occurrence later is refused,
  * :1666-1669); a mono stream with SBR decodes as Parametric Stereo (:1670-1673, two output channels).
- * Scope of the parser slices: one SCE or one CPE per access unit, AAC-LC / AAC-Main. */
+ * Scope of the parser slices: one SCE or one CPE per access unit, AAC-LC / AAC-Main.  A context keeps up to 63
+ * distinct SBR headers of its stream (the derived tables stay on the device); a stream that sends more than that
+ * gets -1 from the frame that brings the 64th. */
 #define HEAAC_CFG_FROM_STREAM (-1)
 
 /* Field for field `struct AVCodec` of libavcodec/avcodec.h:2675-2711 (same order, same types up to
