@@ -34,9 +34,10 @@ __device__ __forceinline__ void wave_sync()
 // ---------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-struct GBuf {
+template <int ST_AUX>
+struct GBufT {
     __amdgpu_buffer_rsrc_t r;
-    __device__ __forceinline__ explicit GBuf(const void *base)
+    __device__ __forceinline__ explicit GBufT(const void *base)
         : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000)) {}
     // v: lane-dependent word index, s: wave-uniform word index
     __device__ __forceinline__ float ld(int v, int s = 0) const
@@ -47,7 +48,7 @@ struct GBuf {
     __device__ __forceinline__ void st(float x, int v, int s = 0) const
     {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), r,
-                                              v * 4 + ((s * 4) & 4095), (s * 4) & ~4095, 0);
+                                              v * 4 + ((s * 4) & 4095), (s * 4) & ~4095, ST_AUX);
     }
     // same with the lane part given as a BYTE offset (hot loops keep it in one VGPR)
     __device__ __forceinline__ float ldb(int vb, int s = 0) const
@@ -58,7 +59,7 @@ struct GBuf {
     __device__ __forceinline__ void stb(float x, int vb, int s = 0) const
     {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), r,
-                                              vb + ((s * 4) & 4095), (s * 4) & ~4095, 0);
+                                              vb + ((s * 4) & 4095), (s * 4) & ~4095, ST_AUX);
     }
     // (re, im) pair at an 8-byte aligned byte offset
     typedef unsigned int u32x2 __attribute__((vector_size(8)));
@@ -70,9 +71,10 @@ struct GBuf {
     __device__ __forceinline__ void stb2(v2f x, int vb, int s = 0) const
     {
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r,
-                                              vb + ((s * 4) & 4095), (s * 4) & ~4095, 0);
+                                              vb + ((s * 4) & 4095), (s * 4) & ~4095, ST_AUX);
     }
 };
+typedef GBufT<0> GBuf;
 
 // Redefine a lane offset opaquely: address arithmetic on it cannot be hoisted out of
 // an unrolled loop (where it would occupy a VGPR per access) and folds into the

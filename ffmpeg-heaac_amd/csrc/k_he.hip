@@ -216,7 +216,13 @@ void k_core_ana(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_
             if (c == 1 && !have1) break;
             const float *uu = c ? w.x0u1 : w.tu;
             float *Wo = g_W + (c ? u1 : u0) * 2048;
-            for (int t = lane; t < 2048; t += WAVE) Wo[t] = uu[(t >> 6) * 65 + (t & 63)];
+            for (int t = lane; t < 2048; t += WAVE) {
+#ifdef CA_NT_ST
+                __builtin_nontemporal_store(uu[(t >> 6) * 65 + (t & 63)], Wo + t);
+#else
+                Wo[t] = uu[(t >> 6) * 65 + (t & 63)];
+#endif
+            }
         }
         wave_sync();
     }
@@ -304,16 +310,43 @@ struct SynIn {
 // (A lane reading its own 256-byte row in 16-byte pieces pulls every line through the vector L1 eight
 // times; with 7 waves per CU the L1 keeps none of them.)
 #define SYN_STAGE_STRIDE 68       // floats per staged row: 64 + 4 (b128 reads of 64 different rows spread over all banks)
+// Streamed once: X rows and ring state in, PCM and ring state out (SYN_NT_LD / SYN_NT_ST: non-temporal policy).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 syn_ld4(const f32x4 *p)
+{
+#ifdef SYN_NT_LD
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ float syn_ld1(const float *p)
+{
+#ifdef SYN_NT_LD
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <class T>
+__device__ __forceinline__ void syn_st(T *p, T v)
+{
+#ifndef SYN_PLAIN_ST
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 __device__ __forceinline__ void syn_load(const float *X0, const float *X1, const float *v_in, int lane, SynIn &d)
 {
-    const float4 *p0 = reinterpret_cast<const float4 *>(X0), *p1 = reinterpret_cast<const float4 *>(X1);
+    const f32x4 *p0 = reinterpret_cast<const f32x4 *>(X0), *p1 = reinterpret_cast<const f32x4 *>(X1);
 #pragma unroll
     for (int q = 0; q < 16; q++) {
-        const float4 t = q < 8 ? p0[q * 64 + lane] : p1[(q - 8) * 64 + lane];
+        const f32x4 t = syn_ld4(q < 8 ? p0 + q * 64 + lane : p1 + (q - 8) * 64 + lane);
         d.x[4 * q] = t.x; d.x[4 * q + 1] = t.y; d.x[4 * q + 2] = t.z; d.x[4 * q + 3] = t.w;
     }
 #pragma unroll
-    for (int r = 0; r < 18; r++) d.h[r] = v_in[lane + 64 * r];
+    for (int r = 0; r < 18; r++) d.h[r] = syn_ld1(v_in + lane + 64 * r);
 }
 
 template <class SL>
@@ -401,7 +434,7 @@ __device__ __forceinline__ void syn_hist_out(const SynWave &w, float *v_out, int
     // new ring state: slots 31..23
 #pragma unroll
     for (int r = 0; r < 18; r++)
-        v_out[lane + 64 * r] = w.vb[(r >> 1) * VB_STRIDE + (r & 1) * 64 + lane];
+        syn_st(v_out + lane + 64 * r, w.vb[(r >> 1) * VB_STRIDE + (r & 1) * 64 + lane]);
 }
 
 // The four pieces in sequence (stage-level kernel).
@@ -470,7 +503,7 @@ void k_synth(const float *__restrict__ g_tab, const float *g_X,
         if (FMT == HEAAC_PCM_F32_PLANAR) {
             for (int ch = 0; ch < nout; ch++) {
                 float *o = reinterpret_cast<float *>(g_pcm) + ((pcm_frame0 + f) * nout + ch) * 2048;
-                channel(ch, [&](int i, int n, float v) { o[64 * i + n] = v; });
+                channel(ch, [&](int i, int n, float v) { syn_st(o + 64 * i + n, v); });
             }
         } else {
             // float_to_int16_interleave (dsputil.c:3989-4001) as 2-byte stores, one pass per channel: the left
@@ -481,7 +514,7 @@ void k_synth(const float *__restrict__ g_tab, const float *g_X,
             int16_t *o = reinterpret_cast<int16_t *>(g_pcm) + (pcm_frame0 + f) * 2048 * nout;
             for (int ch = 0; ch < nout; ch++)
                 channel(ch, [&](int i, int n, float v) {
-                    o[(64 * i + n) * nout + ch] = (int16_t)float_to_int16_one(v);
+                    syn_st(o + (64 * i + n) * nout + ch, (int16_t)float_to_int16_one(v));
                 });
         }
         f = f1;

@@ -15,6 +15,13 @@
 
 #define LC_WAVES 4
 
+// PCM is written once and not read again by the GPU (LC_NT_ST: non-temporal policy)
+#ifdef LC_NT_ST
+#define LC_ST(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define LC_ST(p, v) (*(p) = (v))
+#endif
+
 struct LcWaveLds {
     float sbuf[1024];
     float zbuf[1024];
@@ -74,11 +81,11 @@ void k_lc_decode(const float *__restrict__ g_tab, const uint16_t *__restrict__ g
             float *sout = g_state_out + u * 512;
             if (FMT == HEAAC_PCM_F32_PLANAR) {
                 float *o = reinterpret_cast<float *>(g_pcm) + u * 1024;
-                core2_window(L, ics, HEAAC_ADD_BIAS, buf, sin_, sout, lane, [&](int q, float v) { o[q] = v; });
+                core2_window(L, ics, HEAAC_ADD_BIAS, buf, sin_, sout, lane, [&](int q, float v) { LC_ST(o + q, v); });
             } else if (CH == 1) {
                 int16_t *o = reinterpret_cast<int16_t *>(g_pcm) + u * 1024;
                 core2_window(L, ics, HEAAC_ADD_BIAS, buf, sin_, sout, lane,
-                             [&](int q, float v) { o[q] = (int16_t)float_to_int16_one(v); });
+                             [&](int q, float v) { LC_ST(o + q, (int16_t)float_to_int16_one(v)); });
             } else if (c == 0) {
                 core2_window(L, ics, HEAAC_ADD_BIAS, buf, sin_, sout, lane,
                              [&](int q, float v) { w.pcm0[q] = (uint16_t)float_to_int16_one(v); });
@@ -87,7 +94,7 @@ void k_lc_decode(const float *__restrict__ g_tab, const uint16_t *__restrict__ g
                 // float_to_int16_interleave (dsputil.c:3989-4001): L from LDS, R fresh
                 uint32_t *o = reinterpret_cast<uint32_t *>(g_pcm) + (u0 / 2) * 1024;
                 core2_window(L, ics, HEAAC_ADD_BIAS, buf, sin_, sout, lane, [&](int q, float v) {
-                    o[q] = (uint32_t)w.pcm0[q] | ((uint32_t)(float_to_int16_one(v) & 0xffff) << 16);
+                    LC_ST(o + q, (uint32_t)w.pcm0[q] | ((uint32_t)(float_to_int16_one(v) & 0xffff) << 16));
                 });
             }
         }

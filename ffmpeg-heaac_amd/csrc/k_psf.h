@@ -212,10 +212,14 @@ __device__ __forceinline__ void hybrid_fir(const float *in, const float *filt, f
 // hook(): called once, two thirds into the slot loop (the fused kernel touches the next frame's
 // records into L2 there: early enough to be back before they are needed, late enough to survive
 // in L2 until then).
+#ifndef PS_SO_AUX
+#define PS_SO_AUX 2
+#endif
+typedef GBufT<PS_SO_AUX> GBufSO;          // the state record out: written once per frame, read by the next launch
 template <bool HEAVY, bool ALIGNED8, bool DUAL, class W, class Hook = NoHook>
 __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, const signed char *kti,
                                         int is34, int kh, bool clear_state,
-                                        const GBuf &SI, const GBuf &SO, const GBuf &X,
+                                        const GBuf &SI, const GBufSO &SO, const GBuf &X,
                                         bool is_sub, int q, const v2f (&col)[32],
                                         bool dual = false, int kh2 = 0, bool clear2 = false, Hook hook = Hook())
 {
@@ -484,7 +488,8 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     int lane = opaque(lane_in);
     using WT = PsWaveT<GENERAL>;
     constexpr int XP = 38 * 64;
-    const GBuf SI(st_in), SO(st_out), X(Xrec);
+    const GBuf SI(st_in), X(Xrec);
+    const GBufSO SO(st_out);
     if constexpr (!FUSED) {
         const uint32_t *s = reinterpret_cast<const uint32_t *>(g_p);
         uint32_t *d = reinterpret_cast<uint32_t *>(&w.p);   // w.p is a reference into LDS
