@@ -530,7 +530,7 @@ int heaac_aac_parse_frame(const HeaacAacConfig *cfg, HeaacAacStream *st,
             if (elem_id == 15) elem_id += (int)bits(&b, 8) - 1;
             if (bits_left(&b) < 8 * elem_id) return HEAAC_PARSE_ERR_OVERREAD;
             /* decode_extension_payload (:1650-1690): every payload type is `cnt` bytes here; an SBR
-             * payload is reported, not parsed */
+             * payload is located here and parsed by sbr_parse.c */
             if (elem_id > 0) {
                 const int type = (int)bits(&b, 4);
                 if ((type == EXT_SBR_DATA || type == EXT_SBR_DATA_CRC) && fi.channels && fi.sbr_payload_bit < 0) {

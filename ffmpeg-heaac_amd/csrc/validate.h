@@ -1,7 +1,7 @@
 /* validate.h -- record validation at the C-ABI boundary, one implementation for the host
  * (single-frame codec path, unit tests) and the device (heaac_he_check_batch's kernel).
  *
- * The bitstream parsers are outside this library, so the records are where
+ * The batched entry points take records from any parser (heaac_parse.h is one), so the records are where
  * malformed data would arrive.  The rules are the reference parser's own rejections --
  * read_sbr_grid (aacsbr.c:609-745), sbr_make_f_master / sbr_make_f_derived (:296-593),
  * ff_ps_read_data / read_iid_data / read_icc_data (aacps.c:84-147, 150-279) -- plus the bounds the

@@ -320,8 +320,8 @@ int heaac_he_decode_batch_ex(HeaacDevice *dev, int cfg, int flags,
                              void *d_pcm, int pcm_format,
                              size_t n, void *stream);
 
-/* Record validation.  The bitstream parsers live outside this library, so the per-frame records are
- * where malformed data would arrive; the rules are the reference parser's own rejections
+/* Record validation.  The batched entry points take records from ANY parser (the library's own, heaac_parse.h,
+ * only writes records that pass), so the per-frame records are where malformed data would arrive; the rules are the reference parser's own rejections
  * (read_sbr_grid aacsbr.c:609-745, sbr_make_f_master / sbr_make_f_derived :296-593, ff_ps_read_data
  * aacps.c:150-279) plus the bounds the kernels index with.  heaac_he_decode_batch does NOT validate:
  * it clamps what forms a global address (a bad record gives wrong audio for that frame, never a

@@ -87,7 +87,7 @@ def _write_au(rng, si, aot, cpe, extras=True, sbr=None, quiet=False):
         bw.bits.extend(bits)
         bw.bits.extend([0] * (8 * cnt - 4 - len(bits)))
     elif extras and rng.random() < 0.5:
-        # fill element carrying an SBR payload (type 0xd): located, not parsed
+        # fill element carrying an SBR payload (type 0xd): located by this parser (random bits here)
         cnt = int(rng.integers(1, 20))
         bw.put(6, 3)
         if cnt >= 15:
