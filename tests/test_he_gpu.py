@@ -355,3 +355,16 @@ def test_hev2_phase_parameters_wider_than_the_grid(pkg, oracle, dev):
         nbad, where = _mismatch(d_state.cpu().numpy(), state)
         assert nbad == 0, "step %d: %d state words differ, first at %s" % (step, nbad, where)
     assert hit > 20
+
+
+@pytest.mark.parametrize("cfgname,ps_mode", [("CFG_HEV2", "mix"), ("CFG_HEV1", None)])
+def test_long_chains_stay_bit_exact(pkg, oracle, dev, cfgname, ps_mode):
+    """150 chained frames per stream with header switches, dropped payloads and PS outages along the way: every
+    carried quantity (noise and sine phase indices, the smoothing history, delay lines, the PS transient detector,
+    overlap and filterbank rings) goes round many times; state is handed on in place on the GPU."""
+    hdr = _synth().default_headers(pkg, extra=True, null=True)
+    n = 10
+    seen = _run_chain(pkg, oracle, dev, getattr(pkg, cfgname), n, 150, 77, hdr, ps_mode=ps_mode or "20",
+                      hdr_choice=np.arange(n) % (len(hdr) - 1), coupling=0.5,
+                      events=dict(lead_in=3, p_switch=0.04, p_drop=0.03, p_ps_off=0.03), in_place=True)
+    assert seen["reset"] > 20 and seen["drop"] > 10
