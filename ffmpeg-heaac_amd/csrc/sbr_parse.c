@@ -20,6 +20,7 @@
 #include "heaac_parse.h"
 #include "sbr_iso_tables.h"
 #include "parse_bits.h"
+#include "validate.h"
 
 /* table order of sbr_iso_tables.h = the reference's enums (aacsbr.c:45-56, aacps.c:50-61) */
 enum { T_ENV_15, F_ENV_15, T_ENV_BAL_15, F_ENV_BAL_15, T_ENV_30, F_ENV_30, T_ENV_BAL_30, F_ENV_BAL_30,
@@ -106,7 +107,10 @@ static int table_find_or_add(HeaacSbrHeaderTable *t, const HdrKey *k)
         } else {
             HeaacSbrHeader h;
             const int32_t *v = k->v;
-            if (heaac_sbr_make_header(&h, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11]) == 0) {
+            /* a header the reference builds but whose tables the decode kernels cannot take (no limiter band
+             * left over a dropped patch: the reference then reads gains of earlier frames) counts as not built */
+            if (heaac_sbr_make_header(&h, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11]) == 0 &&
+                heaac_check_sbr_header(&h) == HEAAC_BAD_NONE) {
                 t->h[t->n] = h;
                 t->key[t->n] = *k;
                 __sync_synchronize();                 /* the entry is complete before it becomes visible */

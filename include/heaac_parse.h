@@ -141,6 +141,8 @@ uint64_t heaac_aac_tables_fingerprint(void);
  *     quantiser into one of the coarser (the reference indexes its tables with it) (PS only: ps.start = 0);
  *   - after a failed element the channel state is rolled back to the previous frame's (the reference keeps
  *     a half-written one, bs_num_env = 8 included, and indexes with it on the next frame);
+ *   - a header whose limiter table comes out empty (a short SBR range over a dropped patch; the reference then
+ *     applies gains left by earlier frames) is treated like a failed sbr_reset;
  *   - after a failed sbr_reset the next header resets again (the reference would accept it as "unchanged"
  *     and read data against half-built tables); the very first header of a stream always resets.
  * An access unit WITHOUT an SBR payload (the reference re-applies the previous frame's already dequantised

@@ -368,3 +368,43 @@ def test_long_chains_stay_bit_exact(pkg, oracle, dev, cfgname, ps_mode):
                       hdr_choice=np.arange(n) % (len(hdr) - 1), coupling=0.5,
                       events=dict(lead_in=3, p_switch=0.04, p_drop=0.03, p_ps_off=0.03), in_place=True)
     assert seen["reset"] > 20 and seen["drop"] > 10
+
+
+def _header_zoo(pkg, rng, count):
+    """Distinct derived headers from random header fields at every SBR rate the reference accepts."""
+    seen, out = set(), []
+    rates = [16000, 22050, 24000, 32000, 44100, 48000, 64000, 88200, 96000]
+    tries = 0
+    while len(out) < count and tries < 200000:
+        tries += 1
+        try:
+            h = pkg.sbr_make_header(sample_rate=int(rng.choice(rates)), start_freq=int(rng.integers(0, 16)),
+                                    stop_freq=int(rng.integers(0, 16)), xover=int(rng.integers(0, 8)),
+                                    freq_scale=int(rng.integers(0, 4)), alter_scale=int(rng.integers(0, 2)),
+                                    noise_bands=int(rng.integers(0, 4)), limiter_bands=int(rng.integers(0, 4)),
+                                    limiter_gains=int(rng.integers(0, 4)), interpol_freq=int(rng.integers(0, 2)),
+                                    smoothing_mode=int(rng.integers(0, 2)), amp_res=int(rng.integers(0, 2)))
+        except ValueError:
+            continue
+        if pkg.validate_frame(pkg.CFG_HEV1, np.zeros(1, pkg.SBR_FRAME_DT), h) != "NONE":
+            continue                                   # (an empty limiter table: the parser refuses these headers too)
+        key = h.tobytes()
+        if key not in seen:
+            seen.add(key)
+            out.append(h)
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize("cfgname", ["CFG_HEV1", "CFG_HEV2"])
+def test_header_zoo(pkg, oracle, dev, cfgname):
+    """300 distinct band layouts (every accepted sampling rate, crossover, patch count 1..5, 1..5 noise bands,
+    limiter tables with and without the patch borders, m up to 48, kx down to the lowest the tables allow): one
+    stream per header, chained, with mid-stream switches between them."""
+    rng = np.random.default_rng(2025)
+    hdr = _header_zoo(pkg, rng, 300)
+    assert len(hdr) == 300
+    assert {int(x) for x in hdr["num_patches"]} >= {1, 2, 3, 4, 5} and {int(x) for x in hdr["n_q"]} >= {1, 2, 3, 4, 5}
+    assert hdr["m"].max() >= 40 and hdr["kx"].min() <= 12 and (hdr["kx"].astype(int) + hdr["m"]).max() >= 60
+    n = len(hdr)
+    _run_chain(pkg, oracle, dev, getattr(pkg, cfgname), n, 5, 88, hdr, ps_mode="mix", hdr_choice=np.arange(n),
+               coupling=0.4, events=dict(p_switch=0.2))
