@@ -357,3 +357,52 @@ def test_he_bitstream_to_pcm_on_the_gpu(pkg, oracle, dev, cpe):
         got = pcm.cpu().numpy()
         assert np.array_equal(got.view(np.uint32), ref_pcm.view(np.uint32)), step
         assert np.array_equal(d_state.cpu().numpy().view(np.uint32), state.view(np.uint32)), step
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cpe", [False, True])
+def test_record_space_of_the_writers_on_the_gpu(pkg, oracle, dev, cpe):
+    """The records the SBR / PS writers state (all four frame classes with every pointer value, coupled pairs,
+    PS in 10 / 20 / 34 bands with and without IID, ICC, IPD / OPD, explicit borders, borrowed envelopes) decoded on
+    the GPU and by the oracle: 160 streams x 10 frames, with header changes, on a synthetic core spectrum."""
+    import importlib
+    import torch
+    synth = importlib.import_module("ffmpeg_heaac_amd.synth")
+    rng = np.random.default_rng(91 + cpe)
+    n, steps = 160, 10
+    ch = 2 if cpe else 1
+    hcfg = pkg.CFG_HEV1 if cpe else pkg.CFG_HEV2
+    writers = [SW.SbrStreamWriter(pkg, ch, ps=not cpe, varfrac=0.6) for _ in range(n)]
+    table, index = [synth.null_header(pkg)], {}
+    state = np.zeros((n, pkg.STATE_WORDS[hcfg]), np.float32)
+    d_state = torch.from_numpy(state).cuda()
+    ics_chain = [synth._IcsChain(rng, n) for _ in range(ch)]
+    classes = set()
+    for step in range(steps):
+        sbr = np.zeros(n, pkg.SBR_FRAME_DT)
+        ps = np.zeros(n, pkg.PS_FRAME_DT)
+        for s, w in enumerate(writers):
+            new = step > 0 and rng.random() < 0.15
+            _, exp = w.frame(rng, new_header=new, respec=bool(new and rng.random() < 0.5))
+            key = exp["hdr"].tobytes()
+            if key not in index:
+                index[key] = len(table)
+                table.append(exp["hdr"])
+            sbr[s] = exp["sbr"][0]
+            sbr[s]["hdr"] = index[key]
+            if not cpe:
+                ps[s] = exp["ps"][0]
+            classes |= {c.cls for c in w.ch[:ch]}
+        hdr = np.concatenate(table)
+        ics = np.stack([c.step() for c in ics_chain], axis=1)
+        coeffs = np.ascontiguousarray(np.stack([synth._coeffs(rng, ics[:, c], 400) for c in range(ch)], axis=1))
+        for s in range(0, n, 7):
+            assert pkg.validate_frame(hcfg, sbr[s:s + 1], hdr, ps[s:s + 1] if not cpe else None) == "NONE", (step, s)
+        ref_pcm, state = oracle.he_decode_batch(hcfg, coeffs, ics, sbr, hdr, ps if not cpe else None, state, pkg.PCM_F32)
+        pcm, d_state = dev.he_decode(hcfg, torch.from_numpy(coeffs).cuda(), pkg.to_device(ics), pkg.to_device(sbr),
+                                     pkg.to_device(hdr), pkg.to_device(ps) if not cpe else None, d_state)
+        assert np.isfinite(ref_pcm).all(), step
+        bad = pcm.cpu().numpy().view(np.uint32) != ref_pcm.view(np.uint32)
+        assert not bad.any(), (step, np.nonzero(bad.any(axis=(1, 2)))[0][:8].tolist())
+        assert np.array_equal(d_state.cpu().numpy().view(np.uint32), state.view(np.uint32)), step
+    assert classes == {0, 1, 2, 3}
