@@ -216,10 +216,14 @@ __device__ __forceinline__ void hybrid_fir(const float *in, const float *filt, f
 #define PS_SO_AUX 2
 #endif
 typedef GBufT<PS_SO_AUX> GBufSO;          // the state record out: written once per frame, read by the next launch
+#ifndef PS_XROW_AUX
+#define PS_XROW_AUX 0
+#endif
+typedef GBufT<PS_XROW_AUX> GBufXR;        // the X rows of the slot loop (nt: +1.5 % -- the hybrid synthesis completes these lines later)
 template <bool HEAVY, bool ALIGNED8, bool DUAL, class W, class Hook = NoHook>
 __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, const signed char *kti,
                                         int is34, int kh, bool clear_state,
-                                        const GBuf &SI, const GBufSO &SO, const GBuf &X,
+                                        const GBuf &SI, const GBufSO &SO, const GBufXR &X,
                                         bool is_sub, int q, const v2f (&col)[32],
                                         bool dual = false, int kh2 = 0, bool clear2 = false, Hook hook = Hook())
 {
@@ -489,6 +493,7 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     using WT = PsWaveT<GENERAL>;
     constexpr int XP = 38 * 64;
     const GBuf SI(st_in), X(Xrec);
+    const GBufXR XR(Xrec);
     const GBufSO SO(st_out);
     if constexpr (!FUSED) {
         const uint32_t *s = reinterpret_cast<const uint32_t *>(g_p);
@@ -840,18 +845,18 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
         const int qcol = GENERAL ? (is_sub ? 0 : kh - nsub + nlow) : lane;
         if constexpr (GENERAL) {
             if (aligned8)
-                ps_band<true, true, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X, is_sub, qcol, col);
+                ps_band<true, true, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, XR, is_sub, qcol, col);
             else
-                ps_band<true, false, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X, is_sub, qcol, col);
+                ps_band<true, false, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, XR, is_sub, qcol, col);
         } else {
             // lanes 57..63 also carry the bands 64..70 of their own columns
             const bool dual = lane >= 57;
             const int kh2 = lane + 7;
             if (aligned8)
-                ps_band<true, true, true>(w, g_tab, M.kti, is34, kh, kh >= top, SI, SO, X, is_sub, qcol, col,
+                ps_band<true, true, true>(w, g_tab, M.kti, is34, kh, kh >= top, SI, SO, XR, is_sub, qcol, col,
                                           dual, kh2, kh2 >= top, hook);
             else
-                ps_band<true, false, true>(w, g_tab, M.kti, is34, kh, kh >= top, SI, SO, X, is_sub, qcol, col,
+                ps_band<true, false, true>(w, g_tab, M.kti, is34, kh, kh >= top, SI, SO, XR, is_sub, qcol, col,
                                            dual, kh2, kh2 >= top, hook);
         }
     }
@@ -861,10 +866,10 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     if constexpr (GENERAL) if (lane < nr_bands - 64) {
         const int kh = 64 + lane;
         if (aligned8)
-            ps_band<false, true, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X,
+            ps_band<false, true, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, XR,
                                         false, kh - nsub + nlow, col);
         else
-            ps_band<false, false, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, X,
+            ps_band<false, false, false>(w, g_tab, M.kti, is34, kh, switched || kh >= top, SI, SO, XR,
                                          false, kh - nsub + nlow, col);
     }
     STAMP(7);
