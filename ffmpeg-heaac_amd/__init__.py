@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libheaac_amd.so")
 # ---- constants (include/heaac_dsp.h) ----
 ONLY_LONG_SEQUENCE, LONG_START_SEQUENCE, EIGHT_SHORT_SEQUENCE, LONG_STOP_SEQUENCE = 0, 1, 2, 3
 CFG_LC_MONO, CFG_LC_STEREO, CFG_HEV1, CFG_HEV2, CFG_HEV1_MONO = 0, 1, 2, 3, 4
-PCM_F32, PCM_S16 = 0, 1
+PCM_F32, PCM_S16, PCM_S16_SSE2 = 0, 1, 2
 ADD_BIAS = 385.0
 
 ST_SAVED, ST_SBR, ST_SYNTH, ST_PS = 512, 1972, 1152, 4500

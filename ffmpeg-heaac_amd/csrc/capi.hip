@@ -166,7 +166,8 @@ extern "C" int heaac_lc_decode_batch(HeaacDevice *dev, int channels,
                                      void *d_pcm, int pcm_format, size_t n, void *stream)
 {
     if (!dev || channels < 1 || channels > 2 ||
-        (pcm_format != HEAAC_PCM_F32_PLANAR && pcm_format != HEAAC_PCM_S16_INTERLEAVED))
+        (pcm_format != HEAAC_PCM_F32_PLANAR && pcm_format != HEAAC_PCM_S16_INTERLEAVED &&
+         pcm_format != HEAAC_PCM_S16_INTERLEAVED_SSE2))
         return HEAAC_ERR_ARG;
     if (n == 0)
         return HEAAC_OK;
@@ -224,7 +225,8 @@ extern "C" int heaac_he_decode_batch_ex(HeaacDevice *dev, int cfg, int flags,
                                      size_t n, void *stream)
 {
     if (!dev || (cfg != HEAAC_CFG_HEV1 && cfg != HEAAC_CFG_HEV1_MONO && cfg != HEAAC_CFG_HEV2) ||
-        (pcm_format != HEAAC_PCM_F32_PLANAR && pcm_format != HEAAC_PCM_S16_INTERLEAVED) ||
+        (pcm_format != HEAAC_PCM_F32_PLANAR && pcm_format != HEAAC_PCM_S16_INTERLEAVED &&
+         pcm_format != HEAAC_PCM_S16_INTERLEAVED_SSE2) ||
         (flags & ~HEAAC_HE_DOWNSAMPLED))
         return HEAAC_ERR_ARG;
     if (n == 0)

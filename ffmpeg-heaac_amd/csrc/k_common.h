@@ -12,6 +12,7 @@
 // independent outputs, never from re-associating a sum.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "heaac_dsp.h"
 #include <stdint.h>
 #include "tables.h"
 
@@ -327,6 +328,19 @@ __device__ __forceinline__ int float_to_int16_one(float f)
     if (tmp & 0xf0000)
         tmp = (int)(0x43c0ffffu - (unsigned)tmp) >> 31;
     return (int)(short)(tmp - 0x8000);
+}
+
+// float_to_int16_sse2 (x86/dsputil_mmx.c:2356-2372): cvtps2dq rounds to nearest even and answers NaN or
+// |f| >= 2^31 with 0x80000000; packssdw saturates to int16.
+__device__ __forceinline__ int float_to_int16_sse2(float f)
+{
+    const int v = fabsf(f) < 2147483648.0f ? (int)rintf(f) : (int)0x80000000;
+    return v < -32768 ? -32768 : v > 32767 ? 32767 : v;
+}
+template <int FMT>
+__device__ __forceinline__ int pcm_int16(float f)
+{
+    return FMT == HEAAC_PCM_S16_INTERLEAVED_SSE2 ? float_to_int16_sse2(f) : float_to_int16_one(f);
 }
 
 // Copy `count` floats global -> LDS with the whole workgroup (count % 4 == 0,

@@ -518,7 +518,7 @@ void k_synth(const float *__restrict__ g_tab, const float *g_X,
             int16_t *o = reinterpret_cast<int16_t *>(g_pcm) + (pcm_frame0 + f) * 2048 * nout;
             for (int ch = 0; ch < nout; ch++)
                 channel(ch, [&](int i, int n, float v) {
-                    syn_st(o + (64 * i + n) * nout + ch, (int16_t)float_to_int16_one(v));
+                    syn_st(o + (64 * i + n) * nout + ch, (int16_t)pcm_int16<FMT>(v));
                 });
         }
         f = f1;
@@ -682,7 +682,7 @@ void k_synth_ds(const float *__restrict__ g_tab, const float *g_X,
             } else {
                 int16_t *o = reinterpret_cast<int16_t *>(g_pcm) + f * 1024 * nout + ch;
                 synth_ds_channel(S, S.vb[wave], X0, X1, v_in, v_out, scale, bias, lane,
-                                 [&](int i, int nn, float v) { o[(32 * i + nn) * nout] = (int16_t)float_to_int16_one(v); });
+                                 [&](int i, int nn, float v) { o[(32 * i + nn) * nout] = (int16_t)pcm_int16<FMT>(v); });
             }
         }
     }
@@ -727,7 +727,9 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
     } else
         return HEAAC_ERR_ARG;
     const unsigned long long units = (unsigned long long)n * ncore;
-    const float sf_scale = HEAAC_SF_SCALE;
+    // ac->sf_scale / ac->add_bias: the C conversion's, or the SIMD configuration's (aacdec.c:573-581)
+    const bool simd = pcm_format == HEAAC_PCM_S16_INTERLEAVED_SSE2;
+    const float sf_scale = simd ? -1.0f / 1024.0f : HEAAC_SF_SCALE;
 
     // queue heads of the kernels that draw frames dynamically (k_hfps: [0], k_synth: [2]); the static
     // stride stays where it measured faster (k_core_ana, k_hfadj: neighbouring waves share lines)
@@ -754,12 +756,15 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
             if (rc != HEAAC_OK) return rc;
         }
     }
-    const float scale = -1024 * sf_scale, bias = HEAAC_ADD_BIAS;
+    const float scale = -1024 * sf_scale, bias = simd ? 0.0f : HEAAC_ADD_BIAS;
     if (flags & HEAAC_HE_DOWNSAMPLED) {
         const dim3 gd(he_grid(n, SYN_WAVES)), bd(SYN_WAVES * WAVE);
         char *pcm = (char *)d_pcm + pcm_frame0 * nout * 1024 * (pcm_format == HEAAC_PCM_F32_PLANAR ? 4 : 2);
         if (pcm_format == HEAAC_PCM_F32_PLANAR)
             hipLaunchKernelGGL((k_synth_ds<HEAAC_PCM_F32_PLANAR>), gd, bd, 0, s, d_tab, d_ws_X, d_state_in, d_state_out,
+                               words, off_syn0, nout, (void *)pcm, scale, bias, (unsigned long long)n);
+        else if (simd)
+            hipLaunchKernelGGL((k_synth_ds<HEAAC_PCM_S16_INTERLEAVED_SSE2>), gd, bd, 0, s, d_tab, d_ws_X, d_state_in, d_state_out,
                                words, off_syn0, nout, (void *)pcm, scale, bias, (unsigned long long)n);
         else
             hipLaunchKernelGGL((k_synth_ds<HEAAC_PCM_S16_INTERLEAVED>), gd, bd, 0, s, d_tab, d_ws_X, d_state_in, d_state_out,
@@ -773,6 +778,10 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
                            (unsigned long long)n, (unsigned long long)pcm_frame0, d_queue + 2);
     else if (pcm_format == HEAAC_PCM_S16_INTERLEAVED)
         hipLaunchKernelGGL((k_synth<HEAAC_PCM_S16_INTERLEAVED>), g, b, 0, s, d_tab, d_ws_X, d_state_in, d_state_out,
+                           words, off_syn0, nout, d_pcm, scale, bias,
+                           (unsigned long long)n, (unsigned long long)pcm_frame0, d_queue + 2);
+    else if (simd)
+        hipLaunchKernelGGL((k_synth<HEAAC_PCM_S16_INTERLEAVED_SSE2>), g, b, 0, s, d_tab, d_ws_X, d_state_in, d_state_out,
                            words, off_syn0, nout, d_pcm, scale, bias,
                            (unsigned long long)n, (unsigned long long)pcm_frame0, d_queue + 2);
     else

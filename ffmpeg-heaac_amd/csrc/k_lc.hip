@@ -71,6 +71,8 @@ void k_lc_decode(const float *__restrict__ g_tab, const uint16_t *__restrict__ g
             const bool eight = (half ? ics1.window_sequence[0] : ics0.window_sequence[0]) == HEAAC_EIGHT_SHORT_SEQUENCE;
             imdct_half_regs(L, reinterpret_cast<const float *>(w.T[half]), w.T[half], eight, hl);
         }
+        // add_bias: 385 for the C conversion, 0 for the SIMD configuration (aacdec.c:573-581)
+        constexpr float LC_BIAS = FMT == HEAAC_PCM_S16_INTERLEAVED_SSE2 ? 0.0f : HEAAC_ADD_BIAS;
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             if (c == 1 && !have1) break;
@@ -81,20 +83,20 @@ void k_lc_decode(const float *__restrict__ g_tab, const uint16_t *__restrict__ g
             float *sout = g_state_out + u * 512;
             if (FMT == HEAAC_PCM_F32_PLANAR) {
                 float *o = reinterpret_cast<float *>(g_pcm) + u * 1024;
-                core2_window(L, ics, HEAAC_ADD_BIAS, buf, sin_, sout, lane, [&](int q, float v) { LC_ST(o + q, v); });
+                core2_window(L, ics, LC_BIAS, buf, sin_, sout, lane, [&](int q, float v) { LC_ST(o + q, v); });
             } else if (CH == 1) {
                 int16_t *o = reinterpret_cast<int16_t *>(g_pcm) + u * 1024;
-                core2_window(L, ics, HEAAC_ADD_BIAS, buf, sin_, sout, lane,
-                             [&](int q, float v) { LC_ST(o + q, (int16_t)float_to_int16_one(v)); });
+                core2_window(L, ics, LC_BIAS, buf, sin_, sout, lane,
+                             [&](int q, float v) { LC_ST(o + q, (int16_t)pcm_int16<FMT>(v)); });
             } else if (c == 0) {
-                core2_window(L, ics, HEAAC_ADD_BIAS, buf, sin_, sout, lane,
-                             [&](int q, float v) { w.pcm0[q] = (uint16_t)float_to_int16_one(v); });
+                core2_window(L, ics, LC_BIAS, buf, sin_, sout, lane,
+                             [&](int q, float v) { w.pcm0[q] = (uint16_t)pcm_int16<FMT>(v); });
                 wave_sync();
             } else {
                 // float_to_int16_interleave (dsputil.c:3989-4001): L from LDS, R fresh
                 uint32_t *o = reinterpret_cast<uint32_t *>(g_pcm) + (u0 / 2) * 1024;
-                core2_window(L, ics, HEAAC_ADD_BIAS, buf, sin_, sout, lane, [&](int q, float v) {
-                    LC_ST(o + q, (uint32_t)w.pcm0[q] | ((uint32_t)(float_to_int16_one(v) & 0xffff) << 16));
+                core2_window(L, ics, LC_BIAS, buf, sin_, sout, lane, [&](int q, float v) {
+                    LC_ST(o + q, (uint32_t)w.pcm0[q] | ((uint32_t)(pcm_int16<FMT>(v) & 0xffff) << 16));
                 });
             }
         }
@@ -240,6 +242,8 @@ extern "C" int heaac_launch_lc(const float *d_tab, const uint16_t *d_rev, int ch
     else if (channels == 1 && pcm_format == HEAAC_PCM_S16_INTERLEAVED) LAUNCH(1, HEAAC_PCM_S16_INTERLEAVED);
     else if (channels == 2 && pcm_format == HEAAC_PCM_F32_PLANAR) LAUNCH(2, HEAAC_PCM_F32_PLANAR);
     else if (channels == 2 && pcm_format == HEAAC_PCM_S16_INTERLEAVED) LAUNCH(2, HEAAC_PCM_S16_INTERLEAVED);
+    else if (channels == 1 && pcm_format == HEAAC_PCM_S16_INTERLEAVED_SSE2) LAUNCH(1, HEAAC_PCM_S16_INTERLEAVED_SSE2);
+    else if (channels == 2 && pcm_format == HEAAC_PCM_S16_INTERLEAVED_SSE2) LAUNCH(2, HEAAC_PCM_S16_INTERLEAVED_SSE2);
     else return HEAAC_ERR_ARG;
 #undef LAUNCH
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;

@@ -62,6 +62,13 @@ enum {
                                  [frame][ch][len]                          */
     HEAAC_PCM_S16_INTERLEAVED = 1, /* avcodec_decode_audio3 output:
                                  [frame][len][ch] int16 (dsputil.c:3989)   */
+    /* The decoder as it is configured when float_to_int16_interleave is one of the x86 SIMD versions
+     * (aacdec.c:577-581: add_bias = 0, sf_scale = 1 / -1024, sf_offset = 60 -- the CALLER's spectrum is
+     * 32768 x the C path's, an exact power of two) with float_to_int16_interleave_sse2's conversion
+     * (x86/dsputil_mmx.c:2356-2372, 2405-2436): cvtps2dq = round to nearest even, NaN and |x| >= 2^31 give
+     * 0x80000000; packssdw saturates.  Same layout as HEAAC_PCM_S16_INTERLEAVED.  (AAC-Main prediction reads
+     * sf_scale too, aacdec.c:1285-1287: heaac_spectral_tools_batch computes it for the C path only.) */
+    HEAAC_PCM_S16_INTERLEAVED_SSE2 = 2,
 };
 
 /* ------------------------------------------------------------------ */

@@ -529,6 +529,17 @@ int oracle_float_to_int16_one(float f)
     return (int16_t)(tmp - 0x8000);
 }
 
+/* cvtps2dq (round to nearest even under the default MXCSR; NaN and |f| >= 2^31 give the "integer
+ * indefinite" 0x80000000) followed by packssdw (signed saturation) */
+int oracle_float_to_int16_sse2(float f)
+{
+    long v;
+    if (!(fabsf(f) < 2147483648.0f))
+        return -32768;
+    v = lrintf(f);
+    return v < -32768 ? -32768 : v > 32767 ? 32767 : (int)v;
+}
+
 static void store_pcm(void *pcm, int fmt, size_t frame, int nch, int len,
                       float *const *ch_ret)
 {
@@ -537,6 +548,12 @@ static void store_pcm(void *pcm, int fmt, size_t frame, int nch, int len,
         float *p = (float *)pcm + frame * nch * len;
         for (c = 0; c < nch; c++)
             memcpy(p + (size_t)c * len, ch_ret[c], sizeof(float) * len);
+    } else if (fmt == HEAAC_PCM_S16_INTERLEAVED_SSE2) {
+        /* float_to_int16_interleave_sse2, x86/dsputil_mmx.c:2356-2372, 2405-2436 */
+        int16_t *p = (int16_t *)pcm + frame * nch * len;
+        for (i = 0; i < len; i++)
+            for (c = 0; c < nch; c++)
+                p[i * nch + c] = (int16_t)oracle_float_to_int16_sse2(ch_ret[c][i]);
     } else {
         /* dsputil.c:3989-4001 ff_float_to_int16_interleave_c */
         int16_t *p = (int16_t *)pcm + frame * nch * len;
@@ -568,7 +585,9 @@ int oracle_lc_decode_batch(int channels, const float *coeffs, const HeaacIcs *ic
         for (c = 0; c < channels; c++) {
             size_t u = f * channels + c;
             memcpy(saved, state_in + u * 512, sizeof(saved));
-            oracle_imdct_and_windowing(coeffs + u * 1024, &ics[u], saved, ret[c], HEAAC_ADD_BIAS);
+            /* add_bias of the C conversion or of the SIMD configuration (aacdec.c:573-581) */
+            oracle_imdct_and_windowing(coeffs + u * 1024, &ics[u], saved, ret[c],
+                                       pcm_format == HEAAC_PCM_S16_INTERLEAVED_SSE2 ? 0.0f : HEAAC_ADD_BIAS);
             memcpy(state_out + u * 512, saved, sizeof(saved));
         }
         store_pcm(pcm, pcm_format, f, channels, 1024, rp);

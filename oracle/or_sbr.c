@@ -703,7 +703,7 @@ typedef struct {
     float *W, *Xlow, *Xhigh, *Y, *Xsbr, *X;
 } dump_ptrs;
 
-static int he_frame(int cfg, int flags, const float *coeffs, const HeaacIcs *ics,
+static int he_frame(int cfg, int flags, int simd, const float *coeffs, const HeaacIcs *ics,
                     const HeaacSbrFrame *fr, const HeaacSbrHeader *hdr_tab, size_t n_hdr,
                     const HeaacPsFrame *ps,
                     const float *st_in, float *st_out, float *ret[2], const dump_ptrs *dp)
@@ -717,7 +717,9 @@ static int he_frame(int cfg, int flags, const float *coeffs, const HeaacIcs *ics
     int ch, nch;
     /* state record sub-offsets */
     size_t off_saved[2], off_sbr[2], off_syn[2], off_ps = 0;
-    const float sf_scale = HEAAC_SF_SCALE;
+    /* ac->sf_scale, ac->add_bias: the C conversion's or the SIMD configuration's (aacdec.c:573-581) */
+    const float sf_scale = simd ? -1.0f / 1024.0f : HEAAC_SF_SCALE;
+    const float add_bias = simd ? 0.0f : HEAAC_ADD_BIAS;
 
     if (n_hdr && fr->hdr >= n_hdr)
         return HEAAC_ERR_ARG;
@@ -821,9 +823,9 @@ static int he_frame(int cfg, int flags, const float *coeffs, const HeaacIcs *ics
                 memcpy(Xds[0][i], s.X[ch][0][i], sizeof(Xds[0][i]));
                 memcpy(Xds[1][i], s.X[ch][1][i], sizeof(Xds[1][i]));
             }
-            oracle_qmf_synthesis_ds(&Xds[0][0][0], v, ret[ch], -1024 * sf_scale, HEAAC_ADD_BIAS);
+            oracle_qmf_synthesis_ds(&Xds[0][0][0], v, ret[ch], -1024 * sf_scale, add_bias);
         } else {
-            qmf_synthesis(ret[ch], s.X[ch], v, HEAAC_ADD_BIAS, -1024 * sf_scale);
+            qmf_synthesis(ret[ch], s.X[ch], v, add_bias, -1024 * sf_scale);
         }
         memcpy(st_out + off_syn[ch], v, sizeof(v));
     }
@@ -874,7 +876,7 @@ int oracle_he_decode_batch_ex(int cfg, int flags, const float *coeffs, const Hea
             memcpy(tmp, sin_, words * sizeof(float));
             sin_ = tmp;
         }
-        r = he_frame(cfg, flags, coeffs + f * ncore * 1024, ics + f * ncore, &sbr[f], hdr, n_hdr,
+        r = he_frame(cfg, flags, pcm_format == HEAAC_PCM_S16_INTERLEAVED_SSE2, coeffs + f * ncore * 1024, ics + f * ncore, &sbr[f], hdr, n_hdr,
                      ps ? &ps[f] : NULL, sin_, sout, ret, NULL);
         free(tmp);
         if (r < 0)
@@ -900,7 +902,7 @@ int oracle_he_decode_debug(int cfg, const float *coeffs, const HeaacIcs *ics,
     if (cfg_words(cfg) < 0)
         return HEAAC_ERR_ARG;
     oracle_tables();
-    r = he_frame(cfg, 0, coeffs, ics, sbr, hdr, 0, ps, state_in, state_out, ret, &dp);
+    r = he_frame(cfg, 0, 0, coeffs, ics, sbr, hdr, 0, ps, state_in, state_out, ret, &dp);
     if (r < 0)
         return r;
     if (pcm_f32)

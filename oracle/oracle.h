@@ -75,7 +75,8 @@ void oracle_imdct_and_windowing(const float *coeffs, const HeaacIcs *ics,
                                 float bias);                       /* aacdec.c:1741 */
 
 /* ---- float -> int16 (a27) ---- */
-int  oracle_float_to_int16_one(float f);                           /* dsputil.c:3972 */
+int  oracle_float_to_int16_one(float f);
+int  oracle_float_to_int16_sse2(float f);                          /* x86/dsputil_mmx.c:2356-2372 */
 
 /* ---- SBR stages on plain arrays (a11, a20), for stage tests ---- */
 void oracle_qmf_analysis(const float *in /*1024*/, float *xhist /*288 in/out*/,

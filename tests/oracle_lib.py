@@ -62,7 +62,7 @@ PS_INBUF, PS_DELAY, PS_APDELAY, PS_PEAK, PS_PSMOOTH, PS_PDIFF, PS_H, PS_HIST = \
     0, 60, 2608, 4108, 4142, 4176, 4210, 4482
 
 CFG_LC_MONO, CFG_LC_STEREO, CFG_HEV1, CFG_HEV2, CFG_HEV1_MONO = 0, 1, 2, 3, 4
-PCM_F32, PCM_S16 = 0, 1
+PCM_F32, PCM_S16, PCM_S16_SSE2 = 0, 1, 2
 
 STATE_WORDS = {
     CFG_LC_MONO: ST_SAVED,

@@ -408,3 +408,50 @@ def test_header_zoo(pkg, oracle, dev, cfgname):
     n = len(hdr)
     _run_chain(pkg, oracle, dev, getattr(pkg, cfgname), n, 5, 88, hdr, ps_mode="mix", hdr_choice=np.arange(n),
                coupling=0.4, events=dict(p_switch=0.2))
+
+
+@pytest.mark.parametrize("cfgname", ["CFG_HEV1", "CFG_HEV2", "CFG_LC_STEREO", "CFG_LC_MONO"])
+def test_simd_float_to_int16_configuration(pkg, oracle, dev, cfgname):
+    """HEAAC_PCM_S16_INTERLEAVED_SSE2: add_bias 0, sf_scale 1 / -1024 and the cvtps2dq + packssdw conversion
+    (aacdec.c:577-581, x86/dsputil_mmx.c:2356-2372), spectrum 32768 x the C path's; loud frames saturate on both
+    sides of the range; the downsampled bank too."""
+    import torch
+    synth = _synth()
+    rng = np.random.default_rng(61)
+    cfg = getattr(pkg, cfgname)
+    n, steps = 33, 4
+    big = np.float32(32768.0)
+    if cfgname.startswith("CFG_LC"):
+        ch = pkg.CORE_CH[cfg]
+        state = np.zeros((n, ch * 512), np.float32)
+        d_state = torch.from_numpy(state).cuda()
+        sat = False
+        for coeffs, ics in synth.lc_stream(rng, n, steps, ch):
+            coeffs *= big
+            coeffs[::5] *= 300.0
+            ref, state = oracle.lc_decode_batch(ch, coeffs, ics, state, oracle.PCM_S16_SSE2)
+            pcm, d_state = dev.lc_decode(ch, torch.from_numpy(coeffs).cuda(), pkg.to_device(ics), d_state,
+                                         pcm_format=pkg.PCM_S16_SSE2)
+            assert np.array_equal(pcm.cpu().numpy(), ref)
+            assert np.array_equal(_bits(d_state.cpu().numpy()), _bits(state))
+            sat |= bool((ref == 32767).any() and (ref == -32768).any())
+        assert sat
+        return
+    hdr = synth.default_headers(pkg, extra=True)
+    for downsampled in (False, True):
+        state = np.zeros((n, pkg.STATE_WORDS[cfg]), np.float32)
+        d_state = torch.from_numpy(state).cuda()
+        sat = False
+        for fr in synth.he_stream(rng, cfg, n, steps, hdr, ps_mode="mix", hdr_choice=np.arange(n) % len(hdr), coupling=0.5):
+            coeffs = fr["coeffs"] * big
+            coeffs[::5] *= 2000.0
+            ref, state = oracle.he_decode_batch(cfg, coeffs, fr["ics"], fr["sbr"], hdr, fr["ps"], state,
+                                                oracle.PCM_S16_SSE2, downsampled=downsampled)
+            pcm, d_state = dev.he_decode(cfg, torch.from_numpy(coeffs).cuda(), pkg.to_device(fr["ics"]),
+                                         pkg.to_device(fr["sbr"]), pkg.to_device(hdr),
+                                         pkg.to_device(fr["ps"]) if fr["ps"] is not None else None, d_state,
+                                         pcm_format=pkg.PCM_S16_SSE2, downsampled=downsampled)
+            assert np.array_equal(pcm.cpu().numpy(), ref)
+            assert _mismatch(d_state.cpu().numpy(), state)[0] == 0
+            sat |= bool((ref == 32767).any() and (ref == -32768).any())
+        assert sat

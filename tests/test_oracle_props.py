@@ -193,3 +193,34 @@ def test_independent_coupling_is_the_reference_expression(pkg, oracle):
     assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
     assert np.array_equal(out[0, 1], pcm[0, 1])
     assert np.array_equal(s16[:2].transpose(0, 2, 1), oracle.float_to_int16(out[:2]))
+
+
+def test_simd_configuration_equals_the_c_path_on_in_range_samples(pkg, oracle):
+    """The decoder configured for the x86 SIMD float_to_int16 (add_bias 0, spectrum 32768 x larger, aacdec.c:577-581;
+    cvtps2dq + packssdw, x86/dsputil_mmx.c:2356-2372) against the C configuration (bias 385, dsputil.c:3972-3981) on
+    the same AAC-LC frames: the IMDCT is linear and 32768 is a power of two, so the two int16 outputs agree except where
+    the bias trick's rounding at 385 +- x differs from round-to-nearest-even by one step, and at the clip edges
+    (SURVEY App. A item 5).  Single values: ties go to even, NaN and 2^31 give -32768."""
+    import importlib
+    synth = importlib.import_module("ffmpeg_heaac_amd.synth")
+    rng = np.random.default_rng(23)
+    n = 40
+    state = np.zeros((n, 1024), np.float32)
+    state2 = state.copy()
+    differ = total = 0
+    for coeffs, ics in synth.lc_stream(rng, n, 4, 2):
+        a, state = oracle.lc_decode_batch(2, coeffs, ics, state, oracle.PCM_S16)
+        b, state2 = oracle.lc_decode_batch(2, coeffs * np.float32(32768.0), ics, state2, oracle.PCM_S16_SSE2)
+        # the overlap state scales with the spectrum; after a short-window frame the C path's has been through
+        # "+ 385 - 385" (aacdec.c:1795-1796) and carries that rounding
+        assert np.allclose(state2, state * np.float32(32768.0), rtol=1e-6, atol=2.0)
+        d = np.abs(a.astype(int) - b.astype(int))
+        assert d.max() <= 1
+        differ += int((d != 0).sum()); total += d.size
+    assert differ < 0.02 * total
+    f = oracle.lib().oracle_float_to_int16_sse2
+    import ctypes as C
+    f.argtypes = [C.c_float]
+    assert [f(x) for x in (0.5, 1.5, 2.5, -0.5, -1.5, 32767.49, 32767.5, 40000.0, -32768.5, -40000.0)] == \
+        [0, 2, 2, 0, -2, 32767, 32767, 32767, -32768, -32768]
+    assert f(float("nan")) == -32768 and f(2147483648.0) == -32768 and f(-3e9) == -32768 and f(2147483520.0) == 32767
