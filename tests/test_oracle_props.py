@@ -274,3 +274,49 @@ def test_hf_generator_matches_the_standard_formulas(pkg, oracle):
             checked += 1
             shaped += int(b > 0.3 and abs(a0) > 0.05 and np.abs(want - x[l]).max() > 1e-2 * scale)
     assert checked > 150 and shaped > 40            # the prediction term is at work in many of them
+
+
+def test_envelope_adjuster_delivers_the_transmitted_energy(pkg, oracle):
+    """What the SBR envelope adjuster is FOR (ISO/IEC 14496-3 4.6.18.7): with the limiter open (bs_limiter_gains = 3),
+    no smoothing, a negligible noise floor and no sinusoids, the energy of the adjusted signal over every envelope and
+    limiter band equals the transmitted one, sum over the band of E_orig = 64 * 2^(q / (2 - amp_res)), where the
+    source is not empty.  This pins dequantisation, mapping, energy estimation, gain and boost together to the
+    standard's intent, independently of anybody's code."""
+    import importlib
+    synth = importlib.import_module("ffmpeg_heaac_amd.synth")
+    rng = np.random.default_rng(33)
+    cfg = pkg.CFG_HEV1_MONO
+    checked = 0
+    for variant in (dict(), dict(start_freq=2, stop_freq=8, xover=2, freq_scale=0, noise_bands=1),
+                    dict(start_freq=0, stop_freq=3, xover=1, freq_scale=0, noise_bands=3, amp_res=0)):
+        hdr = pkg.sbr_make_header(limiter_gains=3, smoothing_mode=1, interpol_freq=1, **variant)
+        for trial in range(6):
+            fr = next(iter(synth.he_stream(rng, cfg, 1, 1, hdr, core_bins=900)))
+            c = fr["sbr"][0]["ch"][0]
+            c["noise_facs_q"][:] = 40                       # Q = 2^(6 - 40)
+            c["bs_add_harmonic_flag"] = 0
+            d = oracle.he_decode_debug(cfg, fr["coeffs"], fr["ics"], fr["sbr"], hdr, None,
+                                       np.zeros((1, pkg.STATE_WORDS[cfg]), np.float32))
+            h = hdr[0]
+            kx, L = int(h["kx"]), int(c["bs_num_env"])
+            alpha = 1.0 if c["bs_amp_res"] else 0.5
+            Y = d["Y"].astype(np.float64); Y2 = Y[..., 0] ** 2 + Y[..., 1] ** 2              # [38][64]
+            Xh = d["Xhigh"].astype(np.float64); X2 = Xh[..., 0] ** 2 + Xh[..., 1] ** 2       # [64][40]
+            for e in range(L):
+                a, b = 2 * int(c["t_env"][e]), 2 * int(c["t_env"][e + 1])
+                res = int(c["bs_freq_res"][e + 1])
+                table = h["f_tablehigh"] if res else h["f_tablelow"]
+                nb = int(h["n"][res])
+                e_orig = np.zeros(64)
+                for i in range(nb):
+                    e_orig[int(table[i]):int(table[i + 1])] = 64.0 * 2.0 ** (alpha * int(c["env_facs_q"][e][i]))
+                for q in range(int(h["n_lim"])):
+                    k0, k1 = int(h["f_tablelim"][q]), int(h["f_tablelim"][q + 1])
+                    e_curr = X2[k0:k1, a + 2:b + 2].mean(axis=1)
+                    if (e_curr < 1e3).any():
+                        continue                                                       # an empty source band: the gain caps apply
+                    got = Y2[a:b, k0:k1].mean(axis=0).sum()
+                    want = e_orig[k0:k1].sum()
+                    assert abs(got / want - 1.0) < 2e-3, (variant, trial, e, q, got, want)
+                    checked += 1
+    assert checked > 60
