@@ -320,3 +320,38 @@ def test_envelope_adjuster_delivers_the_transmitted_energy(pkg, oracle):
                     assert abs(got / want - 1.0) < 2e-3, (variant, trial, e, q, got, want)
                     checked += 1
     assert checked > 60
+
+
+@pytest.mark.parametrize("fine", [0, 1])
+def test_ps_intensity_difference_is_the_standards_level_ratio(pkg, oracle, fine):
+    """Parametric Stereo semantics (ISO/IEC 14496-3 8.6.4.6.2, mixing procedure Ra with full coherence): an IID index
+    asks for a level ratio 10 log10(L^2 / R^2) of -25 ... +25 dB (15 steps) or -50 ... +50 dB (31 steps), and with
+    ICC index 0 the decorrelated signal takes no part.  The decoded channels must show that ratio, and their power
+    sum must stay the mono signal's (c1^2 + c2^2 = 2, shared between two channels)."""
+    synth = _synth()
+    rng = np.random.default_rng(40 + fine)
+    hdr = synth.default_headers(pkg)
+    coarse = [-25, -18, -14, -10, -7, -4, -2, 0, 2, 4, 7, 10, 14, 18, 25]
+    fine_t = [-50, -45, -40, -35, -30, -25, -22, -19, -16, -13, -10, -8, -6, -4, -2, 0,
+              2, 4, 6, 8, 10, 13, 16, 19, 22, 25, 30, 35, 40, 45, 50]
+    table = fine_t if fine else coarse
+    idxs = [-15, -9, -3, 0, 4, 11, 15] if fine else [-7, -4, -1, 0, 2, 5, 7]
+    n = len(idxs)
+    st2 = np.zeros((n, pkg.STATE_WORDS[pkg.CFG_HEV2]), np.float32)
+    st1 = np.zeros((n, pkg.STATE_WORDS[pkg.CFG_HEV1_MONO]), np.float32)
+    for t, fr in enumerate(synth.he_stream(rng, pkg.CFG_HEV2, n, 5, hdr)):
+        for s, ix in enumerate(idxs):
+            fr["ps"][s]["iid_par"][:] = ix
+            fr["ps"][s]["icc_par"][:] = 0
+            fr["ps"][s]["iid_quant"] = fine
+        pcm2, st2 = oracle.he_decode_batch(pkg.CFG_HEV2, fr["coeffs"], fr["ics"], fr["sbr"], hdr, fr["ps"], st2)
+        pcm1, st1 = oracle.he_decode_batch(pkg.CFG_HEV1_MONO, fr["coeffs"], fr["ics"], fr["sbr"], hdr, None, st1)
+    bias = np.float32(385.0)
+    for s, ix in enumerate(idxs):
+        l = (pcm2[s, 0] - bias).astype(np.float64); r = (pcm2[s, 1] - bias).astype(np.float64)
+        m = (pcm1[s, 0] - bias).astype(np.float64)
+        el, er, em = (l * l).sum(), (r * r).sum(), (m * m).sum()
+        want_db = table[ix + (15 if fine else 7)]
+        # (at 40 dB and more the weak channel sits near the float grid around the 385 bias)
+        assert abs(10 * np.log10(el / er) - want_db) < (0.05 if abs(want_db) < 40 else 0.3), (ix, 10 * np.log10(el / er), want_db)
+        assert abs((el + er) / (2 * em) - 1.0) < 1e-3, (ix, (el + er) / (2 * em))
