@@ -355,3 +355,30 @@ def test_ps_intensity_difference_is_the_standards_level_ratio(pkg, oracle, fine)
         # (at 40 dB and more the weak channel sits near the float grid around the 385 bias)
         assert abs(10 * np.log10(el / er) - want_db) < (0.05 if abs(want_db) < 40 else 0.3), (ix, 10 * np.log10(el / er), want_db)
         assert abs((el + er) / (2 * em) - 1.0) < 1e-3, (ix, (el + er) / (2 * em))
+
+
+def test_ps_coherence_index_sets_the_inter_channel_correlation(pkg, oracle):
+    """ICC semantics (ISO/IEC 14496-3 8.6.4.6.2, procedure Ra): with IID 0 the two channels are cos(a) s + sin(a) d and
+    cos(a) s - sin(a) d, a = arccos(rho) / 2, d the decorrelated signal -- their normalised correlation is rho when d
+    carries the energy of s and is uncorrelated with it.  The decoded channels follow the standard's rho table
+    (1, 0.937, 0.84118, 0.60092, 0.36764, 0, -0.589, -1) to within what the decorrelator's imperfection allows."""
+    synth = _synth()
+    rng = np.random.default_rng(44)
+    hdr = synth.default_headers(pkg)
+    rho = [1.0, 0.937, 0.84118, 0.60092, 0.36764, 0.0, -0.589, -1.0]
+    n = 8
+    st2 = np.zeros((n, pkg.STATE_WORDS[pkg.CFG_HEV2]), np.float32)
+    acc = np.zeros((n, 3))
+    for t, fr in enumerate(synth.he_stream(rng, pkg.CFG_HEV2, n, 12, hdr, core_bins=900)):
+        for s in range(n):
+            fr["ps"][s]["iid_par"][:] = 0
+            fr["ps"][s]["icc_par"][:] = s
+        pcm2, st2 = oracle.he_decode_batch(pkg.CFG_HEV2, fr["coeffs"], fr["ics"], fr["sbr"], hdr, fr["ps"], st2)
+        if t >= 3:
+            l = (pcm2[:, 0] - np.float32(385.0)).astype(np.float64); r = (pcm2[:, 1] - np.float32(385.0)).astype(np.float64)
+            acc[:, 0] += (l * r).sum(axis=1); acc[:, 1] += (l * l).sum(axis=1); acc[:, 2] += (r * r).sum(axis=1)
+    corr = acc[:, 0] / np.sqrt(acc[:, 1] * acc[:, 2])
+    assert abs(corr[0] - 1.0) < 1e-6 and abs(corr[7] + 1.0) < 0.15, corr
+    assert np.all(np.diff(corr) < 0), corr                       # strictly ordered like the table
+    assert np.abs(corr - np.array(rho)).max() < 0.15, (corr, rho)
+    assert np.allclose(acc[:, 1] / acc[:, 2], 1.0, atol=0.05)    # IID 0: equal levels
