@@ -17,7 +17,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libheaac_amd.so")
+# HEAAC_LIB_PATH: measurement tooling (tools/abv.sh) points the binding at a variant build under ab/
+# without touching the product library; unset everywhere else.
+LIB_PATH = os.environ.get("HEAAC_LIB_PATH") or os.path.join(_HERE, "libheaac_amd.so")
 
 # ---- constants (include/heaac_dsp.h) ----
 ONLY_LONG_SEQUENCE, LONG_START_SEQUENCE, EIGHT_SHORT_SEQUENCE, LONG_STOP_SEQUENCE = 0, 1, 2, 3

@@ -107,6 +107,23 @@ int heaac_asc_parse(HeaacAacConfig *c, const uint8_t *buf, int size)
     return specific;
 }
 
+/* GASpecificConfig behind the AudioSpecificConfig (decode_ga_specific_config, aacdec.c:401-452): the
+ * 960-sample frame length is refused as the reference refuses it; dependsOnCoreCoder / coreCoderDelay and
+ * extensionFlag are read past.  channel_config 0 (a program config element follows) is outside this slice. */
+int heaac_ga_specific_config(const HeaacAacConfig *c, const uint8_t *buf, int size, int bit_offset)
+{
+    if (!c || !buf || size <= 0 || bit_offset < 0) return HEAAC_PARSE_ERR_ARG;
+    Bits b;
+    bits_init(&b, buf, size);
+    skip(&b, bit_offset);
+    if (bit1(&b)) return HEAAC_PARSE_ERR_UNSUPPORTED;          /* frameLengthFlag: 960/120 MDCT window */
+    if (bit1(&b)) skip(&b, 14);                                /* dependsOnCoreCoder: coreCoderDelay */
+    bit1(&b);                                                  /* extensionFlag (no ER object types here) */
+    if (c->chan_config == 0) return HEAAC_PARSE_ERR_UNSUPPORTED;
+    if (b.over) return HEAAC_PARSE_ERR_OVERREAD;
+    return 0;
+}
+
 int heaac_adts_parse_header(HeaacAdtsHeader *h, const uint8_t *buf, int size)
 {
     if (!h || !buf || size < 7) return HEAAC_PARSE_ERR_ARG;

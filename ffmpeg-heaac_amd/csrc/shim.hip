@@ -346,6 +346,7 @@ static void publish_cfg(HeaacCodecContext *avctx, const HeaacDecoderPriv *p)
 {
     const int he = p->out_len == 2048;
     avctx->channels = p->nout;
+    avctx->channel_layout = p->nout == 2 ? HEAAC_CH_LAYOUT_STEREO : HEAAC_CH_LAYOUT_MONO;   // output_configure, aacdec.c:224-301
     avctx->frame_size = p->out_len;
     avctx->sample_rate = he ? 2 * p->m4ac.sample_rate : p->m4ac.sample_rate;
 }
@@ -354,7 +355,10 @@ static int dec_init_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p)
 {
     p->bitstream = 1;
     if (avctx->extradata && avctx->extradata_size > 0) {
-        if (heaac_asc_parse(&p->m4ac, avctx->extradata, avctx->extradata_size) < 0) return -1;
+        const int specific = heaac_asc_parse(&p->m4ac, avctx->extradata, avctx->extradata_size);
+        if (specific < 0) return -1;
+        // decode_ga_specific_config (aacdec.c:401-452): 960-sample frames are refused at init
+        if (heaac_ga_specific_config(&p->m4ac, avctx->extradata, avctx->extradata_size, specific) < 0) return -1;
         if (p->m4ac.chan_config != 1 && p->m4ac.chan_config != 2) return -1;      // this slice: one SCE or one CPE
         if (p->m4ac.object_type != HEAAC_AOT_AAC_LC && p->m4ac.object_type != HEAAC_AOT_AAC_MAIN) return -1;
         p->have_m4ac = 1;
@@ -387,7 +391,7 @@ static int dec_init_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p)
     if (p->have_m4ac) {
         // tentative, as decode_audio_specific_config leaves it; the first access unit settles implicit SBR
         const int he = p->m4ac.sbr == 1;
-        set_cfg(p, he ? (p->m4ac.chan_config == 2 ? HEAAC_CFG_HEV1 : HEAAC_CFG_HEV2)
+        set_cfg(p, he ? (p->m4ac.chan_config == 2 ? HEAAC_CFG_HEV1 : (p->m4ac.ps != 0 ? HEAAC_CFG_HEV2 : HEAAC_CFG_HEV1_MONO))
                       : (p->m4ac.chan_config == 2 ? HEAAC_CFG_LC_STEREO : HEAAC_CFG_LC_MONO));
         publish_cfg(avctx, p);
     }
@@ -479,8 +483,9 @@ static int dec_frame_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p, vo
 static int dec_init(HeaacCodecContext *avctx)
 {
     HeaacDecoderPriv *p = (HeaacDecoderPriv *)avctx->priv_data;
-    if (avctx->cfg == HEAAC_CFG_FROM_STREAM) return dec_init_bitstream(avctx, p);
-    set_cfg(p, avctx->cfg);
+    avctx->sample_fmt = HEAAC_SAMPLE_FMT_S16;                          // aacdec.c:568
+    if (!HEAAC_SUBID_IS_RECORDS(avctx->sub_id)) return dec_init_bitstream(avctx, p);
+    set_cfg(p, avctx->sub_id & 0xff);
     if (!p->ncore) return -1;
     if (heaac_device_create(&p->dev, 64) != HEAAC_OK) return -1;
     if (hipMalloc((void **)&p->d_state, p->words * 4) != hipSuccess ||
@@ -494,6 +499,7 @@ static int dec_init(HeaacCodecContext *avctx)
     for (int i = 0; i < MAX_HDRS; i++) p->hdr[i].kx = 32;      // kx' = 32, m = 0 (aacsbr.c:130)
     if (hipMemcpy(p->d_hdr, p->hdr, sizeof(p->hdr), hipMemcpyHostToDevice) != hipSuccess) return -1;
     avctx->channels = p->nout;
+    avctx->channel_layout = p->nout == 2 ? HEAAC_CH_LAYOUT_STEREO : HEAAC_CH_LAYOUT_MONO;
     avctx->frame_size = p->out_len;
     if (!avctx->sample_rate) avctx->sample_rate = 48000;
     return 0;
@@ -584,6 +590,14 @@ extern "C" HeaacCodec heaac_aac_decoder = {
     dec_sample_fmts, dec_channel_layouts,
 };
 
+extern "C" void heaac_codec_get_context_defaults(HeaacCodecContext *avctx)
+{
+    // avcodec_get_context_defaults2(s, AVMEDIA_TYPE_UNKNOWN), options.c: everything the decoder looks at is 0
+    // except the media type
+    memset(avctx, 0, sizeof(*avctx));
+    avctx->codec_type = HEAAC_MEDIA_TYPE_UNKNOWN;
+}
+
 extern "C" int heaac_codec_open(HeaacCodecContext *avctx, HeaacCodec *codec)
 {
     // utils.c:462-531
@@ -591,6 +605,18 @@ extern "C" int heaac_codec_open(HeaacCodecContext *avctx, HeaacCodec *codec)
     avctx->priv_data = calloc(1, codec->priv_data_size);
     if (!avctx->priv_data) return -12;       /* AVERROR(ENOMEM) */
     avctx->codec = codec;
+    // utils.c:506-514: an unset type / id takes the codec's, a different one is refused
+    if ((avctx->codec_type == HEAAC_MEDIA_TYPE_UNKNOWN || avctx->codec_type == codec->type) && avctx->codec_id == 0) {
+        avctx->codec_type = codec->type;
+        avctx->codec_id = codec->id;
+    }
+    if (avctx->codec_id != codec->id || avctx->codec_type != codec->type) {
+        free(avctx->priv_data);
+        avctx->priv_data = NULL;
+        avctx->codec = NULL;
+        return -1;
+    }
+    avctx->frame_number = 0;
     const int ret = codec->init(avctx);
     if (ret < 0) {
         codec->close(avctx);
@@ -608,7 +634,9 @@ extern "C" int heaac_codec_decode(HeaacCodecContext *avctx, int16_t *samples, in
     if (!avctx || !avctx->codec || !samples || !frame_size_ptr || !avpkt) return -1;
     if (avpkt->size) {
         if (*frame_size_ptr < HEAAC_MAX_AUDIO_FRAME_SIZE) return -1;
-        return avctx->codec->decode(avctx, samples, frame_size_ptr, avpkt);
+        const int ret = avctx->codec->decode(avctx, samples, frame_size_ptr, avpkt);
+        avctx->frame_number++;                                         // utils.c:655
+        return ret;
     }
     *frame_size_ptr = 0;
     return 0;

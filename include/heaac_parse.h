@@ -59,6 +59,10 @@ typedef struct HeaacAacConfig {
 /* AudioSpecificConfig -> config.  Returns the bit offset of the specific config (as the reference
  * does) or a negative HEAAC_PARSE_ERR_*. */
 int heaac_asc_parse(HeaacAacConfig *c, const uint8_t *buf, int size);
+/* GASpecificConfig at the bit offset heaac_asc_parse returned (decode_ga_specific_config,
+ * aacdec.c:401-452): 0, or HEAAC_PARSE_ERR_UNSUPPORTED for 960-sample frames (frameLengthFlag) and for
+ * channel configuration 0 (program config element), HEAAC_PARSE_ERR_OVERREAD when the buffer ends first. */
+int heaac_ga_specific_config(const HeaacAacConfig *c, const uint8_t *buf, int size, int bit_offset);
 
 /* AACADTSHeaderInfo (aac_parser.h / aac_parser.c:29-70) */
 typedef struct HeaacAdtsHeader {

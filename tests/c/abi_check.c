@@ -27,6 +27,30 @@ struct ref_AVCodec {
     const int *supported_samplerates; const int *sample_fmts; const int64_t *channel_layouts;
 };
 
+/* what struct AVPacket looks like (avcodec.h:960-1002), field for field */
+struct ref_AVPacket {
+    int64_t pts, dts; uint8_t *data; int size, stream_index, flags, duration;
+    void (*destruct)(struct ref_AVPacket *); void *priv; int64_t pos, convergence_duration;
+};
+/* the head of struct AVCodecContext of libavcodec 52.78 (avcodec.h:1032-1293: every member up to codec_id, in
+ * order, LIBAVCODEC_VERSION_MAJOR < 53 members included); the members behind it are not declared: channel_layout
+ * (:2502) and the size are pinned as the numbers a build of that header gives on LP64 (976, 1088). */
+struct ref_AVRational { int num, den; };
+struct ref_AVCodecContext_head {
+    const void *av_class; int bit_rate, bit_rate_tolerance, flags, sub_id, me_method;
+    uint8_t *extradata; int extradata_size; struct ref_AVRational time_base; int width, height, gop_size;
+    int pix_fmt, rate_emu; void (*draw_horiz_band)(void *, const void *, int *, int, int, int);
+    int sample_rate, channels, sample_fmt, frame_size, frame_number, real_pict_num, delay;
+    float qcompress, qblur; int qmin, qmax, max_qdiff, max_b_frames; float b_quant_factor;
+    int rc_strategy, b_frame_strategy, hurry_up; struct ref_AVCodec *codec; void *priv_data;
+    int rtp_payload_size; void (*rtp_callback)(void *, void *, int, int);
+    int mv_bits, header_bits, i_tex_bits, p_tex_bits, i_count, p_count, skip_count, misc_bits, frame_bits;
+    void *opaque; char codec_name[32]; int codec_type, codec_id;
+};
+#define REF_AVCTX_SIZE 1088
+#define REF_AVCTX_CHANNEL_LAYOUT 976
+union ref_AVCodecContext { struct ref_AVCodecContext_head h; uint8_t bytes[REF_AVCTX_SIZE]; int64_t align_; };
+
 static unsigned lfg;                      /* any deterministic generator */
 static float frand(void) { lfg = lfg * 1664525u + 1013904223u; return (int)(lfg >> 8) / 8388608.0f - 1.0f; }
 
@@ -52,6 +76,29 @@ static int cpu_checks(void)
     CHECK(offsetof(HeaacCodec, long_name) == offsetof(struct ref_AVCodec, long_name));
     CHECK(offsetof(HeaacCodec, sample_fmts) == offsetof(struct ref_AVCodec, sample_fmts));
     CHECK(offsetof(HeaacCodec, channel_layouts) == offsetof(struct ref_AVCodec, channel_layouts));
+    /* the callbacks receive libavcodec's own AVCodecContext / AVPacket */
+#define SAME(T, R, f) CHECK(offsetof(T, f) == offsetof(R, f) && sizeof(((T *)0)->f) == sizeof(((R *)0)->f))
+    CHECK(sizeof(HeaacPacket) == sizeof(struct ref_AVPacket));
+    SAME(HeaacPacket, struct ref_AVPacket, pts); SAME(HeaacPacket, struct ref_AVPacket, dts);
+    SAME(HeaacPacket, struct ref_AVPacket, data); SAME(HeaacPacket, struct ref_AVPacket, size);
+    SAME(HeaacPacket, struct ref_AVPacket, flags); SAME(HeaacPacket, struct ref_AVPacket, destruct);
+    SAME(HeaacPacket, struct ref_AVPacket, pos); SAME(HeaacPacket, struct ref_AVPacket, convergence_duration);
+    SAME(HeaacCodecContext, struct ref_AVCodecContext_head, av_class);
+    SAME(HeaacCodecContext, struct ref_AVCodecContext_head, sub_id);
+    SAME(HeaacCodecContext, struct ref_AVCodecContext_head, extradata);
+    SAME(HeaacCodecContext, struct ref_AVCodecContext_head, extradata_size);
+    SAME(HeaacCodecContext, struct ref_AVCodecContext_head, draw_horiz_band);
+    SAME(HeaacCodecContext, struct ref_AVCodecContext_head, sample_rate);
+    SAME(HeaacCodecContext, struct ref_AVCodecContext_head, channels);
+    SAME(HeaacCodecContext, struct ref_AVCodecContext_head, sample_fmt);
+    SAME(HeaacCodecContext, struct ref_AVCodecContext_head, frame_size);
+    SAME(HeaacCodecContext, struct ref_AVCodecContext_head, frame_number);
+    SAME(HeaacCodecContext, struct ref_AVCodecContext_head, codec);
+    SAME(HeaacCodecContext, struct ref_AVCodecContext_head, priv_data);
+    SAME(HeaacCodecContext, struct ref_AVCodecContext_head, codec_type);
+    SAME(HeaacCodecContext, struct ref_AVCodecContext_head, codec_id);
+    CHECK(offsetof(HeaacCodecContext, channel_layout) == REF_AVCTX_CHANNEL_LAYOUT);
+    CHECK(sizeof(HeaacCodecContext) == REF_AVCTX_SIZE && sizeof(union ref_AVCodecContext) == REF_AVCTX_SIZE);
     CHECK(!strcmp(heaac_aac_decoder.name, "aac") && heaac_aac_decoder.type == 1);
     CHECK(heaac_aac_decoder.sample_fmts[0] == HEAAC_SAMPLE_FMT_S16 && heaac_aac_decoder.sample_fmts[1] == -1);
     CHECK(heaac_aac_decoder.channel_layouts[0] == 4 && heaac_aac_decoder.channel_layouts[1] == 3 &&
@@ -80,8 +127,11 @@ static int no_device_checks(void)
     CHECK(heaac_device_create(&d, 16) == HEAAC_ERR_NODEVICE && d == NULL);
     CHECK(ff_mdct_init(&c, 11, 1, 1.0) == -1);
     CHECK(av_fft_init(9, 1) == NULL);
-    HeaacCodecContext ctx; memset(&ctx, 0, sizeof(ctx)); ctx.cfg = HEAAC_CFG_LC_STEREO;
+    HeaacCodecContext ctx; heaac_codec_get_context_defaults(&ctx); ctx.sub_id = HEAAC_SUBID_RECORDS(HEAAC_CFG_LC_STEREO);
     CHECK(heaac_codec_open(&ctx, &heaac_aac_decoder) < 0 && ctx.priv_data == NULL);
+    /* a context of another codec is refused before anything is allocated (utils.c:510-513) */
+    heaac_codec_get_context_defaults(&ctx); ctx.codec_id = 0x15001;            /* CODEC_ID_MP3 */
+    CHECK(heaac_codec_open(&ctx, &heaac_aac_decoder) < 0 && ctx.priv_data == NULL && ctx.codec == NULL);
     return fails;
 }
 
@@ -152,9 +202,10 @@ static int gpu_checks(void)
     uint8_t *pkt = malloc(psize);
     HeaacCodecContext ctx[2];
     for (int k = 0; k < 2; k++) {
-        memset(&ctx[k], 0, sizeof(ctx[k])); ctx[k].cfg = HEAAC_CFG_LC_STEREO;
+        heaac_codec_get_context_defaults(&ctx[k]); ctx[k].sub_id = HEAAC_SUBID_RECORDS(HEAAC_CFG_LC_STEREO);
         CHECK(heaac_codec_open(&ctx[k], &heaac_aac_decoder) == 0);
-        CHECK(ctx[k].channels == 2 && ctx[k].frame_size == 1024);
+        CHECK(ctx[k].channels == 2 && ctx[k].frame_size == 1024 && ctx[k].channel_layout == HEAAC_CH_LAYOUT_STEREO);
+        CHECK(ctx[k].codec_id == HEAAC_CODEC_ID_AAC && ctx[k].codec_type == 1 && ctx[k].sample_fmt == HEAAC_SAMPLE_FMT_S16);
     }
     unsigned any = 0;
     for (int frame = 0; frame < 3; frame++) {
@@ -164,9 +215,10 @@ static int gpu_checks(void)
         float *co = (float *)(pkt + sizeof(hp));
         for (int i = 0; i < 2048; i++) co[i] = frand() * (4096.0f / (1024.0f * 32768.0f));
         for (int k = 0; k < 2; k++) {
-            HeaacPacket ap = { pkt, psize };
+            HeaacPacket ap; memset(&ap, 0, sizeof(ap)); ap.data = pkt; ap.size = psize;
             int size = HEAAC_MAX_AUDIO_FRAME_SIZE;
             CHECK(heaac_codec_decode(&ctx[k], pcm[k], &size, &ap) == psize);
+            CHECK(ctx[k].frame_number == frame + 1);
             CHECK(size == 1024 * 2 * 2);
         }
         CHECK(!memcmp(pcm[0], pcm[1], 4096));
@@ -174,34 +226,56 @@ static int gpu_checks(void)
     }
     CHECK(any);
     { /* too small an output buffer, and a packet of the wrong configuration, are refused */
-        HeaacPacket ap = { pkt, psize };
+        HeaacPacket ap; memset(&ap, 0, sizeof(ap)); ap.data = pkt; ap.size = psize;
         int size = 100;
         CHECK(heaac_codec_decode(&ctx[0], pcm[0], &size, &ap) < 0);
         ((HeaacFramePacket *)pkt)->cfg = HEAAC_CFG_HEV2; size = HEAAC_MAX_AUDIO_FRAME_SIZE;
         CHECK(heaac_codec_decode(&ctx[0], pcm[0], &size, &ap) < 0);
     }
     for (int k = 0; k < 2; k++) CHECK(heaac_codec_close(&ctx[k]) == 0);
-    { /* the reference's own packet: an AAC access unit, configuration from extradata (AAC-LC 48 kHz mono).
-         One SCE with max_sfb = 0 (silence), then END: 32 bits, zero padding behind. */
-        static const uint8_t asc[2] = { 0x11, 0x88 };
-        static const uint8_t au[12] = { 0x00, 0xc8, 0x00, 0x07 };
-        HeaacCodecContext bs; memset(&bs, 0, sizeof(bs));
-        bs.cfg = HEAAC_CFG_FROM_STREAM; bs.extradata = asc; bs.extradata_size = 2;
-        CHECK(heaac_codec_open(&bs, &heaac_aac_decoder) == 0);
-        CHECK(bs.channels == 1 && bs.frame_size == 1024 && bs.sample_rate == 48000);
+    { /* the reference's own packet in the reference's own records: a context and a packet laid out as libavcodec
+         lays them out (transcribed above, filled the way avcodec_alloc_context / av_init_packet fill them) go
+         through open / decode / close by pointer cast, as libavcodec's dispatch would pass them.  AAC-LC 48 kHz
+         mono from extradata; one SCE with max_sfb = 0 (silence), then END: 32 bits, zero padding behind. */
+        static uint8_t asc[2] = { 0x11, 0x88 };
+        static uint8_t au[12] = { 0x00, 0xc8, 0x00, 0x07 };
+        union ref_AVCodecContext rc; memset(&rc, 0, sizeof(rc));
+        rc.h.codec_type = -1;                                    /* AVMEDIA_TYPE_UNKNOWN */
+        rc.h.time_base.num = 0; rc.h.time_base.den = 1;
+        rc.h.extradata = asc; rc.h.extradata_size = 2;
+        HeaacCodecContext *bs = (HeaacCodecContext *)&rc;
+        CHECK(heaac_codec_open(bs, &heaac_aac_decoder) == 0);
+        CHECK(rc.h.channels == 1 && rc.h.frame_size == 1024 && rc.h.sample_rate == 48000 && rc.h.sample_fmt == 1);
+        CHECK(rc.h.codec_id == 0x15002 && rc.h.codec_type == 1 && rc.h.priv_data != NULL);
+        CHECK(rc.h.codec == (struct ref_AVCodec *)&heaac_aac_decoder);
+        int64_t layout; memcpy(&layout, rc.bytes + REF_AVCTX_CHANNEL_LAYOUT, 8);
+        CHECK(layout == 4);                                      /* CH_LAYOUT_MONO */
         for (int frame = 0; frame < 2; frame++) {
-            HeaacPacket ap = { au, (int)sizeof(au) };
+            struct ref_AVPacket rp; memset(&rp, 0, sizeof(rp));
+            rp.pts = rp.dts = (int64_t)0x8000000000000000ULL;    /* AV_NOPTS_VALUE */
+            rp.pos = -1; rp.data = au; rp.size = (int)sizeof(au);
             int size = HEAAC_MAX_AUDIO_FRAME_SIZE;
-            CHECK(heaac_codec_decode(&bs, pcm[0], &size, &ap) == (int)sizeof(au));
-            CHECK(size == 1024 * 2);
+            CHECK(heaac_codec_decode(bs, pcm[0], &size, (HeaacPacket *)&rp) == (int)sizeof(au));
+            CHECK(size == 1024 * 2 && rc.h.frame_number == frame + 1);
             int nz = 0;
             for (int i = 0; i < 1024; i++) nz |= pcm[0][i];
             CHECK(nz == 0);
         }
-        HeaacPacket bad = { asc, 2 };                  /* not an access unit */
+        /* the callbacks themselves, as the reference's table entry would be called */
+        {
+            struct ref_AVPacket rp; memset(&rp, 0, sizeof(rp)); rp.data = au; rp.size = (int)sizeof(au);
+            int size = HEAAC_MAX_AUDIO_FRAME_SIZE;
+            const struct ref_AVCodec *tab = (const struct ref_AVCodec *)&heaac_aac_decoder;
+            CHECK(tab->decode(&rc, pcm[0], &size, &rp) == (int)sizeof(au) && size == 2048);
+        }
+        struct ref_AVPacket bad; memset(&bad, 0, sizeof(bad)); bad.data = asc; bad.size = 2;   /* not an access unit */
         int size = HEAAC_MAX_AUDIO_FRAME_SIZE;
-        CHECK(heaac_codec_decode(&bs, pcm[0], &size, &bad) < 0);
-        CHECK(heaac_codec_close(&bs) == 0);
+        CHECK(heaac_codec_decode(bs, pcm[0], &size, (HeaacPacket *)&bad) < 0);
+        CHECK(heaac_codec_close(bs) == 0 && rc.h.priv_data == NULL && rc.h.codec == NULL);
+        /* 960-sample frames (frameLengthFlag) are refused at open, as decode_ga_specific_config refuses them */
+        static uint8_t asc960[2] = { 0x11, 0x8c };
+        memset(&rc, 0, sizeof(rc)); rc.h.codec_type = -1; rc.h.extradata = asc960; rc.h.extradata_size = 2;
+        CHECK(heaac_codec_open(bs, &heaac_aac_decoder) < 0 && rc.h.priv_data == NULL);
     }
     free(pcm[0]); free(pcm[1]); free(pkt);
     return fails;

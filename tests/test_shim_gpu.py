@@ -84,12 +84,34 @@ def test_ff_fft_permute_calc(pkg, oracle, dev, nbits):
 
 
 class HeaacPacket(C.Structure):
-    _fields_ = [("data", C.c_void_p), ("size", C.c_int)]
+    """AVPacket (avcodec.h:960-1002)"""
+    _fields_ = [("pts", C.c_int64), ("dts", C.c_int64), ("data", C.c_void_p), ("size", C.c_int),
+                ("stream_index", C.c_int), ("flags", C.c_int), ("duration", C.c_int), ("destruct", C.c_void_p),
+                ("priv", C.c_void_p), ("pos", C.c_int64), ("convergence_duration", C.c_int64)]
+
+    def __init__(self, data=None, size=0):
+        super().__init__(pts=-2 ** 63, dts=-2 ** 63, data=data, size=size, pos=-1)
 
 
 class HeaacCodecContext(C.Structure):
-    _fields_ = [("sample_rate", C.c_int), ("channels", C.c_int), ("frame_size", C.c_int), ("cfg", C.c_int),
-                ("codec", C.c_void_p), ("priv_data", C.c_void_p), ("extradata", C.c_char_p), ("extradata_size", C.c_int)]
+    """AVCodecContext of libavcodec 52.78 (include/heaac_codec.h): named where the decoder reads or writes."""
+    _fields_ = [("av_class", C.c_void_p), ("bit_rate", C.c_int), ("bit_rate_tolerance", C.c_int), ("flags", C.c_int),
+                ("sub_id", C.c_int), ("me_method", C.c_int), ("extradata", C.c_char_p), ("extradata_size", C.c_int),
+                ("opaque_44", C.c_int * 7), ("draw_horiz_band", C.c_void_p), ("sample_rate", C.c_int),
+                ("channels", C.c_int), ("sample_fmt", C.c_int), ("frame_size", C.c_int), ("frame_number", C.c_int),
+                ("opaque_100", C.c_int * 13), ("codec", C.c_void_p), ("priv_data", C.c_void_p),
+                ("opaque_168", C.c_int * 24), ("codec_type", C.c_int), ("codec_id", C.c_int),
+                ("opaque_272", C.c_int * 176), ("channel_layout", C.c_int64), ("request_channel_layout", C.c_int64),
+                ("opaque_992", C.c_int * 24)]
+
+    def __init__(self, cfg=-1, extradata=None, extradata_size=0):
+        # cfg >= 0: parser-output packets of that configuration (HEAAC_SUBID_RECORDS); -1: AAC access units
+        super().__init__(codec_type=-1, sub_id=(0x48450000 | cfg) if cfg >= 0 else 0, extradata=extradata,
+                         extradata_size=extradata_size)
+
+
+assert C.sizeof(HeaacPacket) == 72 and C.sizeof(HeaacCodecContext) == 1088
+assert HeaacCodecContext.priv_data.offset == 160 and HeaacCodecContext.channel_layout.offset == 976
 
 
 @pytest.mark.parametrize("cfgname", ["CFG_LC_STEREO", "CFG_HEV1", "CFG_HEV2"])

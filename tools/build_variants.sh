@@ -1,8 +1,16 @@
 #!/bin/bash
-# Build the product library and (ab/libstamps.so) a copy with in-kernel phase stamps; run here, before gpurun.
+# Build the product library and variants of it under ab/ (run here, before gpurun):
+#   tools/build_variants.sh                      product + ab/libstamps.so (in-kernel phase stamps)
+#   tools/build_variants.sh name "-DFOO -DBAR"   additionally ab/libname.so with those extra flags
+#   VARIANT_SED='s/a/b/' tools/build_variants.sh name ""   ... with a sed script applied to the copied sources
 set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
 make -C $root/ffmpeg-heaac_amd/csrc -j8 -s
-rm -rf /tmp/csrc_stamps && mkdir -p /tmp/csrc_stamps $root/ab
-cp $root/ffmpeg-heaac_amd/csrc/*.hip $root/ffmpeg-heaac_amd/csrc/*.h $root/ffmpeg-heaac_amd/csrc/*.c $root/ffmpeg-heaac_amd/csrc/Makefile /tmp/csrc_stamps/
-make -C /tmp/csrc_stamps -j8 -s ROOT=$root EXTRA="-DHF_STAMPS -DPS_STAMPS" OUT=$root/ab/libstamps.so
+mkdir -p $root/ab
+build() {   # name, flags, sed script
+    rm -rf /tmp/csrc_$1 && mkdir -p /tmp/csrc_$1
+    cp $root/ffmpeg-heaac_amd/csrc/*.hip $root/ffmpeg-heaac_amd/csrc/*.h $root/ffmpeg-heaac_amd/csrc/*.c $root/ffmpeg-heaac_amd/csrc/Makefile /tmp/csrc_$1/
+    if [ -n "$3" ]; then sed -i -E "$3" /tmp/csrc_$1/*.hip /tmp/csrc_$1/*.h; fi
+    make -C /tmp/csrc_$1 -j8 -s ROOT=$root EXTRA="$2" OUT=$root/ab/lib$1.so
+}
+if [ -n "$1" ]; then build "$1" "$2" "$VARIANT_SED"; else build stamps "-DHF_STAMPS -DPS_STAMPS" ""; fi
