@@ -28,11 +28,49 @@ struct HeaacDevice {
     hipStream_t lane[HE_MAX_LANES];
     hipEvent_t fork, join[HE_MAX_LANES];
     int lanes;
+    // The HE calls share the workspace and the queue heads, so they must not overlap: the stream of the
+    // last HE call and an event behind its launches are kept, and a call that arrives on ANOTHER stream
+    // while that work is still in flight is refused (HEAAC_ERR_ARG) instead of racing on the workspace.
+    hipStream_t owner;
+    hipEvent_t done;
+    int owner_valid, done_recorded;
 };
+
+// Claim the HE workspace for stream s (see HeaacDevice::owner).
+static int he_claim(HeaacDevice *d, hipStream_t s, bool *capturing)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    *capturing = cs != hipStreamCaptureStatusNone;
+    if (d->owner_valid && d->owner != s) {
+        // the earlier call's work must have finished; inside a capture that cannot be asked
+        if (*capturing) return HEAAC_ERR_ARG;
+        if (d->done_recorded) {
+            const hipError_t q = hipEventQuery(d->done);
+            if (q == hipErrorNotReady) return HEAAC_ERR_ARG;
+            if (q != hipSuccess) { (void)hipGetLastError(); return HEAAC_ERR_HIP; }
+        }
+    }
+    d->owner = s;
+    d->owner_valid = 1;
+    return HEAAC_OK;
+}
+static int he_release(HeaacDevice *d, hipStream_t s, bool capturing, int rc)
+{
+    d->done_recorded = 0;
+    if (!capturing) {
+        if (hipEventRecord(d->done, s) != hipSuccess) return rc == HEAAC_OK ? HEAAC_ERR_HIP : rc;
+        d->done_recorded = 1;
+    }
+    return rc;
+}
 static int he_lanes()
 {
-    const char *env = getenv("HEAAC_LANES");                 /* tuning knob */
-    int l = env ? atoi(env) : 2;
+    int l = 2;
+#ifdef HEAAC_TUNING
+    const char *env = getenv("HEAAC_LANES");                 /* -DHEAAC_TUNING builds only: lanes sweep */
+    if (env) l = atoi(env);
+#endif
     return l < 1 ? 1 : l > HE_MAX_LANES ? HE_MAX_LANES : l;
 }
 #define HE_LANES he_lanes()
@@ -67,8 +105,10 @@ extern "C" const char *heaac_strerror(int err)
 static size_t he_chunk_frames(size_t max_frames)
 {
     size_t cap = HE_CHUNK_FRAMES;
-    const char *env = getenv("HEAAC_CHUNK_FRAMES");          /* tuning knob */
+#ifdef HEAAC_TUNING
+    const char *env = getenv("HEAAC_CHUNK_FRAMES");          /* -DHEAAC_TUNING builds only: chunk sweep */
     if (env && atol(env) >= 64) cap = (size_t)atol(env);
+#endif
     size_t chunk = max_frames < cap ? max_frames : cap;
     return chunk < 64 ? 64 : chunk;
 }
@@ -119,7 +159,8 @@ extern "C" int heaac_device_create(HeaacDevice **out, size_t max_frames)
         rc = HEAAC_ERR_HIP;
     free(t);
     d->lanes = HE_LANES;
-    if (rc == HEAAC_OK && hipEventCreateWithFlags(&d->fork, hipEventDisableTiming) != hipSuccess)
+    if (rc == HEAAC_OK && (hipEventCreateWithFlags(&d->fork, hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&d->done, hipEventDisableTiming) != hipSuccess))
         rc = HEAAC_ERR_HIP;
     for (int k = 0; k < d->lanes && rc == HEAAC_OK; k++)
         if (hipEventCreateWithFlags(&d->join[k], hipEventDisableTiming) != hipSuccess ||
@@ -145,6 +186,7 @@ extern "C" void heaac_device_destroy(HeaacDevice *d)
         if (d->join[k]) (void)hipEventDestroy(d->join[k]);
     }
     if (d->fork) (void)hipEventDestroy(d->fork);
+    if (d->done) (void)hipEventDestroy(d->done);
     free(d);
 }
 
@@ -242,6 +284,9 @@ extern "C" int heaac_he_decode_batch_ex(HeaacDevice *dev, int cfg, int flags,
                              (pcm_format == HEAAC_PCM_F32_PLANAR ? 4 : 2);
     const size_t set_floats = dev->chunk * (WS_W_FLOATS + WS_X_FLOATS);
     hipStream_t s = (hipStream_t)stream;
+    bool capturing = false;
+    const int claim = he_claim(dev, s, &capturing);
+    if (claim != HEAAC_OK) return claim;
     // one chunk: everything on the caller's stream; more: fork onto the two lanes and join again
     // (event fork / join, so the call stays capturable into a hipGraph)
     const bool lanes = n > dev->chunk && dev->sets > 1;
@@ -272,7 +317,7 @@ extern "C" int heaac_he_decode_batch_ex(HeaacDevice *dev, int cfg, int flags,
                 hipStreamWaitEvent(s, dev->join[k], 0) != hipSuccess)
                 rc = rc == HEAAC_OK ? HEAAC_ERR_HIP : rc;
     }
-    return rc;
+    return he_release(dev, s, capturing, rc);
 }
 
 extern "C" int heaac_qmf_analysis_batch(HeaacDevice *dev, const float *d_in,

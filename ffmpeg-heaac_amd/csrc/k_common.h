@@ -86,7 +86,10 @@ __device__ __forceinline__ int opaque(int v)
     return v;
 }
 
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+    __device__ __forceinline__ void operator()(int) const {}
+};
 
 // ---------------------------------------------------------------------------
 // L2 prefetch of a record the wave will read a little later: every lane loads one dword of a

@@ -217,11 +217,7 @@ void k_core_ana(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_
             const float *uu = c ? w.x0u1 : w.tu;
             float *Wo = g_W + (c ? u1 : u0) * 2048;
             for (int t = lane; t < 2048; t += WAVE) {
-#ifdef CA_NT_ST
-                __builtin_nontemporal_store(uu[(t >> 6) * 65 + (t & 63)], Wo + t);
-#else
                 Wo[t] = uu[(t >> 6) * 65 + (t & 63)];
-#endif
             }
         }
         wave_sync();
@@ -285,7 +281,7 @@ struct SynLdsT {
 };
 typedef SynLdsT<SYN_WAVES> SynLds;
 
-#ifdef HF_STAMPS
+#ifdef HEAAC_TUNING
 #define SSTAMP(i) TL_STAMP(i, (i) == 0)
 #else
 #define SSTAMP(i) do {} while (0)
@@ -314,33 +310,13 @@ struct SynIn {
 // (A lane reading its own 256-byte row in 16-byte pieces pulls every line through the vector L1 eight
 // times; with 7 waves per CU the L1 keeps none of them.)
 #define SYN_STAGE_STRIDE 68       // floats per staged row: 64 + 4 (b128 reads of 64 different rows spread over all banks)
-// Streamed once: X rows and ring state in, PCM and ring state out (SYN_NT_LD / SYN_NT_ST: non-temporal policy).
+// Streamed once: X rows and ring state in (default policy: non-temporal loads measured no gain), PCM and
+// ring state out (non-temporal stores: -5.9 % kernel time, profiles/r02_experiments.md E7).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 syn_ld4(const f32x4 *p)
-{
-#ifdef SYN_NT_LD
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ float syn_ld1(const float *p)
-{
-#ifdef SYN_NT_LD
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
+__device__ __forceinline__ f32x4 syn_ld4(const f32x4 *p) { return *p; }
+__device__ __forceinline__ float syn_ld1(const float *p) { return *p; }
 template <class T>
-__device__ __forceinline__ void syn_st(T *p, T v)
-{
-#ifndef SYN_PLAIN_ST
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
+__device__ __forceinline__ void syn_st(T *p, T v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void syn_load(const float *X0, const float *X1, const float *v_in, int lane, SynIn &d)
 {
     const f32x4 *p0 = reinterpret_cast<const f32x4 *>(X0), *p1 = reinterpret_cast<const f32x4 *>(X1);
@@ -699,11 +675,16 @@ static int he_grid(unsigned long long units, int per_block)
     return (int)g;
 }
 
-// HEAAC_HE_UNFUSED=1 keeps the HF and PS stages in separate kernels (A/B measurements)
+// The product fuses the HF stage with baseline PS (k_hfps).  A -DHEAAC_TUNING build keeps the stages in
+// separate kernels when HEAAC_HE_UNFUSED=1 is set (A/B measurements only).
 static bool he_fused()
 {
+#ifdef HEAAC_TUNING
     static const bool fused = []() { const char *e = getenv("HEAAC_HE_UNFUSED"); return !(e && e[0] == '1'); }();
     return fused;
+#else
+    return true;
+#endif
 }
 
 extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cfg,
@@ -819,7 +800,7 @@ extern "C" int heaac_launch_qmf_synthesis_ds(const float *d_tab, const float *d_
 }
 
 
-#ifdef HF_STAMPS
+#ifdef HEAAC_TUNING
 // accumulated phase timeline of this translation unit's kernels (k_synth): out[0..31] cycles, out[32] units
 extern "C" int heaac_debug_timeline_he(unsigned long long *out)
 {

@@ -15,12 +15,8 @@
 
 #define LC_WAVES 4
 
-// PCM is written once and not read again by the GPU (LC_NT_ST: non-temporal policy)
-#ifdef LC_NT_ST
-#define LC_ST(p, v) __builtin_nontemporal_store((v), (p))
-#else
+// PCM stores keep the default cache policy (non-temporal measured inside the box-to-box noise, profiles/r02_experiments.md E7)
 #define LC_ST(p, v) (*(p) = (v))
-#endif
 
 struct LcWaveLds {
     float sbuf[1024];

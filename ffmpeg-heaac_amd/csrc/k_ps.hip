@@ -77,7 +77,7 @@ __global__ __launch_bounds__(HFPS_WAVES * WAVE)
 void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g_sbr,
             const HeaacSbrHeader *__restrict__ g_hdr, unsigned n_hdr, const HeaacPsFrame *__restrict__ g_ps,
             const float *g_W, const float *g_state_in, float *g_state_out, int state_words,
-            int off_sbr, int off_ps, float *g_X, unsigned long long n, unsigned *g_queue)
+            int off_sbr, int off_ps, float *g_X, unsigned long long n_frames, unsigned *g_queue)
 {
     using WT = PsWaveT<false>;
     static_assert(WT::SCR <= HF_XLOW_WORDS, "|s|^2 / subL / subR lie over X_low");
@@ -111,27 +111,20 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
     // index out a frame early).  Level 1 = the SBR and PS frame records (1.2 KB): k_hfps -6.8 %.  Level 2
     // adds W and the SBR state (16 KB) for another 0.3 %, but those lines leave L2 again before they are
     // used and are fetched twice (measured: +14.5 KiB per frame of FETCH_SIZE) -- not worth the traffic.
-#ifndef HFPS_PREFETCH
-#define HFPS_PREFETCH 1
-#endif
     const unsigned sink = lds_addr(s_dump);
     unsigned long long f = (unsigned long long)blockIdx.x * HFPS_WAVES + wave;
     unsigned tk = 0;
     if (lane == 0) tk = atomicAdd(g_queue, 1u) + gridDim.x * HFPS_WAVES;          // queue starts behind the static ones
     unsigned long long f1 = (unsigned long long)__builtin_amdgcn_readfirstlane(tk);
-    while (f < n) {
+    while (f < n_frames) {
         unsigned nxt = 0;
         if (lane == 0) nxt = atomicAdd(g_queue, 1u) + gridDim.x * HFPS_WAVES;
-        auto prefetch_next = [&]() {
-            if (HFPS_PREFETCH >= 1 && f1 < n) {
+        // slot of the PS loop at which the next frame's SBR and PS records (1.2 KB) are touched into L2
+        constexpr int TOUCH_RECORDS_SLOT = 20;
+        auto prefetch_next = [&](int n) {
+            if (n == TOUCH_RECORDS_SLOT && f1 < n_frames) {
                 l2_touch(&g_sbr[f1], sizeof(HeaacSbrFrame), lane, sink);
                 l2_touch(&g_ps[f1], sizeof(HeaacPsFrame), lane, sink);
-                if (HFPS_PREFETCH >= 2) {
-                    l2_touch(g_W + f1 * 2048, 2048 * 4, lane, sink);
-                    l2_touch(g_state_in + f1 * state_words + off_sbr, HEAAC_ST_SBR * 4, lane, sink);
-                }
-                if (HFPS_PREFETCH >= 3)
-                    l2_touch(g_state_in + f1 * state_words + off_ps, HEAAC_ST_PS * 4, lane, sink);
             }
         };
         const bool base = __builtin_amdgcn_readfirstlane(!ps_frame_is_general(&g_ps[f]));
@@ -228,7 +221,7 @@ extern "C" int heaac_launch_hfps(const float *d_tab, const HeaacSbrFrame *d_sbr,
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
 }
 
-#if defined(HF_STAMPS) || defined(PS_STAMPS)
+#ifdef HEAAC_TUNING
 // accumulated phase timeline of the fused kernel: out[0..31] cycles per phase, out[32] frames
 extern "C" int heaac_debug_timeline(unsigned long long *out)
 {

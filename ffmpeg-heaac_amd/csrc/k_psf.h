@@ -5,14 +5,12 @@
 #include "heaac_dsp.h"
 #include "k_hf.h"
 
-#ifdef PS_STAMPS
+#ifdef HEAAC_TUNING
 #define STAMP(i) TL_STAMP(16 + (i), false)
 #else
 #define STAMP(i) do {} while (0)
 #endif
-#ifndef PS_SCHED_GROUP
-#define PS_SCHED_GROUP 4
-#endif
+#define PS_SCHED_GROUP 4       // slots between scheduling barriers of the PS slot loop
 #define SUB_STRIDE 66          // one sub-subband row: 32 slots * (re,im) + 2 pad
 
 // Table 8.48 / 8.49 of ISO/IEC 14496-3 (aacpsdata.c:145-158): hybrid band -> parameter band
@@ -209,17 +207,11 @@ __device__ __forceinline__ void hybrid_fir(const float *in, const float *filt, f
 // store is discarded anyway) also carry the QMF band kh2 of their own column -- one of the
 // bands >= 64 with the one-slot delay -- so that every X row leaves as one full 256-byte
 // store and no separate pass over the slots is needed.  dual: this lane has a second role.
-// hook(): called once, two thirds into the slot loop (the fused kernel touches the next frame's
-// records into L2 there: early enough to be back before they are needed, late enough to survive
-// in L2 until then).
-#ifndef PS_SO_AUX
-#define PS_SO_AUX 2
-#endif
-typedef GBufT<PS_SO_AUX> GBufSO;          // the state record out: written once per frame, read by the next launch
-#ifndef PS_XROW_AUX
-#define PS_XROW_AUX 0
-#endif
-typedef GBufT<PS_XROW_AUX> GBufXR;        // the X rows of the slot loop (nt: +1.5 % -- the hybrid synthesis completes these lines later)
+// hook(n): called at the head of every slot n (n is a compile-time constant at each call).  The
+// fused kernel touches the next frame's records into L2 from it: early enough to be back before
+// they are needed, late enough to survive in L2 until then.
+typedef GBufT<2> GBufSO;          // the state record out (aux 2 = non-temporal): written once per frame, read by the next launch
+typedef GBufT<0> GBufXR;          // the X rows of the slot loop (nt measured +1.5 %: the hybrid synthesis completes these lines later)
 template <bool HEAVY, bool ALIGNED8, bool DUAL, class W, class Hook = NoHook>
 __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, const signed char *kti,
                                         int is34, int kh, bool clear_state,
@@ -303,7 +295,7 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
     // Fully unrolled over the 32 slots: ring positions and column indices are static.
 #pragma unroll
     for (int n = 0; n < 32; n++) {
-        if (n == 20) hook();
+        hook(n);
         if ((!ALIGNED8 || (n & 7) == 0) && n > stop) {
             // next envelope (aacps.c:900-938)
             e++;

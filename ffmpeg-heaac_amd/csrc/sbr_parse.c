@@ -190,124 +190,151 @@ static int read_header(HeaacSbrStream *s, Bits *b, int *tables_touched)
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* time / frequency grid (read_sbr_grid, aacsbr.c:609-745)                                       */
+/* time / frequency grid.  VALUES as read_sbr_grid / copy_sbr_grid leave them (aacsbr.c:609-766); */
+/* the form is this parser's own: the syntax is read into a description of the two frame ends,   */
+/* and the envelope borders, the noise border and the transient envelope are derived from it.    */
 /* ------------------------------------------------------------------------------------------ */
-static const int8_t k_ceil_log2[6] = { 0, 1, 2, 2, 3, 3 };
+/* sbr_grid() transmits, for each END of the frame that the frame class declares variable, an absolute
+ * border and up to three relative borders walking inwards from it; a fixed end sits at slot 0 / 16 and
+ * has no relative borders (FIXFIX instead spreads 1, 2 or 4 envelopes evenly).  Class bit 1 = the
+ * leading end is variable, bit 0 = the trailing end is. */
+#define GRID_LEAD_VAR(cls)  (((cls) >> 1) & 1)
+#define GRID_TRAIL_VAR(cls) ((cls) & 1)
+#define GRID_SLOTS 16                                  /* numTimeSlots (1024-sample frames) */
 
-static int read_grid(const HeaacSbrStream *s, Bits *b, HeaacSbrChanState *c)
+typedef struct GridSyntax {
+    int cls, L;                                        /* frame class, envelopes */
+    int lead_abs, trail_abs;                           /* first and last border */
+    int n_lead, n_trail;                               /* relative borders at either end */
+    int lead_step[3], trail_step[3];                   /* their distances (2 r + 2), walking inwards */
+    unsigned pointer;                                  /* bs_pointer; 0 where none is sent */
+    uint8_t res[5];                                    /* bs_freq_res of envelope 1..L */
+} GridSyntax;
+
+/* bits of bs_pointer for L envelopes: ceil(log2(L + 1)) */
+static int grid_pointer_bits(int L) { int n = 0; while ((1 << n) < L + 1) n++; return n; }
+
+static int grid_read_syntax(Bits *b, GridSyntax *g)
 {
-    unsigned pointer = 0;
-    int abs_bord_trail = 16, num_rel_lead, num_rel_trail;
-    const unsigned num_env_old = c->bs_num_env;
-
-    c->bs_freq_res[0] = c->bs_freq_res[c->bs_num_env];
-    c->bs_amp_res = s->bs_amp_res_header;
-    c->t_env_num_env_old = c->t_env[num_env_old];
-
-    switch (c->bs_frame_class = (uint8_t)bits(b, 2)) {
-    case FIXFIX: {
-        const int L = 1 << bits(b, 2);
-        if (L == 1) c->bs_amp_res = 0;
-        if (L > 4) return HEAAC_PARSE_ERR_DATA;
-        c->bs_num_env = (uint8_t)L;
-        c->t_env[0] = 0;
-        c->t_env[L] = 16;
-        const int step = (16 + (L >> 1)) / L;
-        for (int i = 0; i < L - 1; i++) c->t_env[i + 1] = (uint8_t)(c->t_env[i] + step);
-        c->bs_freq_res[1] = (uint8_t)bit1(b);
-        for (int i = 1; i < L; i++) c->bs_freq_res[i + 1] = c->bs_freq_res[1];
-        break;
+    memset(g, 0, sizeof(*g));
+    g->cls = (int)bits(b, 2);
+    g->trail_abs = GRID_SLOTS;
+    if (g->cls == FIXFIX) {
+        g->L = 1 << bits(b, 2);
+        if (g->L > 4) return HEAAC_PARSE_ERR_DATA;     /* "too many SBR envelopes in FIXFIX" */
+        const unsigned r = bit1(b);                    /* one resolution bit for all envelopes */
+        for (int e = 0; e < g->L; e++) g->res[e] = (uint8_t)r;
+        return HEAAC_PARSE_OK;
     }
-    case FIXVAR: {
-        abs_bord_trail += (int)bits(b, 2);
-        num_rel_trail = (int)bits(b, 2);
-        const int L = num_rel_trail + 1;
-        c->bs_num_env = (uint8_t)L;
-        c->t_env[0] = 0;
-        c->t_env[L] = (uint8_t)abs_bord_trail;
-        for (int i = 0; i < num_rel_trail; i++)
-            c->t_env[L - 1 - i] = (uint8_t)(c->t_env[L - i] - 2 * bits(b, 2) - 2);
-        pointer = bits(b, k_ceil_log2[L]);
-        for (int i = 0; i < L; i++) c->bs_freq_res[L - i] = (uint8_t)bit1(b);
-        break;
-    }
-    case VARFIX: {
-        c->t_env[0] = (uint8_t)bits(b, 2);
-        num_rel_lead = (int)bits(b, 2);
-        const int L = num_rel_lead + 1;
-        c->bs_num_env = (uint8_t)L;
-        c->t_env[L] = 16;
-        for (int i = 0; i < num_rel_lead; i++)
-            c->t_env[i + 1] = (uint8_t)(c->t_env[i] + 2 * bits(b, 2) + 2);
-        pointer = bits(b, k_ceil_log2[L]);
-        for (int i = 0; i < L; i++) c->bs_freq_res[1 + i] = (uint8_t)bit1(b);
-        break;
-    }
-    default: { /* VARVAR */
-        c->t_env[0] = (uint8_t)bits(b, 2);
-        abs_bord_trail += (int)bits(b, 2);
-        num_rel_lead  = (int)bits(b, 2);
-        num_rel_trail = (int)bits(b, 2);
-        const int L = num_rel_lead + num_rel_trail + 1;
-        if (L > 5) return HEAAC_PARSE_ERR_DATA;
-        c->bs_num_env = (uint8_t)L;
-        c->t_env[L] = (uint8_t)abs_bord_trail;
-        for (int i = 0; i < num_rel_lead; i++)
-            c->t_env[i + 1] = (uint8_t)(c->t_env[i] + 2 * bits(b, 2) + 2);
-        for (int i = 0; i < num_rel_trail; i++)
-            c->t_env[L - 1 - i] = (uint8_t)(c->t_env[L - i] - 2 * bits(b, 2) - 2);
-        pointer = bits(b, k_ceil_log2[L]);
-        for (int i = 0; i < L; i++) c->bs_freq_res[1 + i] = (uint8_t)bit1(b);
-        break;
-    }
-    }
-    const int L = c->bs_num_env;
-    if (pointer > (unsigned)L + 1) return HEAAC_PARSE_ERR_DATA;
-    /* the reference rejects t_env[i-1] > t_env[i] (:715-720); equality is rejected here too (see the
-     * header).  uint8 wrap of a trailing border walked below zero shows up as a non-monotone table. */
-    for (int i = 1; i <= L; i++)
-        if (c->t_env[i - 1] >= c->t_env[i]) return HEAAC_PARSE_ERR_DATA;
-
-    c->bs_num_noise = (uint8_t)((L > 1) + 1);
-    c->t_q[0] = c->t_env[0];
-    c->t_q[c->bs_num_noise] = c->t_env[L];
-    if (c->bs_num_noise > 1) {
-        unsigned idx;
-        if (c->bs_frame_class == FIXFIX) {
-            idx = (unsigned)L >> 1;
-        } else if (c->bs_frame_class & 1) {            /* FIXVAR, VARVAR */
-            const int p1 = (int)pointer - 1;
-            idx = (unsigned)(L - (p1 > 1 ? p1 : 1));
-        } else {                                       /* VARFIX */
-            if (!pointer)          idx = 1;
-            else if (pointer == 1) idx = (unsigned)L - 1;
-            else                   idx = pointer - 1;
-        }
-        c->t_q[1] = c->t_env[idx];
-    }
-    c->e_a[0] = (int8_t)-(c->e_a[1] != (int)num_env_old);
-    c->e_a[1] = -1;
-    if ((c->bs_frame_class & 1) && pointer)
-        c->e_a[1] = (int8_t)(L + 1 - (int)pointer);
-    else if (c->bs_frame_class == VARFIX && pointer > 1)
-        c->e_a[1] = (int8_t)(pointer - 1);
+    /* absolute borders, then the counts, then the relative borders: leading end first */
+    if (GRID_LEAD_VAR(g->cls))  g->lead_abs = (int)bits(b, 2);
+    if (GRID_TRAIL_VAR(g->cls)) g->trail_abs += (int)bits(b, 2);
+    if (GRID_LEAD_VAR(g->cls))  g->n_lead = (int)bits(b, 2);
+    if (GRID_TRAIL_VAR(g->cls)) g->n_trail = (int)bits(b, 2);
+    g->L = g->n_lead + g->n_trail + 1;
+    if (g->L > 5) return HEAAC_PARSE_ERR_DATA;         /* "too many SBR envelopes in VARVAR" */
+    for (int i = 0; i < g->n_lead; i++)  g->lead_step[i]  = 2 * (int)bits(b, 2) + 2;
+    for (int i = 0; i < g->n_trail; i++) g->trail_step[i] = 2 * (int)bits(b, 2) + 2;
+    g->pointer = bits(b, grid_pointer_bits(g->L));
+    /* one resolution bit per envelope; a frame with only its trailing end variable sends them last
+     * envelope first */
+    const int backwards = g->cls == FIXVAR;
+    for (int e = 0; e < g->L; e++) g->res[backwards ? g->L - 1 - e : e] = (uint8_t)bit1(b);
     return HEAAC_PARSE_OK;
 }
 
-/* copy_sbr_grid (:747-766) */
+/* Envelope borders t[0..L].  0 = fine; non-zero = two borders meet or cross (the reference's uint8
+ * arithmetic wraps a border walked below zero to > 235, which its own monotony check then refuses;
+ * meeting borders are refused here as well, see heaac_parse.h). */
+static int grid_borders(const GridSyntax *g, int t[6])
+{
+    const int L = g->L;
+    t[0] = g->lead_abs;
+    t[L] = g->trail_abs;
+    if (g->cls == FIXFIX) {
+        for (int e = 1; e < L; e++) t[e] = e * (GRID_SLOTS / L);      /* L in {1, 2, 4} */
+    } else {
+        for (int i = 0; i < g->n_lead; i++)  t[1 + i] = t[i] + g->lead_step[i];
+        for (int i = 0; i < g->n_trail; i++) t[L - 1 - i] = t[L - i] - g->trail_step[i];
+    }
+    for (int e = 0; e < L; e++)
+        if (t[e] >= t[e + 1] || t[e] < 0) return 1;
+    return 0;
+}
+
+/* Index into t_env[] of the middle noise border (two noise floors only).  ISO/IEC 14496-3 4.6.18.3.3 counts
+ * the pointer from the variable end; the reference's expression for a variable trailing end is
+ * `bs_num_env - FFMAX(bs_pointer - 1, 1)` on an UNSIGNED bs_pointer (aacsbr.c:613, 729): with bs_pointer = 0
+ * the subtraction wraps and the index comes out as L + 1, one past the last border -- t_env[] keeps what an
+ * earlier frame with more envelopes left there (0 in a new stream).  The reference is the contract, so the
+ * same entry is taken here (ISO would give L - 1); tests/test_sbr_parse.py pins the case. */
+static int grid_noise_border_index(const GridSyntax *g)
+{
+    const int L = g->L, p = (int)g->pointer;
+    if (g->cls == FIXFIX) return L >> 1;
+    if (GRID_TRAIL_VAR(g->cls)) return p == 0 ? L + 1 : L - (p > 2 ? p - 1 : 1);
+    return p == 0 ? 1 : p == 1 ? L - 1 : p - 1;        /* VARFIX: counted from the leading end */
+}
+
+/* l_A: the envelope that starts at the transient, or -1 */
+static int grid_transient_envelope(const GridSyntax *g)
+{
+    const int p = (int)g->pointer;
+    if (GRID_TRAIL_VAR(g->cls)) return p ? g->L + 1 - p : -1;
+    if (g->cls == VARFIX) return p > 1 ? p - 1 : -1;
+    return -1;
+}
+
+/* What a channel keeps of the PREVIOUS frame's grid when a new one arrives: the resolution and the end of
+ * its last envelope, and whether its transient envelope was its last (l_APrev). */
+static void grid_carry(HeaacSbrChanState *c)
+{
+    const int L_old = c->bs_num_env;
+    c->bs_freq_res[0] = c->bs_freq_res[L_old];
+    c->t_env_num_env_old = c->t_env[L_old];
+    c->e_a[0] = (int8_t)-(c->e_a[1] != L_old);
+}
+
+static int read_grid(const HeaacSbrStream *s, Bits *b, HeaacSbrChanState *c)
+{
+    GridSyntax g;
+    int t[6];
+    /* the previous frame's values move first, as in the reference, also when this grid is refused */
+    c->bs_freq_res[0] = c->bs_freq_res[c->bs_num_env];
+    c->t_env_num_env_old = c->t_env[c->bs_num_env];
+    const int L_old = c->bs_num_env;
+    const int rc = grid_read_syntax(b, &g);
+    if (rc) return rc;                                 /* (the caller rolls a refused element's channel state back) */
+    c->bs_frame_class = (uint8_t)g.cls;
+    c->bs_amp_res = (g.cls == FIXFIX && g.L == 1) ? 0 : s->bs_amp_res_header;
+    c->bs_num_env = (uint8_t)g.L;
+    const int crossed = grid_borders(&g, t);
+    for (int e = 0; e <= g.L; e++) c->t_env[e] = (uint8_t)t[e];
+    for (int e = 0; e < g.L; e++) c->bs_freq_res[1 + e] = g.res[e];
+    if (g.pointer > (unsigned)g.L + 1 || crossed) return HEAAC_PARSE_ERR_DATA;
+
+    c->bs_num_noise = (uint8_t)(g.L > 1 ? 2 : 1);
+    c->t_q[0] = c->t_env[0];
+    c->t_q[c->bs_num_noise] = c->t_env[g.L];
+    if (c->bs_num_noise > 1) c->t_q[1] = c->t_env[grid_noise_border_index(&g)];
+    c->e_a[0] = (int8_t)-(c->e_a[1] != L_old);
+    c->e_a[1] = (int8_t)grid_transient_envelope(&g);
+    return HEAAC_PARSE_OK;
+}
+
+/* The second channel of a coupled pair takes the first one's grid (copy_sbr_grid): its own carries, then
+ * every transmitted grid field of the partner. */
 static void copy_grid(HeaacSbrChanState *dst, const HeaacSbrChanState *src)
 {
-    dst->bs_freq_res[0]    = dst->bs_freq_res[dst->bs_num_env];
-    dst->t_env_num_env_old = dst->t_env[dst->bs_num_env];
-    dst->e_a[0]            = (int8_t)-(dst->e_a[1] != dst->bs_num_env);
-    memcpy(dst->bs_freq_res + 1, src->bs_freq_res + 1, 7);
-    memcpy(dst->t_env, src->t_env, sizeof(dst->t_env));
-    memcpy(dst->t_q, src->t_q, sizeof(dst->t_q));
-    dst->bs_num_env     = src->bs_num_env;
-    dst->bs_amp_res     = src->bs_amp_res;
-    dst->bs_num_noise   = src->bs_num_noise;
+    grid_carry(dst);
     dst->bs_frame_class = src->bs_frame_class;
-    dst->e_a[1]         = src->e_a[1];
+    dst->bs_num_env = src->bs_num_env;
+    dst->bs_num_noise = src->bs_num_noise;
+    dst->bs_amp_res = src->bs_amp_res;
+    dst->e_a[1] = src->e_a[1];
+    for (int i = 0; i < 8; i++) dst->t_env[i] = src->t_env[i];
+    for (int i = 1; i < 8; i++) dst->bs_freq_res[i] = src->bs_freq_res[i];
+    for (int i = 0; i < 3; i++) dst->t_q[i] = src->t_q[i];
 }
 
 static void read_dtdf(Bits *b, HeaacSbrChanState *c)
@@ -448,168 +475,219 @@ static int read_cpe(HeaacSbrStream *s, const HeaacSbrHeader *h, Bits *b)
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* Parametric Stereo (ff_ps_read_data, aacps.c:150-279)                                          */
+/* Parametric Stereo payload.  VALUES as ff_ps_read_data leaves them (aacps.c:84-279); the form  */
+/* is this parser's own: ps_data() is read as a mode header, a time grid and then one block per   */
+/* parameter KIND, each kind described by a record of where it lives and how it is coded.        */
 /* ------------------------------------------------------------------------------------------ */
-static const int8_t k_num_env_tab[2][4] = { { 0, 1, 2, 4 }, { 1, 2, 3, 4 } };
-static const int8_t k_nr_iidicc_par[6] = { 10, 20, 34, 10, 20, 34 };
-static const int8_t k_nr_ipdopd_par[6] = { 5, 11, 17, 5, 11, 17 };
-static const int8_t k_huff_iid[4] = { PS_IID_DF0, PS_IID_DF1, PS_IID_DT0, PS_IID_DT1 };
+/* resolution mode 0..5 -> parameters per envelope (ISO/IEC 14496-3 Table 8.4x): modes 3..5 repeat 0..2 with
+ * the fine IID quantiser */
+static int ps_mode_bands(int mode)  { static const int8_t n[3] = { 10, 20, 34 }; return n[mode % 3]; }
+static int ps_mode_phases(int mode) { static const int8_t n[3] = { 5, 11, 17 };  return n[mode % 3]; }
 
-enum { PAR_IID, PAR_ICC, PAR_IPDOPD };
+/* One kind of stereo parameter of one frame. */
+typedef struct PsKind {
+    int8_t (*par)[34];            /* [envelope][band] */
+    int count;                    /* values per envelope */
+    int book[2];                  /* code book by direction: [0] along frequency, [1] along time */
+    int bias[2];                  /* what that code book adds to a difference */
+    int modulo;                   /* phases wrap modulo 8; 0 = plain integers */
+    int lo, hi;                   /* legal range of an accumulated value (ignored for phases) */
+} PsKind;
 
-/* READ_PAR_DATA (aacps.c:84-119): kind selects offset, mask and the error condition */
-static int read_par(Bits *b, HeaacPsState *ps, int8_t (*par)[34], int kind, int num, int table, int e, int dt)
+static PsKind ps_kind_iid(HeaacPsState *ps)
 {
-    const int offset = kind == PAR_IPDOPD ? 0 : ps_huff_offset[table];
-    const int8_t *prev = NULL;
-    if (dt) {
-        int e_prev = e ? e - 1 : ps->num_env_old - 1;
-        if (e_prev < 0) e_prev = 0;
-        prev = par[e_prev];
+    const int fine = ps->iid_quant;
+    const int df = fine ? PS_IID_DF1 : PS_IID_DF0, dt = fine ? PS_IID_DT1 : PS_IID_DT0;
+    const int top = fine ? 15 : 7;
+    const PsKind k = { ps->iid_par, ps->nr_iid_par, { df, dt }, { ps_huff_offset[df], ps_huff_offset[dt] }, 0, -top, top };
+    return k;
+}
+static PsKind ps_kind_icc(HeaacPsState *ps)
+{
+    const PsKind k = { ps->icc_par, ps->nr_icc_par, { PS_ICC_DF, PS_ICC_DT },
+                       { ps_huff_offset[PS_ICC_DF], ps_huff_offset[PS_ICC_DT] }, 0, 0, 7 };
+    return k;
+}
+static PsKind ps_kind_phase(HeaacPsState *ps, int opd)
+{
+    const PsKind k = { opd ? ps->opd_par : ps->ipd_par, ps->nr_ipdopd_par,
+                       { opd ? PS_OPD_DF : PS_IPD_DF, opd ? PS_OPD_DT : PS_IPD_DT }, { 0, 0 }, 8, 0, 0 };
+    return k;
+}
+
+/* One envelope of one kind: a direction bit, then `count` code words.  Along frequency a value continues
+ * from its lower neighbour (from 0 for the first), along time from the same band of the previous envelope --
+ * for envelope 0 the last one of the previous frame. */
+static int ps_read_envelope(Bits *b, const HeaacPsState *ps, const PsKind *k, int e)
+{
+    const int along_time = (int)bit1(b);
+    const Tree *book = &g_ps_tree[k->book[along_time]];
+    const int8_t *before = NULL;
+    if (along_time) {
+        const int src = e > 0 ? e - 1 : ps->num_env_old > 0 ? ps->num_env_old - 1 : 0;
+        before = k->par[src];
     }
-    int val = 0;
-    for (int k = 0; k < num; k++) {
-        const int sym = tree_read(&g_ps_tree[table], b);
+    int run = 0;
+    for (int band = 0; band < k->count; band++) {
+        const int sym = tree_read(book, b);
         if (sym < 0) return HEAAC_PARSE_ERR_DATA;
-        if (dt) val = prev[k] + sym - offset;
-        else    val += sym - offset;
-        if (kind == PAR_IPDOPD) val &= 7;
-        par[e][k] = (int8_t)val;
-        if (kind == PAR_IID && abs(par[e][k]) > 7 + 8 * ps->iid_quant) return HEAAC_PARSE_ERR_DATA;
-        if (kind == PAR_ICC && (par[e][k] < 0 || par[e][k] > 7)) return HEAAC_PARSE_ERR_DATA;
+        run = (before ? before[band] : run) + sym - k->bias[along_time];
+        if (k->modulo) run &= k->modulo - 1;
+        else if (run < k->lo || run > k->hi) { k->par[e][band] = (int8_t)run; return HEAAC_PARSE_ERR_DATA; }
+        k->par[e][band] = (int8_t)run;
     }
     return HEAAC_PARSE_OK;
 }
 
-/* ps_read_extension_data (:121-139): bits consumed */
-static int read_ps_extension(Bits *b, HeaacPsState *ps, int id)
+/* All envelopes of a kind that is switched on; a kind that is off reads as zeros. */
+static int ps_read_kind(Bits *b, HeaacPsState *ps, int enabled, PsKind k)
+{
+    if (!enabled) { memset(k.par, 0, 5 * 34); return HEAAC_PARSE_OK; }
+    for (int e = 0; e < ps->num_env; e++)
+        if (ps_read_envelope(b, ps, &k, e)) return HEAAC_PARSE_ERR_DATA;
+    return HEAAC_PARSE_OK;
+}
+
+/* enable_ps_header: which kinds are on and at which resolution.  0, or non-zero for a reserved mode. */
+static int ps_read_modes(Bits *b, HeaacPsState *ps)
+{
+    if ((ps->enable_iid = (uint8_t)bit1(b))) {
+        const int mode = (int)bits(b, 3);
+        if (mode > 5) return 1;
+        ps->nr_iid_par = (uint8_t)ps_mode_bands(mode);
+        ps->nr_ipdopd_par = (uint8_t)ps_mode_phases(mode);
+        ps->iid_quant = mode >= 3;
+    }
+    if ((ps->enable_icc = (uint8_t)bit1(b))) {
+        const int mode = (int)bits(b, 3);
+        if (mode > 5) return 1;                        /* (the reference stores the reserved value before refusing it) */
+        ps->icc_mode = (uint8_t)mode;
+        ps->nr_icc_par = (uint8_t)ps_mode_bands(mode);
+    }
+    ps->enable_ext = (uint8_t)bit1(b);
+    return 0;
+}
+
+/* Envelope count and borders: class 0 = 0, 1, 2 or 4 envelopes cutting the 32 slots evenly, class 1 = 1..4
+ * envelopes with transmitted borders.  border_position[0] = -1. */
+static void ps_read_time_grid(Bits *b, HeaacPsState *ps)
+{
+    ps->frame_class = (uint8_t)bit1(b);
+    const int code = (int)bits(b, 2);
+    ps->num_env_old = ps->num_env;
+    ps->num_env = (uint8_t)(ps->frame_class ? code + 1 : code == 3 ? 4 : code);
+    ps->border_position[0] = -1;
+    for (int e = 1; e <= ps->num_env; e++)
+        ps->border_position[e] = (int8_t)(ps->frame_class ? (int)bits(b, 5) : e * 32 / ps->num_env - 1);
+}
+
+/* ps_extension(): id 0 carries the phase parameters (IPD and OPD interleaved per envelope) and a
+ * reserved bit; other ids carry nothing this decoder reads.  Returns the bits consumed. */
+static int ps_read_extension(Bits *b, HeaacPsState *ps, int id)
 {
     const int at = b->pos;
-    if (id) return 0;
-    ps->enable_ipdopd = (uint8_t)bit1(b);
-    if (ps->enable_ipdopd) {
+    if (id != 0) return 0;
+    if ((ps->enable_ipdopd = (uint8_t)bit1(b))) {
+        const PsKind ipd = ps_kind_phase(ps, 0), opd = ps_kind_phase(ps, 1);
         for (int e = 0; e < ps->num_env; e++) {
-            int dt = (int)bit1(b);
-            read_par(b, ps, ps->ipd_par, PAR_IPDOPD, ps->nr_ipdopd_par, dt ? PS_IPD_DT : PS_IPD_DF, e, dt);
-            dt = (int)bit1(b);
-            read_par(b, ps, ps->opd_par, PAR_IPDOPD, ps->nr_ipdopd_par, dt ? PS_OPD_DT : PS_OPD_DF, e, dt);
+            ps_read_envelope(b, ps, &ipd, e);
+            ps_read_envelope(b, ps, &opd, e);
         }
     }
     bit1(b);                                           /* reserved_ps */
     return b->pos - at;
 }
 
+/* The extension container: a byte count (escaped at 15), then extensions while at least one byte
+ * remains; what is left is padding.  Non-zero if the extensions ran past the count. */
+static int ps_read_extensions(Bits *b, HeaacPsState *ps)
+{
+    int left = (int)bits(b, 4);
+    if (left == 15) left += (int)bits(b, 8);
+    left *= 8;
+    while (left > 7) {
+        const int id = (int)bits(b, 2);
+        left -= 2 + ps_read_extension(b, ps, id);
+    }
+    if (left < 0) return 1;
+    b->pos += left;
+    return 0;
+}
+
+/* The last envelope must reach the end of the frame (slot 31): if it does not -- or no envelope was
+ * sent -- one more is appended that repeats the last parameters known (this frame's last envelope, or
+ * the previous frame's).  aacps.c:234-253. */
+static void ps_close_time_grid(HeaacPsState *ps)
+{
+    const int n = ps->num_env;
+    if (n && ps->border_position[n] >= 31) return;
+    const int from = n ? n - 1 : (int)ps->num_env_old - 1;
+    if (from >= 0 && from != n) {
+        int8_t (*const sets[4])[34] = { ps->iid_par, ps->icc_par, ps->ipd_par, ps->opd_par };
+        const int on[4] = { ps->enable_iid, ps->enable_icc, ps->enable_ipdopd, ps->enable_ipdopd };
+        for (int k = 0; k < 4; k++)
+            if (on[k]) memcpy(sets[k][n], sets[k][from], 34);
+    }
+    ps->num_env = (uint8_t)(n + 1);
+    ps->border_position[n + 1] = 31;
+}
+
+/* What this parser refuses although the reference goes on (heaac_parse.h): borders that do not ascend, and
+ * values outside the quantiser of THIS frame in an envelope borrowed from an earlier one. */
+static int ps_frame_is_usable(const HeaacPsState *ps_c)
+{
+    HeaacPsState *ps = (HeaacPsState *)ps_c;           /* (the kind records are not const-qualified) */
+    for (int e = 0; e < ps->num_env; e++)
+        if (ps->border_position[e] >= ps->border_position[e + 1]) return 0;
+    const PsKind kinds[2] = { ps_kind_iid(ps), ps_kind_icc(ps) };
+    const int on[2] = { ps->enable_iid, ps->enable_icc };
+    for (int k = 0; k < 2; k++)
+        for (int e = 0; on[k] && e < ps->num_env; e++)
+            for (int band = 0; band < kinds[k].count; band++)
+                if (kinds[k].par[e][band] < kinds[k].lo || kinds[k].par[e][band] > kinds[k].hi) return 0;
+    return 1;
+}
+
 /* Returns the bits the SBR reader must step over; *status = OK or the error that cleared ps->start. */
 static int read_ps(Bits *host, HeaacPsState *ps, int bits_left_in_ext, int *status)
 {
-    Bits gb = *host, *b = &gb;
+    Bits own = *host, *b = &own;                       /* a private cursor: the host only moves on success */
     const int at = b->pos;
+    int ok;
     *status = HEAAC_PARSE_ERR_DATA;
 
-    const unsigned header = bit1(b);
-    if (header) {
-        ps->enable_iid = (uint8_t)bit1(b);
-        if (ps->enable_iid) {
-            const int iid_mode = (int)bits(b, 3);
-            if (iid_mode > 5) goto err;
-            ps->nr_iid_par    = (uint8_t)k_nr_iidicc_par[iid_mode];
-            ps->iid_quant     = iid_mode > 2;
-            ps->nr_ipdopd_par = (uint8_t)k_nr_ipdopd_par[iid_mode];
+    const int has_modes = (int)bit1(b);
+    ok = !(has_modes && ps_read_modes(b, ps));
+    if (ok) {
+        ps_read_time_grid(b, ps);
+        ok = ps_read_kind(b, ps, ps->enable_iid, ps_kind_iid(ps)) == HEAAC_PARSE_OK &&
+             ps_read_kind(b, ps, ps->enable_icc, ps_kind_icc(ps)) == HEAAC_PARSE_OK;
+    }
+    if (ok && ps->enable_ext) ok = !ps_read_extensions(b, ps);
+    if (ok) {
+        ps_close_time_grid(ps);
+        /* band layout of this frame: 34 bands as soon as one kind is sent at that resolution; a frame
+         * that sends neither keeps the layout it had */
+        ps->is34bands_old = ps->is34bands;
+        if (ps->enable_iid || ps->enable_icc)
+            ps->is34bands = (ps->enable_iid && ps->nr_iid_par == 34) || (ps->enable_icc && ps->nr_icc_par == 34);
+        if (!ps->enable_ipdopd) {
+            memset(ps->ipd_par, 0, sizeof(ps->ipd_par));
+            memset(ps->opd_par, 0, sizeof(ps->opd_par));
         }
-        ps->enable_icc = (uint8_t)bit1(b);
-        if (ps->enable_icc) {
-            const int icc_mode = (int)bits(b, 3);
-            if (icc_mode > 5) goto err;                /* (the reference stores the reserved value first) */
-            ps->icc_mode = (uint8_t)icc_mode;
-            ps->nr_icc_par = (uint8_t)k_nr_iidicc_par[icc_mode];
-        }
-        ps->enable_ext = (uint8_t)bit1(b);
+        if (has_modes) ps->start = 1;
+        ok = ps_frame_is_usable(ps);
     }
-    ps->frame_class = (uint8_t)bit1(b);
-    ps->num_env_old = ps->num_env;
-    ps->num_env     = (uint8_t)k_num_env_tab[ps->frame_class][bits(b, 2)];
-
-    ps->border_position[0] = -1;
-    if (ps->frame_class) {
-        for (int e = 1; e <= ps->num_env; e++) ps->border_position[e] = (int8_t)bits(b, 5);
-    } else {
-        const int shift = ps->num_env == 4 ? 2 : ps->num_env == 2 ? 1 : 0;   /* ff_log2_tab[num_env], num_env in {0,1,2,4} */
-        for (int e = 1; e <= ps->num_env; e++) ps->border_position[e] = (int8_t)((e * 32 >> shift) - 1);
-    }
-    if (ps->enable_iid) {
-        for (int e = 0; e < ps->num_env; e++) {
-            const int dt = (int)bit1(b);
-            if (read_par(b, ps, ps->iid_par, PAR_IID, ps->nr_iid_par, k_huff_iid[2 * dt + ps->iid_quant], e, dt)) goto err;
-        }
-    } else {
-        memset(ps->iid_par, 0, sizeof(ps->iid_par));
-    }
-    if (ps->enable_icc) {
-        for (int e = 0; e < ps->num_env; e++) {
-            const int dt = (int)bit1(b);
-            if (read_par(b, ps, ps->icc_par, PAR_ICC, ps->nr_icc_par, dt ? PS_ICC_DT : PS_ICC_DF, e, dt)) goto err;
-        }
-    } else {
-        memset(ps->icc_par, 0, sizeof(ps->icc_par));
-    }
-    if (ps->enable_ext) {
-        int cnt = (int)bits(b, 4);
-        if (cnt == 15) cnt += (int)bits(b, 8);
-        cnt *= 8;
-        while (cnt > 7) {
-            const int id = (int)bits(b, 2);
-            cnt -= 2 + read_ps_extension(b, ps, id);
-        }
-        if (cnt < 0) goto err;
-        b->pos += cnt;
-    }
-    /* fix up envelopes (:234-253) */
-    if (!ps->num_env || ps->border_position[ps->num_env] < 31) {
-        const int source = ps->num_env ? ps->num_env - 1 : ps->num_env_old - 1;
-        if (source >= 0 && source != ps->num_env) {
-            if (ps->enable_iid) memcpy(ps->iid_par[ps->num_env], ps->iid_par[source], 34);
-            if (ps->enable_icc) memcpy(ps->icc_par[ps->num_env], ps->icc_par[source], 34);
-            if (ps->enable_ipdopd) {
-                memcpy(ps->ipd_par[ps->num_env], ps->ipd_par[source], 34);
-                memcpy(ps->opd_par[ps->num_env], ps->opd_par[source], 34);
-            }
-        }
-        ps->num_env++;
-        ps->border_position[ps->num_env] = 31;
-    }
-    ps->is34bands_old = ps->is34bands;
-    if (ps->enable_iid || ps->enable_icc)
-        ps->is34bands = (ps->enable_iid && ps->nr_iid_par == 34) || (ps->enable_icc && ps->nr_icc_par == 34);
-    if (!ps->enable_ipdopd) {
-        memset(ps->ipd_par, 0, sizeof(ps->ipd_par));
-        memset(ps->opd_par, 0, sizeof(ps->opd_par));
-    }
-    if (header) ps->start = 1;
-    /* stricter than the reference: the borders must ascend, and an envelope borrowed from the previous frame
-     * must fit the quantiser of this one (see heaac_parse.h) */
-    for (int e = 0; e < ps->num_env; e++)
-        if (ps->border_position[e] >= ps->border_position[e + 1]) goto err;
-    if (ps->enable_iid)
-        for (int e = 0; e < ps->num_env; e++)
-            for (int k = 0; k < ps->nr_iid_par; k++)
-                if (abs(ps->iid_par[e][k]) > 7 + 8 * ps->iid_quant) goto err;
-    /* (a borrowed ICC envelope can hold the value an earlier, refused frame stopped at) */
-    if (ps->enable_icc)
-        for (int e = 0; e < ps->num_env; e++)
-            for (int k = 0; k < ps->nr_icc_par; k++)
-                if (ps->icc_par[e][k] < 0 || ps->icc_par[e][k] > 7) goto err;
-
-    {
-        const int consumed = b->pos - at;
-        if (consumed <= bits_left_in_ext) {
-            host->pos += consumed;
+    if (ok) {
+        const int used = b->pos - at;
+        if (used <= bits_left_in_ext) {
+            host->pos += used;
             if (b->over) host->over = 1;
             *status = HEAAC_PARSE_OK;
-            return consumed;
+            return used;
         }
         *status = HEAAC_PARSE_ERR_OVERREAD;
     }
-err:
     ps->start = 0;
     host->pos += bits_left_in_ext;
     return bits_left_in_ext;

@@ -79,12 +79,11 @@ HEAAC_HD int heaac_check_sbr_channel(const HeaacSbrChannel *c, int n_q)
         if (c->t_env[i] >= c->t_env[i + 1]) return HEAAC_BAD_SBR_T_ENV;
     if (c->t_q[0] != c->t_env[0] || c->t_q[c->bs_num_noise] != c->t_env[L])
         return HEAAC_BAD_SBR_T_Q;
-    if (c->bs_num_noise > 1) {
-        /* the middle noise border is one of the envelope borders (bs_pointer may select the first, :726) */
-        int found = 0;
-        for (int i = 0; i <= L; i++) found |= c->t_q[1] == c->t_env[i];
-        if (!found) return HEAAC_BAD_SBR_T_Q;
-    }
+    /* The middle noise border is an envelope border of this frame -- or, for a frame with a variable trailing
+     * end and bs_pointer = 0, the entry behind the last border that an EARLIER frame left in t_env[] (the
+     * reference's unsigned pointer arithmetic, aacsbr.c:729; csrc/sbr_parse.c grid_noise_border_index): any time
+     * slot a border can have, or 0.  It only enters `t_env[e] >= t_q[1]` (sbr_mapping, aacsbr.c:1467). */
+    if (c->bs_num_noise > 1 && c->t_q[1] > 19) return HEAAC_BAD_SBR_T_Q;
     if (c->bs_amp_res > 1 || c->bs_add_harmonic_flag > 1 || c->t_env_num_env_old > 19 ||
         c->e_a[0] < -1 || c->e_a[0] > 0 || c->e_a[1] < -1 || c->e_a[1] > L)
         return HEAAC_BAD_SBR_FLAGS;

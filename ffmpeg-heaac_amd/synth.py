@@ -159,7 +159,8 @@ class _SbrChain:
             amp = int(h["bs_amp_res_header"])
         out["bs_num_env"] = num_env
         out["bs_amp_res"] = amp
-        out["t_env"][: num_env + 1] = t
+        self.t_env[: num_env + 1] = t                           # entries behind the last border persist (uint8_t t_env[8])
+        out["t_env"][:] = self.t_env
         out["bs_freq_res"][1: num_env + 1] = fr
         num_noise = 2 if num_env > 1 else 1
         out["bs_num_noise"] = num_noise
@@ -168,10 +169,11 @@ class _SbrChain:
             if cls == 0:
                 idx = num_env >> 1
             elif cls == 1:
-                idx = num_env - max(pointer - 1, 1)
+                # unsigned bs_pointer (aacsbr.c:613, 729): pointer 0 selects the stale entry behind the last border
+                idx = num_env + 1 if pointer == 0 else num_env - max(pointer - 1, 1)
             else:
                 idx = 1 if pointer == 0 else (num_env - 1 if pointer == 1 else pointer - 1)
-            tq = [t[0], t[idx], t[num_env]]
+            tq = [t[0], self.t_env[idx], t[num_env]]
         out["t_q"][: len(tq)] = tq
         # l_APrev / l_A (aacsbr.c:737-743)
         e_a0 = -1 if (self.e_a1 != num_env_old) else 0

@@ -225,8 +225,12 @@ typedef struct HeaacPsFrame {
  * prototype, noise table, PS filters) resident in HBM for one device, plus a
  * scratch workspace sized for `max_frames`.  One per GPU/process.  The HE
  * calls pass intermediates (and a frame queue) through that workspace, so the
- * calls on one HeaacDevice must be ordered on one stream (or serialised by the
- * caller); concurrent streams take one HeaacDevice each. */
+ * HE calls on one HeaacDevice must not overlap: the context remembers the stream
+ * of its last HE call, and an HE call on ANOTHER stream while that work is still
+ * in flight returns HEAAC_ERR_ARG (it is accepted once the earlier work has
+ * completed; inside a stream capture the question cannot be asked, so a capture
+ * must run on the stream of the context's previous HE call -- warm up on the
+ * capture stream).  Concurrent streams take one HeaacDevice each. */
 typedef struct HeaacDevice HeaacDevice;
 
 /* Create the context on the current HIP device.  Returns 0 on success,

@@ -4,7 +4,9 @@ records per frame and of the int16 PCM of the whole stream (host parser -> oracl
 The vectors are data: once minted they pin parser + decoder against drift without the writers' models, and
 `tests/test_golden.py` decodes the same bytes through the codec surface on the GPU.
 
-    python tests/golden/make_bitstream_vectors.py
+    python tests/golden/make_bitstream_vectors.py            # write new streams
+    python tests/golden/make_bitstream_vectors.py --rehash   # keep the stored BYTES, re-derive what must come out of them
+                                                             # (after a deliberate change of parser semantics)
 """
 import hashlib, importlib, json, os, sys
 
@@ -91,13 +93,15 @@ def main():
     pkg = importlib.import_module("ffmpeg-heaac_amd")
     import oracle_lib as oracle
     out = {}
+    path = os.path.join(ROOT, "tests", "golden", "bitstreams.json")
+    stored = json.load(open(path)) if "--rehash" in sys.argv else None
     for name in STREAMS:
-        aus = write_stream(pkg, name)
+        aus = [bytes.fromhex(a) for a in stored[name]["access_units"]] if stored else write_stream(pkg, name)
         rec, pcm, shape = decode_stream(pkg, oracle, name, aus)
         out[name] = dict(asc=STREAMS[name][0].hex(), access_units=[a.hex() for a in aus], records_sha256=rec,
                          pcm_s16_sha256=pcm, frame_shape=shape)
         print(name, len(aus), "units,", sum(len(a) for a in aus), "bytes, pcm", pcm[:16])
-    json.dump(out, open(os.path.join(ROOT, "tests", "golden", "bitstreams.json"), "w"), indent=0)
+    json.dump(out, open(path, "w"), indent=0)
 
 
 if __name__ == "__main__":

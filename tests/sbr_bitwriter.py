@@ -119,6 +119,7 @@ class Channel:
         self.amp_res = 0
         self.t_env_num_env_old = 0
         self.cls = 0
+        self.pointer = 0
 
     # -- grid ---------------------------------------------------------------------------------
     def draw_grid(self, rng, bw, amp_res_header, varfrac):
@@ -198,6 +199,7 @@ class Channel:
                 break
         bw.bits.extend(w.bits)
         self.cls, self.num_env, self.amp_res = cls, L, amp
+        self.pointer = pointer
         self.t_env[:L + 1] = t
         self.freq_res[1:L + 1] = fr
         Q = 2 if L > 1 else 1
@@ -207,10 +209,12 @@ class Channel:
             if cls == 0:
                 idx = L >> 1
             elif cls & 1:
-                idx = L - max(pointer - 1, 1)
+                # the reference's pointer is unsigned: `bs_num_env - FFMAX(bs_pointer - 1, 1)` wraps for pointer 0
+                # and selects t_env[L + 1], what an earlier frame left behind the last border (aacsbr.c:613, 729)
+                idx = L + 1 if pointer == 0 else L - max(pointer - 1, 1)
             else:
                 idx = 1 if pointer == 0 else (L - 1 if pointer == 1 else pointer - 1)
-            self.t_q[1] = t[idx]
+            self.t_q[1] = self.t_env[idx]
         e_a0 = -1 if self.e_a[1] != num_env_old else 0
         e_a1 = -1
         if (cls & 1) and pointer:

@@ -23,9 +23,9 @@ def declared_symbols():
 
 def test_headers_declare_what_the_package_lists(pkg):
     decl = declared_symbols()
-    assert set(pkg.EXPORTED) <= decl, set(pkg.EXPORTED) - decl
+    assert set(pkg.EXPORTED) <= decl - {"av_class"}, set(pkg.EXPORTED) - decl
     # nothing declared is missing from the package's list either
-    assert decl - {"heaac_iso_qmf_c", "heaac_iso_noise"} <= set(pkg.EXPORTED), decl - set(pkg.EXPORTED)
+    assert decl - {"heaac_iso_qmf_c", "heaac_iso_noise", "av_class"} <= set(pkg.EXPORTED), decl - set(pkg.EXPORTED)   # av_class: a field of the AVCodecContext layout
 
 
 def test_library_exports_every_declared_symbol(pkg):

@@ -246,6 +246,36 @@ def test_he_decode_is_graph_capturable(pkg, oracle, dev):
     assert nbad == 0, where
 
 
+@pytest.mark.gpu
+def test_he_calls_on_two_streams_may_not_overlap(pkg):
+    """One HeaacDevice = one workspace: an HE call on a second stream while the first stream's call is still in
+    flight is refused (HEAAC_ERR_ARG), and accepted once that work has completed."""
+    import torch
+    synth = _synth()
+    rng = np.random.default_rng(5)
+    hdr = synth.default_headers(pkg)
+    n, cfg = 32768, pkg.CFG_HEV2
+    fr = next(synth.he_stream(rng, cfg, 256, 1, hdr))
+    rep = n // 256
+    args = (torch.from_numpy(fr["coeffs"]).cuda().repeat(rep, 1, 1), pkg.to_device(fr["ics"]).repeat(rep),
+            pkg.to_device(fr["sbr"]).repeat(rep), pkg.to_device(hdr), pkg.to_device(fr["ps"]).repeat(rep))
+    st = torch.zeros((n, pkg.STATE_WORDS[cfg]), device="cuda")
+    pcm = torch.empty((n, 2, 2048), device="cuda")
+    d = pkg.Device(n)
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(a):
+        d.he_decode(cfg, *args, st, state_out=st, pcm=pcm)                 # ~1 ms of device work
+    with torch.cuda.stream(b):
+        with pytest.raises(pkg.HeaacError):
+            d.he_decode(cfg, *args, st, state_out=st, pcm=pcm)
+    a.synchronize()
+    with torch.cuda.stream(b):
+        d.he_decode(cfg, *args, st, state_out=st, pcm=pcm)                 # the first stream is idle now
+    torch.cuda.synchronize()
+    d.close()
+
+
 def _random_headers(pkg, rng, count):
     """`count` valid SBR headers drawn over the whole parameter space (and three SBR rates)."""
     hs = []

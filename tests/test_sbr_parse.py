@@ -69,6 +69,34 @@ def test_cpe_payloads_coupled_and_not(pkg, seed):
     assert seen["table"] > 2
 
 
+def test_middle_noise_border_follows_the_unsigned_pointer_of_the_reference(pkg):
+    """read_sbr_grid computes the middle noise border of a frame with a variable trailing end as
+    `bs_num_env - FFMAX(bs_pointer - 1, 1)` on an UNSIGNED bs_pointer (aacsbr.c:613, 729): for bs_pointer = 0 the
+    index wraps to bs_num_env + 1 and t_q[1] becomes what an earlier frame left behind the last border in t_env[]
+    (ISO/IEC 14496-3 4.6.18.3.3 would take border bs_num_env - 1).  The parser reproduces the reference; this test
+    states the expected value from the reference's expression, evaluated in 32-bit unsigned arithmetic."""
+    rng = np.random.default_rng(21)
+    tab = pkg.SbrHeaderTable(64)
+    st = pkg.sbr_streams(1)
+    w = SW.SbrStreamWriter(pkg, 1, ps=False, varfrac=0.9)
+    hits = differs = 0
+    for f in range(400):
+        bits, exp = w.frame(rng)
+        r, sbr, _, _ = pkg.sbr_parse_payload(st[0], tab, 24000, SW.to_bytes(bits), 1, False)
+        assert r == 0, f
+        c = w.ch[0]
+        ch = sbr["ch"][0][0]
+        L = int(ch["bs_num_env"])
+        if (c.cls & 1) and L > 1:
+            idx = (L - max((c.pointer - 1) & 0xffffffff, 1)) & 0xffffffff      # FFMAX on unsigned operands
+            assert int(ch["t_q"][1]) == int(ch["t_env"][idx]), (f, c.cls, L, c.pointer)
+            if c.pointer == 0:
+                hits += 1
+                assert idx == L + 1
+                differs += int(ch["t_q"][1]) != int(ch["t_env"][L - 1])            # what ISO's signed reading gives
+    assert hits >= 10 and differs >= 5
+
+
 def test_ps_modes_20_and_34(pkg):
     for modes in ("20", "34"):
         _run_stream(pkg, np.random.default_rng(5), 1, True, 40, ps_modes=modes)

@@ -49,7 +49,7 @@ POISON_SBR = [
     ("SBR_T_ENV", lambda f, h: f["ch"][0]["t_env"].__setitem__(1, 0)),                       # not increasing
     ("SBR_T_ENV", lambda f, h: f["ch"][0]["t_env"].__setitem__(int(f["ch"][0]["bs_num_env"]), 20)),
     ("SBR_T_ENV", lambda f, h: f["ch"][0]["t_env"].__setitem__(0, 200)),
-    ("SBR_T_Q", lambda f, h: f["ch"][0]["t_q"].__setitem__(1, 15)),
+    ("SBR_T_Q", lambda f, h: f["ch"][0]["t_q"].__setitem__(1, 20)),
     ("SBR_FLAGS", lambda f, h: f["ch"][0]["bs_invf_mode"][0].__setitem__(0, 4)),
     ("SBR_FLAGS", lambda f, h: f["ch"][0]["e_a"].__setitem__(1, 9)),
     ("SBR_FLAGS", lambda f, h: f.__setitem__("bs_coupling", 1)),                           # coupling on an SCE

@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs a -DHEAAC_TUNING build (tools/build_variants.sh tuning "-DHEAAC_TUNING"; HEAAC_LIB_PATH=ab/libtuning.so)
 # usage (via gpurun): tools/chunk_sweep.sh <tag> <lanes>:<chunk> ...  -- headline bench per (HEAAC_LANES, HEAAC_CHUNK_FRAMES)
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-/root/repo}
