@@ -115,7 +115,7 @@ EXPORTED = [
     # heaac_codec.h
     "heaac_aac_decoder", "heaac_codec_open", "heaac_codec_decode", "heaac_codec_close",
     # heaac_parse.h
-    "heaac_asc_parse", "heaac_ga_specific_config", "heaac_codec_get_context_defaults", "heaac_adts_parse_header", "heaac_aac_parse_frame", "heaac_aac_parse_batch",
+    "heaac_asc_parse", "heaac_ga_specific_config", "heaac_codec_get_context_defaults", "heaac_adts_parse_header", "heaac_adts_probe", "heaac_adts_split", "heaac_aac_parse_frame", "heaac_aac_parse_batch",
     "heaac_aac_tables_fingerprint",
     "heaac_sbr_table_create", "heaac_sbr_table_destroy", "heaac_sbr_table_count", "heaac_sbr_table_data",
     "heaac_sbr_stream_init", "heaac_sbr_stream_bytes", "heaac_sbr_parse_payload", "heaac_sbr_no_payload",
@@ -424,6 +424,30 @@ def adts_parse_header(buf):
     h = AdtsHeader()
     r = lib().heaac_adts_parse_header(C.byref(h), bytes(buf), len(buf))
     return h, r
+
+
+ADTS_PACKET_DT = np.dtype([("offset", "<u8"), ("size", "<u8"), ("kind", "<i4"), ("header_size", "<i4")])
+ADTS_FRAME, ADTS_JUNK, ADTS_TRUNCATED, ADTS_TAG = 0, 1, 2, 3
+
+
+def adts_probe(buf):
+    """heaac_adts_probe: the demuxer's probe score of a raw ADTS buffer."""
+    return lib().heaac_adts_probe(bytes(buf), C.c_size_t(len(buf)))
+
+
+def adts_split(buf):
+    """heaac_adts_split: (packets [ADTS_PACKET_DT], header of the first frame or None)."""
+    buf = bytes(buf)
+    L = lib()
+    L.heaac_adts_split.restype = C.c_long
+    n = L.heaac_adts_split(buf, C.c_size_t(len(buf)), None, C.c_size_t(0), None)
+    if n < 0:
+        raise HeaacError("heaac_adts_split -> %d" % n)
+    out = np.zeros(n, ADTS_PACKET_DT)
+    h = AdtsHeader()
+    m = L.heaac_adts_split(buf, C.c_size_t(len(buf)), out.ctypes.data_as(C.c_void_p), C.c_size_t(n), C.byref(h))
+    assert m == n
+    return out, (h if (out["kind"] != ADTS_JUNK).any() and ((out["kind"] == ADTS_FRAME) | (out["kind"] == ADTS_TRUNCATED)).any() else None)
 
 
 def aac_parse_batch(cfg, streams, aus, threads=0):

@@ -21,12 +21,13 @@ static Tree g_sf_tree, g_spec_tree[11];
 static float g_pow2sf[428];                           /* ff_aac_pow2sf_tab: 2^((i - 200) / 4), aac_tablegen.h */
 static float g_mag[16];                               /* q^(4/3), q = 0..15 (aactab.c: codebook vector values) */
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;
+static int g_tables_bad;                              /* a code book did not fit its tree (never with the shipped tables) */
 
 static void tables_init(void)
 {
-    tree_build(&g_sf_tree, aac_sf_code, NULL, aac_sf_bits, 121);
+    g_tables_bad |= tree_build(&g_sf_tree, aac_sf_code, NULL, aac_sf_bits, 121);
     for (int b = 0; b < 11; b++)
-        tree_build(&g_spec_tree[b], NULL, aac_spec_code + aac_spec_first[b], aac_spec_bits + aac_spec_first[b],
+        g_tables_bad |= tree_build(&g_spec_tree[b], NULL, aac_spec_code + aac_spec_first[b], aac_spec_bits + aac_spec_first[b],
                    aac_spec_first[b + 1] - aac_spec_first[b]);
     for (int i = 0; i < 428; i++) g_pow2sf[i] = (float)pow(2, (i - 200) / 4.);
     for (int q = 0; q < 16; q++) g_mag[q] = (float)pow((double)q, 4.0 / 3.0);
@@ -480,6 +481,7 @@ int heaac_aac_parse_frame(const HeaacAacConfig *cfg, HeaacAacStream *st,
         cfg->sampling_index < 0 || cfg->sampling_index > 12)
         return HEAAC_PARSE_ERR_ARG;
     pthread_once(&g_once, tables_init);
+    if (g_tables_bad) return HEAAC_PARSE_ERR_ARG;
     Bits b;
     bits_init(&b, au, size);
     if (peek(&b, 12) == 0xfff) {
@@ -487,6 +489,11 @@ int heaac_aac_parse_frame(const HeaacAacConfig *cfg, HeaacAacStream *st,
         HeaacAdtsHeader h;
         const int hs = heaac_adts_parse_header(&h, au, size);
         if (hs < 0) return HEAAC_PARSE_ERR_DATA;
+        /* parse_adts_frame_header (aacdec.c:1935-1971) takes rate and object type from every header and refuses
+         * more than one raw data block per frame.  `cfg` is the caller's (read-only, shared by a batch): a header
+         * that contradicts it would be dequantised against the wrong band tables, so it is refused instead. */
+        if (h.num_aac_frames != 1) return HEAAC_PARSE_ERR_UNSUPPORTED;
+        if (h.sampling_index != cfg->sampling_index || h.object_type != cfg->object_type) return HEAAC_PARSE_ERR_DATA;
         b.pos = hs * 8;
     }
     WinInfo w[2];
@@ -610,6 +617,7 @@ int heaac_aac_parse_batch(const HeaacAacConfig *cfg, HeaacAacStream *st,
     if (!cfg || !st || !au || !size || !coeffs || !ics || !tools) return HEAAC_PARSE_ERR_ARG;
     if (!n) return 0;
     pthread_once(&g_once, tables_init);
+    if (g_tables_bad) return HEAAC_PARSE_ERR_ARG;
     if (threads <= 0) threads = (int)sysconf(_SC_NPROCESSORS_ONLN);
     if (threads < 1) threads = 1;
     if ((size_t)threads > n) threads = (int)n;

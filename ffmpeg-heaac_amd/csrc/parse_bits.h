@@ -57,14 +57,19 @@ static inline int bits_left(const Bits *b) { return b->size_bits - b->pos; }
 /* ------------------------------------------------------------------------------------------ */
 typedef struct { int16_t child[2]; } Node;           /* >= 0: node index, < 0: -(symbol + 1), 0 at root only */
 #define TREE_LUT_BITS 10
+#define TREE_MAX_SYMBOLS 289                          /* the largest code book of the path (AAC spectral books 1-4: 81, 5-6: 81,
+                                                         7-8: 64, 9-10: 169, 11: 289; SBR <= 121; PS <= 61) */
+#define TREE_MAX_NODES (2 * TREE_MAX_SYMBOLS + 2)
 /* lut[prefix]: length << 16 | symbol for a code of <= TREE_LUT_BITS bits; 0xff << 16 for a prefix that is no code;
- * otherwise (length 0) the node reached after TREE_LUT_BITS bits, from where the walk goes on bit by bit */
-typedef struct { Node *n; int count; uint32_t *lut; } Tree;
+ * otherwise (length 0) the node reached after TREE_LUT_BITS bits, from where the walk goes on bit by bit.
+ * Fixed storage: building a tree allocates nothing, so it cannot fail half-way inside pthread_once. */
+typedef struct { Node n[TREE_MAX_NODES]; int count; uint32_t lut[1u << TREE_LUT_BITS]; } Tree;
 
-static inline void tree_build(Tree *t, const uint32_t *code32, const uint16_t *code16, const uint8_t *len, int n)
+/* Returns 0, or -1 if the book does not fit the fixed storage (a table-generation error, caught by the tests). */
+static inline int tree_build(Tree *t, const uint32_t *code32, const uint16_t *code16, const uint8_t *len, int n)
 {
-    int cap = 2 * n + 2;
-    t->n = (Node *)calloc(cap, sizeof(Node));
+    memset(t, 0, sizeof(*t));
+    if (n > TREE_MAX_SYMBOLS) return -1;
     t->count = 1;
     for (int s = 0; s < n; s++) {
         const uint32_t c = code32 ? code32[s] : code16[s];
@@ -75,6 +80,7 @@ static inline void tree_build(Tree *t, const uint32_t *code32, const uint16_t *c
                 t->n[at].child[bit] = (int16_t)-(s + 1);
             } else {
                 if (t->n[at].child[bit] <= 0) {
+                    if (t->count >= TREE_MAX_NODES) return -1;
                     t->n[at].child[bit] = (int16_t)t->count;
                     t->count++;
                 }
@@ -82,7 +88,6 @@ static inline void tree_build(Tree *t, const uint32_t *code32, const uint16_t *c
             }
         }
     }
-    t->lut = (uint32_t *)calloc(1u << TREE_LUT_BITS, sizeof(uint32_t));
     for (uint32_t p = 0; p < (1u << TREE_LUT_BITS); p++) {
         int at = 0;
         uint32_t e = 0;
@@ -95,6 +100,7 @@ static inline void tree_build(Tree *t, const uint32_t *code32, const uint16_t *c
         }
         t->lut[p] = e;
     }
+    return 0;
 }
 
 static inline int tree_read(const Tree *t, Bits *b)

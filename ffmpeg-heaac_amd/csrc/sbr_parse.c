@@ -32,13 +32,14 @@ enum { EXTENSION_ID_PS = 2 };
 
 static Tree g_sbr_tree[10], g_ps_tree[10];
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;
+static int g_tables_bad;                              /* a code book did not fit its tree (never with the shipped tables) */
 
 static void tables_init(void)
 {
     for (int t = 0; t < 10; t++) {
-        tree_build(&g_sbr_tree[t], sbr_huff_code + sbr_huff_first[t], NULL, sbr_huff_bits + sbr_huff_first[t],
+        g_tables_bad |= tree_build(&g_sbr_tree[t], sbr_huff_code + sbr_huff_first[t], NULL, sbr_huff_bits + sbr_huff_first[t],
                    sbr_huff_first[t + 1] - sbr_huff_first[t]);
-        tree_build(&g_ps_tree[t], ps_huff_code + ps_huff_first[t], NULL, ps_huff_bits + ps_huff_first[t],
+        g_tables_bad |= tree_build(&g_ps_tree[t], ps_huff_code + ps_huff_first[t], NULL, ps_huff_bits + ps_huff_first[t],
                    ps_huff_first[t + 1] - ps_huff_first[t]);
     }
 }
@@ -785,6 +786,7 @@ int heaac_sbr_parse_payload(HeaacSbrStream *st, HeaacSbrHeaderTable *tab, int sa
         (channels != 1 && channels != 2) || (allow_ps && !ps))
         return HEAAC_PARSE_ERR_ARG;
     pthread_once(&g_once, tables_init);
+    if (g_tables_bad) return HEAAC_PARSE_ERR_ARG;
 
     Bits gb, *b = &gb;
     bits_init(b, au, size);

@@ -81,6 +81,34 @@ typedef struct HeaacAdtsHeader {
  * -1 no sync word, -2 reserved sampling index, -3 frame length shorter than the header. */
 int heaac_adts_parse_header(HeaacAdtsHeader *h, const uint8_t *buf, int size);
 
+/* ---- a raw ADTS (.aac) buffer -> access units (libavformat/raw.c:666-717, libavcodec/aac_ac3_parser.c:26-100) ---- */
+enum {
+    HEAAC_ADTS_FRAME = 0,         /* one ADTS frame, header included: an access unit for heaac_aac_parse_frame /
+                                   * heaac_heaac_parse_frame / heaac_codec_decode */
+    HEAAC_ADTS_JUNK = 1,          /* bytes no header claims (damage, padding); the reference's parser passes such
+                                   * spans to the decoder as packets, which refuses them */
+    HEAAC_ADTS_TRUNCATED = 2,     /* a header whose frame runs past the end of the buffer */
+    HEAAC_ADTS_TAG = 3            /* an ID3v2 tag at the start (stepped over by the demuxer, raw.c:677-679, :711) */
+};
+typedef struct HeaacAdtsPacket {
+    size_t offset, size;          /* span of the buffer */
+    int kind;                     /* HEAAC_ADTS_* */
+    int header_size;              /* frames: 7, or 9 with a CRC */
+} HeaacAdtsPacket;
+
+/* adts_aac_probe (raw.c:666-702): 51 if the buffer starts (behind an ID3v2 tag) with three or more frames in
+ * step, 50 for a run of more than 500 anywhere, 25 for a run of three, 1 for a single header, else 0. */
+int heaac_adts_probe(const uint8_t *buf, size_t size);
+
+/* Walk a whole .aac buffer into packets, frames behind each other as ff_aac_ac3_parse delivers them.  Directly
+ * behind a good frame a header is taken as the reference takes it (sync word, legal sampling index, length >= 7);
+ * a header found while SEARCHING (start of the buffer, behind damage) must be followed by another header one frame
+ * length on (the probe's rule; the reference's streaming parser cannot look ahead and takes the first seven bytes
+ * that parse).  Writes up to max_out packets (out may be NULL to count) and returns how many the buffer holds, or
+ * a negative HEAAC_PARSE_ERR_*.  *first_header (may be NULL) receives the first frame's header: the stream's
+ * configuration as parse_adts_frame_header (aacdec.c:1935-1971) would take it. */
+long heaac_adts_split(const uint8_t *buf, size_t size, HeaacAdtsPacket *out, size_t max_out, HeaacAdtsHeader *first_header);
+
 /* What the parser carries from frame to frame of one stream (IndividualChannelStream
  * window_sequence[1] / use_kb_window[1], aac.h:137-138).  Zero-initialise for a new stream. */
 typedef struct HeaacAacStream {

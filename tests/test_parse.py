@@ -284,6 +284,19 @@ def test_adts_header(pkg):
     st = np.zeros(1, pkg.AAC_STREAM_DT)
     out = pkg.aac_parse_batch(_cfg(pkg), st, [bw.bytes(pad=0) + au], threads=1)
     assert out["failed"] == 0 and out["info"][0]["bits_consumed"] == 56 + e["bits"]
+    # parse_adts_frame_header (aacdec.c:1935-1971): more than one raw data block per frame is unsupported, and a
+    # header whose rate or object type contradicts the configuration the batch was given is refused (the reference
+    # adopts the header's values; here `cfg` is read-only and a mismatch would pick the wrong band tables)
+    def hdr(aot_m1, si, rdb):
+        w = W.BitWriter()
+        for v, n in ((0xfff, 12), (0, 1), (0, 2), (1, 1), (aot_m1, 2), (si, 4), (0, 1), (2, 3), (0, 4),
+                     (7 + len(au), 13), (0x7ff, 11), (rdb, 2)):
+            w.put(v, n)
+        return w.bytes(pad=0)
+    for h, want in ((hdr(1, 3, 0), 0), (hdr(1, 3, 1), -3), (hdr(1, 4, 0), -1), (hdr(0, 3, 0), -1)):   # OK, UNSUPPORTED, DATA, DATA
+        st = np.zeros(1, pkg.AAC_STREAM_DT)
+        out = pkg.aac_parse_batch(_cfg(pkg), st, [h + au], threads=1)
+        assert int(out["status"][0]) == want, (want, int(out["status"][0]))
 
 
 def test_iso_tables_fingerprint(pkg):
