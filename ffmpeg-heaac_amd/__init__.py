@@ -115,7 +115,9 @@ EXPORTED = [
     # heaac_codec.h
     "heaac_aac_decoder", "heaac_codec_open", "heaac_codec_decode", "heaac_codec_close",
     # heaac_parse.h
-    "heaac_asc_parse", "heaac_ga_specific_config", "heaac_codec_get_context_defaults", "heaac_adts_parse_header", "heaac_adts_probe", "heaac_adts_split", "heaac_aac_parse_frame", "heaac_aac_parse_batch",
+    "heaac_asc_parse", "heaac_ga_specific_config", "heaac_codec_get_context_defaults", "heaac_adts_parse_header", "heaac_adts_probe", "heaac_adts_split",
+    "heaac_multi_shard", "heaac_multi_create", "heaac_multi_destroy", "heaac_multi_devices", "heaac_multi_device",
+    "heaac_multi_stream", "heaac_multi_he_decode", "heaac_aac_parse_frame", "heaac_aac_parse_batch",
     "heaac_aac_tables_fingerprint",
     "heaac_sbr_table_create", "heaac_sbr_table_destroy", "heaac_sbr_table_count", "heaac_sbr_table_data",
     "heaac_sbr_stream_init", "heaac_sbr_stream_bytes", "heaac_sbr_parse_payload", "heaac_sbr_no_payload",
