@@ -94,10 +94,11 @@ long heaac_adts_split(const uint8_t *buf, size_t size, HeaacAdtsPacket *out, siz
         HeaacAdtsHeader h;
         int flen = header_at(buf, size, at, &h);
         if (flen && !in_step) {
-            /* a candidate found while searching: the header behind it must be one too, unless the buffer ends
-             * first (then the candidate is the last, possibly cut, frame) */
+            /* a candidate found while searching: the header behind it must be one too, or the candidate ends
+             * exactly where the buffer ends (the last frame).  One that runs past the end cannot be told from
+             * payload bytes and stays junk; only a frame directly behind a good one is reported as cut short. */
             const size_t next = at + (size_t)flen;
-            if (next + 7 <= size && !header_at(buf, size, next, NULL)) flen = 0;
+            if (next != size && !header_at(buf, size, next, NULL)) flen = 0;
         }
         if (!flen) {
             in_step = 0;

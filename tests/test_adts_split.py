@@ -96,6 +96,12 @@ def test_truncated_tail_and_degenerate_buffers(pkg):
     buf = b"".join(frames)[:-10]
     got, _ = spans(pkg, buf)
     assert [g[0] for g in got] == [pkg.ADTS_FRAME] * 3 + [pkg.ADTS_TRUNCATED]
+    # while SEARCHING, a header whose frame would run past the end is not believed (it may be payload bytes)
+    fake = bytes([0xff, 0xf1, 0x4c, 0x80, 0x7f, 0xff, 0xfc])            # length 1023
+    buf = bytes(12) + fake + bytes(100)
+    assert [g[0] for g in spans(pkg, buf)[0]] == [pkg.ADTS_JUNK]
+    buf = bytes(12) + fake + bytes(1023 - 7)                            # ... unless it ends exactly with the buffer
+    assert [g[0] for g in spans(pkg, buf)[0]] == [pkg.ADTS_JUNK, pkg.ADTS_FRAME]
     assert spans(pkg, b"")[0] == []
     assert spans(pkg, bytes(5))[0] == [(pkg.ADTS_JUNK, 0, 5)]
     assert spans(pkg, bytes([0xff] * 64))[0] == [(pkg.ADTS_JUNK, 0, 64)]  # sync words with a reserved sampling index
