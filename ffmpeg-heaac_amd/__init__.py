@@ -94,6 +94,14 @@ TOOLS_FRAME_DT = np.dtype([
     ("ch", TOOLS_CH_DT, (2,)),
 ])
 assert TOOLS_ICS_DT.itemsize == 144 and TNS_DT.itemsize == 2668 and TOOLS_FRAME_DT.itemsize == 7132
+MAX_CCE, MAX_CCE_LINKS = 2, 4
+CC_BEFORE_TNS, CC_BETWEEN_TNS_AND_IMDCT, CC_AFTER_IMDCT = 0, 1, 3
+TOOLS_PRE, TOOLS_POST, TOOLS_ALL = 1, 2, 3
+CCE_LINK_DT = np.dtype([("target_ch", "u1"), ("pad", "u1", (3,)), ("gain", "<f4", (120,))])
+CCE_FRAME_DT = np.dtype([("present", "u1"), ("elem_id", "u1"), ("coupling_point", "u1"), ("n_links", "u1"),
+                         ("behind_target", "u1"), ("seq", "u1"), ("pad", "u1", (2,)), ("ics", TOOLS_ICS_DT), ("band_type", "u1", (128,)),
+                         ("link", CCE_LINK_DT, (MAX_CCE_LINKS,))])
+assert CCE_LINK_DT.itemsize == 484 and CCE_FRAME_DT.itemsize == 2216
 assert SBR_HDR_DT.itemsize == 532 and SBR_CH_DT.itemsize == 336
 assert SBR_FRAME_DT.itemsize == 680 and PS_FRAME_DT.itemsize == 532
 
@@ -115,7 +123,7 @@ EXPORTED = [
     # heaac_codec.h
     "heaac_aac_decoder", "heaac_codec_open", "heaac_codec_decode", "heaac_codec_close",
     # heaac_parse.h
-    "heaac_asc_parse", "heaac_ga_specific_config", "heaac_codec_get_context_defaults", "heaac_adts_parse_header", "heaac_adts_probe", "heaac_adts_split",
+    "heaac_asc_parse", "heaac_ga_specific_config", "heaac_aac_parse_frame_ex", "heaac_spectral_tools_batch_ex", "heaac_codec_get_context_defaults", "heaac_adts_parse_header", "heaac_adts_probe", "heaac_adts_split",
     "heaac_multi_shard", "heaac_multi_create", "heaac_multi_destroy", "heaac_multi_devices", "heaac_multi_device",
     "heaac_multi_stream", "heaac_multi_he_decode", "heaac_aac_parse_frame", "heaac_aac_parse_batch",
     "heaac_aac_tables_fingerprint",
@@ -295,6 +303,27 @@ class Device:
                                                 C.c_size_t(n), _stream()), "heaac_spectral_tools_batch")
         return coeffs
 
+    def spectral_tools_ex(self, channels, stages, coeffs, tools, rng=None, pred=None, cce=None, cce_coeffs=None):
+        """heaac_spectral_tools_batch_ex: the PRE / POST halves; cce [n][n_cce] records (uint8 tensor) and
+        cce_coeffs [n][n_cce][1024] couple into the target in POST."""
+        import torch
+        n = coeffs.shape[0]
+        assert coeffs.dtype == torch.float32 and coeffs.numel() == n * channels * 1024
+        assert tools.dtype == torch.uint8 and tools.numel() == n * TOOLS_FRAME_DT.itemsize
+        n_cce = 0
+        if cce is not None:
+            n_cce = cce.numel() // (n * CCE_FRAME_DT.itemsize)
+            assert cce.dtype == torch.uint8 and cce.numel() == n * n_cce * CCE_FRAME_DT.itemsize
+            assert cce_coeffs.dtype == torch.float32 and cce_coeffs.numel() == n * n_cce * 1024
+        _check(lib().heaac_spectral_tools_batch_ex(self._h, channels, stages, _ptr(coeffs), _ptr(tools),
+                                                   _ptr(rng) if rng is not None else None,
+                                                   _ptr(rng) if rng is not None else None,
+                                                   _ptr(pred) if pred is not None else None,
+                                                   _ptr(pred) if pred is not None else None,
+                                                   _ptr(cce) if n_cce else None, _ptr(cce_coeffs) if n_cce else None,
+                                                   n_cce, C.c_size_t(n), _stream()), "heaac_spectral_tools_batch_ex")
+        return coeffs
+
     # -- HE-AAC --
     def couple_after_imdct(self, channels, pcm, cce, coupling, s16=False):
         """heaac_couple_after_imdct_batch: pcm [n][channels][1024] f32 updated in place; returns the int16
@@ -408,9 +437,10 @@ class AdtsHeader(C.Structure):
 
 
 COUPLING_DT = np.dtype([("gain", "<f4", (2,)), ("on", "u1", (2,)), ("pad", "u1", (2,))])
-AAC_STREAM_DT = np.dtype([("window_sequence", "u1", (2,)), ("use_kb_window", "u1", (2,)), ("pad", "u1", (4,))])
+AAC_STREAM_DT = np.dtype([("window_sequence", "u1", (2,)), ("use_kb_window", "u1", (2,)),
+                          ("cce_window_sequence", "u1", (2,)), ("cce_use_kb_window", "u1", (2,))])
 AAC_INFO_DT = np.dtype([("channels", "<i4"), ("bits_consumed", "<i4"), ("sbr_payload_bit", "<i4"),
-                        ("sbr_payload_bytes", "<i4"), ("sbr_crc", "<i4")])
+                        ("sbr_payload_bytes", "<i4"), ("sbr_crc", "<i4"), ("elem_id", "<i4"), ("n_cce", "<i4")])
 
 
 def asc_parse(buf):
@@ -450,6 +480,27 @@ def adts_split(buf):
     m = L.heaac_adts_split(buf, C.c_size_t(len(buf)), out.ctypes.data_as(C.c_void_p), C.c_size_t(n), C.byref(h))
     assert m == n
     return out, (h if (out["kind"] != ADTS_JUNK).any() and ((out["kind"] == ADTS_FRAME) | (out["kind"] == ADTS_TRUNCATED)).any() else None)
+
+
+class _CceOut(C.Structure):
+    _fields_ = [("cce", C.c_void_p), ("coeffs", C.c_void_p), ("ics", C.c_void_p), ("tools", C.c_void_p)]
+
+
+def aac_parse_frame_ex(cfg, stream, au, coeff_channels=2, with_cce=True):
+    """heaac_aac_parse_frame_ex on one access unit.  `stream`: one AAC_STREAM_DT record (updated in place).
+    Returns (status, dict(coeffs [coeff_channels][1024], ics, tools, info, cce [MAX_CCE], cce_coeffs, cce_ics, cce_tools))."""
+    au = bytes(au)
+    out = dict(coeffs=np.zeros((coeff_channels, 1024), np.float32), ics=np.zeros(2, ICS_DT),
+               tools=np.zeros(1, TOOLS_FRAME_DT), info=np.zeros(1, AAC_INFO_DT),
+               cce=np.zeros(MAX_CCE, CCE_FRAME_DT), cce_coeffs=np.zeros((MAX_CCE, 1024), np.float32),
+               cce_ics=np.zeros(MAX_CCE, ICS_DT), cce_tools=np.zeros(MAX_CCE, TOOLS_FRAME_DT))
+    co = _CceOut(out["cce"].ctypes.data, out["cce_coeffs"].ctypes.data, out["cce_ics"].ctypes.data,
+                 out["cce_tools"].ctypes.data)
+    r = lib().heaac_aac_parse_frame_ex(C.byref(cfg), stream.ctypes.data_as(C.c_void_p), au, len(au), coeff_channels,
+                                       out["coeffs"].ctypes.data_as(C.c_void_p), out["ics"].ctypes.data_as(C.c_void_p),
+                                       out["tools"].ctypes.data_as(C.c_void_p), C.byref(co) if with_cce else None,
+                                       out["info"].ctypes.data_as(C.c_void_p))
+    return r, out
 
 
 def aac_parse_batch(cfg, streams, aus, threads=0):

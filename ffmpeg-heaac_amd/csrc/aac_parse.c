@@ -472,13 +472,141 @@ static int read_ics(const HeaacAacConfig *cfg, Bits *b, int common_window, Heaac
 enum { TYPE_SCE, TYPE_CPE, TYPE_CCE, TYPE_LFE, TYPE_DSE, TYPE_PCE, TYPE_FIL, TYPE_END };
 enum { EXT_SBR_DATA = 0xd, EXT_SBR_DATA_CRC = 0xe };
 
+/* program_config_element: read past (decode_pce, aacdec.c:303-357).  The reference turns it into a channel
+ * layout (output_configure); this slice keeps the layout of the configuration. */
+static int skip_pce(Bits *b)
+{
+    bits(b, 2);                                        /* object_type */
+    bits(b, 4);                                        /* sampling_index */
+    const int num_front = (int)bits(b, 4), num_side = (int)bits(b, 4), num_back = (int)bits(b, 4);
+    const int num_lfe = (int)bits(b, 2), num_assoc = (int)bits(b, 3), num_cc = (int)bits(b, 4);
+    if (bit1(b)) bits(b, 4);                           /* mono_mixdown_tag */
+    if (bit1(b)) bits(b, 4);                           /* stereo_mixdown_tag */
+    if (bit1(b)) bits(b, 3);                           /* mixdown_coeff_index, pseudo_surround */
+    skip(b, 5 * (num_front + num_side + num_back));    /* is_cpe + tag per element */
+    skip(b, 4 * num_lfe);
+    skip(b, 4 * num_assoc);
+    skip(b, 5 * num_cc);                               /* cc_element_is_ind_sw + tag */
+    b->pos = (b->pos + 7) & ~7;
+    const int comment = 8 * (int)bits(b, 8);
+    if (bits_left(b) < comment) return HEAAC_PARSE_ERR_OVERREAD;
+    skip(b, comment);
+    return HEAAC_PARSE_OK;
+}
+
+/* coupling_channel_element (decode_cce, aacdec.c:1503-1570).  The element's target list is resolved against the
+ * ONE output element of this slice the way apply_channel_coupling walks it (:1870-1898): every entry consumes
+ * one gain list, or two for a pair coupled with separate gains (ch_select 3), whether or not it names our
+ * element; an entry that does name it contributes links (target channel, list index). */
+typedef struct { int type, id, ch_select; } CceTarget;
+
+static int read_cce(const HeaacAacConfig *cfg, Bits *b, int elem_id, int target_type, int target_id, int behind,
+                    HeaacCceFrame *out, HeaacToolsChannel *ch, WinInfo *w, float coef[1024])
+{
+    CceTarget tg[8];
+    int num_gain = 0;
+    memset(out, 0, sizeof(*out));
+    out->present = 1;
+    out->elem_id = (uint8_t)elem_id;
+    out->behind_target = (uint8_t)behind;
+    int point = 2 * (int)bit1(b);                      /* ind_sw_cce_flag */
+    const int num_coupled = (int)bits(b, 3);
+    for (int c = 0; c <= num_coupled; c++) {
+        num_gain++;
+        tg[c].type = bit1(b) ? TYPE_CPE : TYPE_SCE;
+        tg[c].id = (int)bits(b, 4);
+        tg[c].ch_select = 2;
+        if (tg[c].type == TYPE_CPE) {
+            tg[c].ch_select = (int)bits(b, 2);
+            if (tg[c].ch_select == 3) num_gain++;
+        }
+    }
+    point += (int)(bit1(b) || (point >> 1));           /* cc_domain; an independently switched element is always 3 */
+    out->coupling_point = (uint8_t)point;
+    const int sign = (int)bit1(b);
+    const double scale = pow(2., pow(2., (int)bits(b, 2) - 3));
+    int r = read_ics(cfg, b, 0, ch, w, coef);
+    if (r < 0) return r;
+    out->ics = ch->ics;
+    memcpy(out->band_type, ch->band_type, sizeof(out->band_type));
+
+    /* the gain lists, in transmission order (:1538-1567) */
+    float gl[16][120];
+    memset(gl, 0, sizeof(gl));
+    for (int c = 0; c < num_gain; c++) {
+        int idx = 0, cge = 1, gain = 0;
+        float gain_cache = 1.0f;
+        if (c) {
+            cge = point == HEAAC_CC_AFTER_IMDCT ? 1 : (int)bit1(b);
+            if (cge) {
+                const int sym = tree_read(&g_sf_tree, b);
+                if (sym < 0) return HEAAC_PARSE_ERR_DATA;
+                gain = sym - 60;
+            }
+            gain_cache = (float)pow(scale, -gain);
+        }
+        if (point == HEAAC_CC_AFTER_IMDCT) {
+            gl[c][0] = gain_cache;
+            continue;
+        }
+        for (int g = 0; g < ch->ics.num_window_groups; g++)
+            for (int sfb = 0; sfb < ch->ics.max_sfb; sfb++, idx++) {
+                if (idx >= 120) return HEAAC_PARSE_ERR_DATA;
+                if (ch->band_type[idx] == 0) continue;                 /* ZERO_BT */
+                if (!cge) {
+                    const int sym = tree_read(&g_sf_tree, b);
+                    if (sym < 0) return HEAAC_PARSE_ERR_DATA;
+                    int t = sym - 60;
+                    if (t) {
+                        int sgn = 1;
+                        t = gain += t;
+                        if (sign) { sgn -= 2 * (t & 1); t >>= 1; }
+                        gain_cache = (float)(pow(scale, -t) * sgn);
+                    }
+                }
+                gl[c][idx] = gain_cache;
+            }
+    }
+    /* which lists land on the output element, and on which of its channels */
+    int index = 0, n_links = 0;
+    for (int c = 0; c <= num_coupled; c++) {
+        if (tg[c].type == target_type && tg[c].id == target_id) {
+            int use[2], nuse = 0, chn[2];
+            if (tg[c].ch_select != 1) {
+                use[nuse] = index; chn[nuse++] = 0;
+                if (tg[c].ch_select != 0) index++;
+            }
+            if (tg[c].ch_select != 2) { use[nuse] = index++; chn[nuse++] = 1; }
+            for (int k = 0; k < nuse; k++) {
+                if (n_links >= HEAAC_MAX_CCE_LINKS) return HEAAC_PARSE_ERR_UNSUPPORTED;
+                out->link[n_links].target_ch = (uint8_t)chn[k];
+                memcpy(out->link[n_links].gain, gl[use[k]], sizeof(out->link[n_links].gain));
+                n_links++;
+            }
+        } else {
+            index += 1 + (tg[c].ch_select == 3);
+        }
+    }
+    out->n_links = (uint8_t)n_links;
+    return HEAAC_PARSE_OK;
+}
+
 int heaac_aac_parse_frame(const HeaacAacConfig *cfg, HeaacAacStream *st,
                           const uint8_t *au, int size,
                           float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
                           HeaacAacFrameInfo *info)
 {
+    return heaac_aac_parse_frame_ex(cfg, st, au, size, 2, coeffs, ics, tools, NULL, info);
+}
+
+int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
+                             const uint8_t *au, int size, int coeff_channels,
+                             float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
+                             const HeaacCceOut *cce, HeaacAacFrameInfo *info)
+{
     if (!cfg || !st || !au || size <= 0 || !coeffs || !ics || !tools ||
-        cfg->sampling_index < 0 || cfg->sampling_index > 12)
+        cfg->sampling_index < 0 || cfg->sampling_index > 12 || coeff_channels < 1 || coeff_channels > 2 ||
+        (cce && (!cce->cce || !cce->coeffs || !cce->ics || !cce->tools)))
         return HEAAC_PARSE_ERR_ARG;
     pthread_once(&g_once, tables_init);
     if (g_tables_bad) return HEAAC_PARSE_ERR_ARG;
@@ -496,26 +624,32 @@ int heaac_aac_parse_frame(const HeaacAacConfig *cfg, HeaacAacStream *st,
         if (h.sampling_index != cfg->sampling_index || h.object_type != cfg->object_type) return HEAAC_PARSE_ERR_DATA;
         b.pos = hs * 8;
     }
-    WinInfo w[2];
+    WinInfo w[2], wc[HEAAC_MAX_CCE];
     for (int c = 0; c < 2; c++) {
         w[c].window_sequence[0] = st->window_sequence[c];
         w[c].use_kb_window[0] = st->use_kb_window[c];
         w[c].window_sequence[1] = w[c].use_kb_window[1] = 0;
     }
     memset(tools, 0, sizeof(*tools));
-    HeaacAacFrameInfo fi = { 0, 0, -1, 0, 0 };
+    HeaacAacFrameInfo fi = { 0, 0, -1, 0, 0, 0, 0 };
+    /* The coupling elements name their targets by (type, tag): the output element of this slice is the one SCE /
+     * CPE of the configuration (set_default_channel_config: tag 0), known before the walk starts. */
+    const int target_type = cfg->chan_config == 2 ? TYPE_CPE : TYPE_SCE;
+    int cce_tag[HEAAC_MAX_CCE], n_cce = 0;
+    if (cce) memset(cce->cce, 0, HEAAC_MAX_CCE * sizeof(HeaacCceFrame));
     int elem, r;
     while ((elem = (int)bits(&b, 3)) != TYPE_END) {
         int elem_id = (int)bits(&b, 4);
         switch (elem) {
         case TYPE_SCE:
-        case TYPE_LFE:
             if (fi.channels) return HEAAC_PARSE_ERR_UNSUPPORTED;
             if ((r = read_ics(cfg, &b, 0, &tools->ch[0], &w[0], coeffs)) < 0) return r;
             fi.channels = 1;
+            fi.elem_id = elem_id;
             break;
         case TYPE_CPE: {
             if (fi.channels) return HEAAC_PARSE_ERR_UNSUPPORTED;
+            if (coeff_channels < 2) return HEAAC_PARSE_ERR_ARG;
             /* decode_cpe (:1453-1492) without the spectral tools (GPU stages) */
             const int common = (int)bit1(&b);
             tools->common_window = (uint8_t)common;
@@ -538,8 +672,38 @@ int heaac_aac_parse_frame(const HeaacAacConfig *cfg, HeaacAacStream *st,
             if ((r = read_ics(cfg, &b, common, &tools->ch[0], &w[0], coeffs)) < 0) return r;
             if ((r = read_ics(cfg, &b, common, &tools->ch[1], &w[1], coeffs + 1024)) < 0) return r;
             fi.channels = 2;
+            fi.elem_id = elem_id;
             break;
         }
+        case TYPE_CCE: {
+            if (!cce || n_cce >= HEAAC_MAX_CCE) return HEAAC_PARSE_ERR_UNSUPPORTED;
+            for (int k = 0; k < n_cce; k++)
+                if (cce_tag[k] == elem_id) return HEAAC_PARSE_ERR_DATA;           /* the same element twice */
+            /* slots in ascending tag order: a smaller tag arriving later moves the earlier element up */
+            int slot = n_cce;
+            while (slot > 0 && cce_tag[slot - 1] > elem_id) {
+                cce->cce[slot] = cce->cce[slot - 1];
+                cce->tools[slot] = cce->tools[slot - 1];
+                memcpy(cce->coeffs + slot * 1024, cce->coeffs + (slot - 1) * 1024, 4096);
+                wc[slot] = wc[slot - 1];
+                cce_tag[slot] = cce_tag[slot - 1];
+                slot--;
+            }
+            cce_tag[slot] = elem_id;
+            n_cce++;
+            /* the coupling channel's window history: by slot (a stream keeps its elements' tags) */
+            wc[slot].window_sequence[0] = st->cce_window_sequence[slot];
+            wc[slot].use_kb_window[0] = st->cce_use_kb_window[slot];
+            wc[slot].window_sequence[1] = wc[slot].use_kb_window[1] = 0;
+            memset(&cce->tools[slot], 0, sizeof(HeaacToolsFrame));
+            r = read_cce(cfg, &b, elem_id, target_type, 0, fi.channels != 0, &cce->cce[slot], &cce->tools[slot].ch[0],
+                         &wc[slot], cce->coeffs + slot * 1024);
+            if (r < 0) return r;
+            cce->cce[slot].seq = (uint8_t)(n_cce - 1);
+            break;
+        }
+        case TYPE_LFE:
+            return HEAAC_PARSE_ERR_UNSUPPORTED;        /* no LFE in a one- or two-channel layout */
         case TYPE_DSE: {
             /* skip_data_stream_element (:602-620) */
             const int align = (int)bit1(&b);
@@ -550,6 +714,9 @@ int heaac_aac_parse_frame(const HeaacAacConfig *cfg, HeaacAacStream *st,
             b.pos += 8 * count;
             break;
         }
+        case TYPE_PCE:
+            if ((r = skip_pce(&b)) < 0) return r;
+            break;
         case TYPE_FIL: {
             if (elem_id == 15) elem_id += (int)bits(&b, 8) - 1;
             if (bits_left(&b) < 8 * elem_id) return HEAAC_PARSE_ERR_OVERREAD;
@@ -566,8 +733,6 @@ int heaac_aac_parse_frame(const HeaacAacConfig *cfg, HeaacAacStream *st,
             }
             break;
         }
-        case TYPE_CCE:
-        case TYPE_PCE:
         default:
             return HEAAC_PARSE_ERR_UNSUPPORTED;
         }
@@ -575,6 +740,11 @@ int heaac_aac_parse_frame(const HeaacAacConfig *cfg, HeaacAacStream *st,
         if (bits_left(&b) < 3) return HEAAC_PARSE_ERR_OVERREAD;
     }
     if (!fi.channels) return HEAAC_PARSE_ERR_DATA;
+    if (fi.elem_id != 0 && n_cce) {
+        /* the links were resolved against tag 0 (the default layout's): an output element with another tag is only
+         * reachable through a program config element */
+        return HEAAC_PARSE_ERR_UNSUPPORTED;
+    }
     for (int c = 0; c < fi.channels; c++) {
         ics[c].window_sequence[0] = w[c].window_sequence[0];
         ics[c].window_sequence[1] = w[c].window_sequence[1];
@@ -583,6 +753,15 @@ int heaac_aac_parse_frame(const HeaacAacConfig *cfg, HeaacAacStream *st,
         st->window_sequence[c] = w[c].window_sequence[0];
         st->use_kb_window[c] = w[c].use_kb_window[0];
     }
+    for (int k = 0; k < n_cce; k++) {
+        cce->ics[k].window_sequence[0] = wc[k].window_sequence[0];
+        cce->ics[k].window_sequence[1] = wc[k].window_sequence[1];
+        cce->ics[k].use_kb_window[0] = wc[k].use_kb_window[0];
+        cce->ics[k].use_kb_window[1] = wc[k].use_kb_window[1];
+        st->cce_window_sequence[k] = wc[k].window_sequence[0];
+        st->cce_use_kb_window[k] = wc[k].use_kb_window[0];
+    }
+    fi.n_cce = n_cce;
     fi.bits_consumed = b.pos;
     if (info) *info = fi;
     return HEAAC_PARSE_OK;

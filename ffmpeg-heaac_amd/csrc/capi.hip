@@ -225,14 +225,27 @@ extern "C" int heaac_spectral_tools_batch(HeaacDevice *dev, int channels, float 
                                           const HeaacPredictorState *d_pred_in, HeaacPredictorState *d_pred_out,
                                           size_t n, void *stream)
 {
-    if (!dev || channels < 1 || channels > 2 || (d_rng_in && !d_rng_out) || (d_pred_in && !d_pred_out))
+    return heaac_spectral_tools_batch_ex(dev, channels, HEAAC_TOOLS_ALL, d_coeffs, d_tools, d_rng_in, d_rng_out,
+                                         d_pred_in, d_pred_out, NULL, NULL, 0, n, stream);
+}
+
+extern "C" int heaac_spectral_tools_batch_ex(HeaacDevice *dev, int channels, int stages, float *d_coeffs,
+                                             const HeaacToolsFrame *d_tools,
+                                             const int32_t *d_rng_in, int32_t *d_rng_out,
+                                             const HeaacPredictorState *d_pred_in, HeaacPredictorState *d_pred_out,
+                                             const HeaacCceFrame *d_cce, const float *d_cce_coeffs, int n_cce,
+                                             size_t n, void *stream)
+{
+    if (!dev || channels < 1 || channels > 2 || (d_rng_in && !d_rng_out) || (d_pred_in && !d_pred_out) ||
+        !stages || (stages & ~HEAAC_TOOLS_ALL) || n_cce < 0 || n_cce > HEAAC_MAX_CCE ||
+        (n_cce && (!d_cce || !d_cce_coeffs)))
         return HEAAC_ERR_ARG;
     if (n == 0)
         return HEAAC_OK;
     if (!d_coeffs || !d_tools)
         return HEAAC_ERR_ARG;
-    return heaac_launch_spectral_tools(channels, d_coeffs, d_tools, d_rng_in, d_rng_out, d_pred_in, d_pred_out, n,
-                                       (hipStream_t)stream);
+    return heaac_launch_spectral_tools(channels, d_coeffs, d_tools, d_rng_in, d_rng_out, d_pred_in, d_pred_out,
+                                       stages, d_cce, d_cce_coeffs, n_cce, n, (hipStream_t)stream);
 }
 
 extern "C" int heaac_he_decode_batch_ex(HeaacDevice *dev, int cfg, int flags,

@@ -207,11 +207,52 @@ __device__ __forceinline__ void tools_tns_window(ToolsWave &w, int ch, int win, 
     }
 }
 
+// apply_channel_coupling (aacdec.c:1870-1898) with apply_dependent_coupling (:1813-1843) at one coupling point:
+// every coupling element of the access unit (slots in ascending tag order) adds gain * its spectrum into the
+// target channels its links name.  The band walk is wave-uniform, the lanes spread over a band's lines.
+template <int CH>
+__device__ __forceinline__ void tools_dependent_coupling(ToolsWave &w, const HeaacCceFrame *cce, const float *cce_coeffs,
+                                                         int n_cce, int point, int lane)
+{
+    for (int e = 0; e < n_cce; e++) {
+        const HeaacCceFrame &c = cce[e];
+        if (!c.present || c.coupling_point != point) continue;
+        const float *src0 = cce_coeffs + e * 1024;
+        const int n_links = c.n_links < HEAAC_MAX_CCE_LINKS ? c.n_links : HEAAC_MAX_CCE_LINKS;
+        for (int l = 0; l < n_links; l++) {
+            const HeaacCceLink &k = c.link[l];
+            if (k.target_ch >= CH) continue;
+            float *dest = w.coef[k.target_ch];
+            const float *src = src0;
+            int idx = 0;
+            for (int g = 0; g < c.ics.num_window_groups && g < 8; g++) {
+                const int glen = c.ics.group_len[g];
+                for (int i = 0; i < c.ics.max_sfb && idx < 120; i++, idx++) {
+                    if (c.band_type[idx] == 0) continue;                       // ZERO_BT
+                    const float gain = k.gain[idx];
+                    const int o = c.ics.swb_offset[i], len = c.ics.swb_offset[i + 1] - o;
+                    for (int t = lane; t < glen * len; t += WAVE) {
+                        const int group = t / len, kk = o + t - group * len;
+                        const int p = group * 128 + kk;
+                        if (dest + p - w.coef[k.target_ch] < 1024 && src + p - src0 < 1024)
+                            dest[p] += gain * src[p];
+                    }
+                }
+                dest += glen * 128;
+                src += glen * 128;
+            }
+            wave_sync();
+        }
+    }
+}
+
 template <int CH>
 __global__ __launch_bounds__(TL_WAVES * WAVE)
 void k_spectral_tools(float *g_coeffs, const HeaacToolsFrame *__restrict__ g_tools,
                       const int *g_rng_in, int *g_rng_out,
-                      const HeaacPredictorState *g_pred_in, HeaacPredictorState *g_pred_out, unsigned long long n)
+                      const HeaacPredictorState *g_pred_in, HeaacPredictorState *g_pred_out,
+                      int stages, const HeaacCceFrame *__restrict__ g_cce, const float *__restrict__ g_cce_coeffs,
+                      int n_cce, unsigned long long n)
 {
     __shared__ ToolsWave S[TL_WAVES];
     __shared__ LcgSkip K;
@@ -239,20 +280,21 @@ void k_spectral_tools(float *g_coeffs, const HeaacToolsFrame *__restrict__ g_too
             for (int i = lane; i < (int)(sizeof(HeaacToolsFrame) / 4); i += WAVE) d[i] = s[i];
         }
         wave_sync();
-        if (g_rng_in) {
+        const bool pre = stages & HEAAC_TOOLS_PRE, post = stages & HEAAC_TOOLS_POST;
+        if (pre && g_rng_in) {
             unsigned rs = (unsigned)g_rng_in[f];
 #pragma unroll
             for (int c = 0; c < CH; c++) rs = tools_pns(w, K, c, rs, lane);
             if (lane == 0) g_rng_out[f] = (int)rs;
         }
         const bool common = CH == 2 && w.t.common_window;
-        if (g_pred_in && !common) {             // decode_ics, aacdec.c:1381-1382
+        if (pre && g_pred_in && !common) {      // decode_ics, aacdec.c:1381-1382
 #pragma unroll
             for (int c = 0; c < CH; c++)
                 tools_prediction(w, c, g_pred_in + (f * CH + c) * HEAAC_MAX_PREDICTORS,
                                  g_pred_out + (f * CH + c) * HEAAC_MAX_PREDICTORS, lane);
         }
-        if (CH == 2) {
+        if (CH == 2 && pre) {
             if (w.t.common_window && w.t.ms_present) { tools_mid_side(w, lane); wave_sync(); }
             if (g_pred_in && common) {          // decode_cpe, aacdec.c:1486-1489
                 for (int c = 0; c < 2; c++)
@@ -262,11 +304,18 @@ void k_spectral_tools(float *g_coeffs, const HeaacToolsFrame *__restrict__ g_too
             tools_intensity(w, lane);
             wave_sync();
         }
-        {
+        if (post) {
+            if (n_cce)
+                tools_dependent_coupling<CH>(w, g_cce + f * n_cce, g_cce_coeffs + f * n_cce * 1024, n_cce,
+                                             HEAAC_CC_BEFORE_TNS, lane);
             // lane -> (channel, window)
             const int ch = lane >> 3, win = lane & 7;
             if (ch < CH && w.t.ch[ch].tns.present && win < w.t.ch[ch].ics.num_windows)
                 tools_tns_window(w, ch, win, w.lpc[lane]);
+            wave_sync();
+            if (n_cce)
+                tools_dependent_coupling<CH>(w, g_cce + f * n_cce, g_cce_coeffs + f * n_cce * 1024, n_cce,
+                                             HEAAC_CC_BETWEEN_TNS_AND_IMDCT, lane);
         }
         wave_sync();
         {
@@ -282,6 +331,7 @@ void k_spectral_tools(float *g_coeffs, const HeaacToolsFrame *__restrict__ g_too
 extern "C" int heaac_launch_spectral_tools(int channels, float *d_coeffs, const HeaacToolsFrame *d_tools,
                                            const int *d_rng_in, int *d_rng_out,
                                            const HeaacPredictorState *d_pred_in, HeaacPredictorState *d_pred_out,
+                                           int stages, const HeaacCceFrame *d_cce, const float *d_cce_coeffs, int n_cce,
                                            size_t n, hipStream_t s)
 {
     if (n == 0) return HEAAC_OK;
@@ -289,10 +339,12 @@ extern "C" int heaac_launch_spectral_tools(int channels, float *d_coeffs, const 
     if (g > 256) g = 256;
     if (channels == 2)
         hipLaunchKernelGGL(k_spectral_tools<2>, dim3((unsigned)g), dim3(TL_WAVES * WAVE), 0, s, d_coeffs, d_tools,
-                           d_rng_in, d_rng_out, d_pred_in, d_pred_out, (unsigned long long)n);
+                           d_rng_in, d_rng_out, d_pred_in, d_pred_out, stages, d_cce, d_cce_coeffs, n_cce,
+                           (unsigned long long)n);
     else if (channels == 1)
         hipLaunchKernelGGL(k_spectral_tools<1>, dim3((unsigned)g), dim3(TL_WAVES * WAVE), 0, s, d_coeffs, d_tools,
-                           d_rng_in, d_rng_out, d_pred_in, d_pred_out, (unsigned long long)n);
+                           d_rng_in, d_rng_out, d_pred_in, d_pred_out, stages, d_cce, d_cce_coeffs, n_cce,
+                           (unsigned long long)n);
     else
         return HEAAC_ERR_ARG;
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;

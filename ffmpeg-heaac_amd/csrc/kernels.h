@@ -54,6 +54,7 @@ extern "C" {
 int heaac_launch_spectral_tools(int channels, float *d_coeffs, const HeaacToolsFrame *d_tools,
                                 const int *d_rng_in, int *d_rng_out,
                                 const HeaacPredictorState *d_pred_in, HeaacPredictorState *d_pred_out,
+                                int stages, const HeaacCceFrame *d_cce, const float *d_cce_coeffs, int n_cce,
                                 size_t n, hipStream_t s);
 int heaac_launch_fft_calc(const float *d_tab, int nbits, float *d_z, size_t n, hipStream_t s);
 int heaac_launch_imdct_mirror(float *d_out, int n, size_t count, hipStream_t s);

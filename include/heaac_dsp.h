@@ -484,6 +484,62 @@ int heaac_spectral_tools_batch(HeaacDevice *dev, int channels, float *d_coeffs,
                                const HeaacPredictorState *d_pred_in, HeaacPredictorState *d_pred_out,
                                size_t n, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Dependent channel coupling: a coupling_channel_element whose spectrum is added into its target
+ * channels BEFORE the IMDCT -- apply_dependent_coupling (aacdec.c:1813-1843) under apply_channel_coupling
+ * (:1870-1898), at the two points spectral_to_sample knows (:1912, :1917): before the target's TNS and between TNS
+ * and IMDCT.  (The third point, AFTER_IMDCT, is heaac_couple_after_imdct_batch above.)
+ * ------------------------------------------------------------------------ */
+enum { HEAAC_CC_BEFORE_TNS = 0, HEAAC_CC_BETWEEN_TNS_AND_IMDCT = 1, HEAAC_CC_AFTER_IMDCT = 3 };   /* aac.h:83-87 */
+#define HEAAC_MAX_CCE 2               /* coupling elements per access unit carried by the batched records */
+#define HEAAC_MAX_CCE_LINKS 4         /* gain lists of one coupling element that land on the (one) target element */
+
+/* One gain list of a coupling element applied to one channel of the target element: coup->gain[index][] with the
+ * list index resolved against the target as apply_channel_coupling resolves it. */
+typedef struct HeaacCceLink {
+    uint8_t target_ch;                /* channel of the target element: 0 or 1 */
+    uint8_t pad[3];
+    float   gain[120];                /* [idx], idx = g * max_sfb + sfb of the COUPLING channel's grouping;
+                                         AFTER_IMDCT: gain[0] only (decode_cce, aacdec.c:1541-1543) */
+} HeaacCceLink;                       /* 484 B */
+
+typedef struct HeaacCceFrame {
+    uint8_t present;                  /* 0: this slot holds no coupling element in this access unit */
+    uint8_t elem_id;                  /* instance tag; slots are filled in ascending tag order, the order in which
+                                         apply_channel_coupling walks ac->che[TYPE_CCE][] */
+    uint8_t coupling_point;           /* HEAAC_CC_* */
+    uint8_t n_links;
+    uint8_t behind_target;            /* 1: the element follows the target element in the access unit (order of the
+                                         noise generator across elements) */
+    uint8_t seq;                      /* position among the access unit's coupling elements in BITSTREAM order (the
+                                         slots are in tag order) */
+    uint8_t pad[2];
+    HeaacToolsIcs ics;                /* the coupling channel's own grouping and band offsets */
+    uint8_t band_type[128];           /* its band types: ZERO_BT (0) bands couple nothing (:1828) */
+    HeaacCceLink link[HEAAC_MAX_CCE_LINKS];
+} HeaacCceFrame;                      /* 2216 B */
+
+/* heaac_spectral_tools_batch in two halves, with dependent coupling in the second:
+ *   HEAAC_TOOLS_PRE   noise substitution, AAC-Main prediction, M/S, intensity stereo -- what the reference does
+ *                     while it parses an element (decode_ics / decode_cpe)
+ *   HEAAC_TOOLS_POST  what spectral_to_sample does to the element before its IMDCT (aacdec.c:1911-1918): coupling
+ *                     at BEFORE_TNS, TNS, coupling at BETWEEN_TNS_AND_IMDCT
+ * d_cce [n][n_cce] / d_cce_coeffs [n][n_cce][1024]: the access unit's coupling elements (slots in ascending tag
+ * order) and their spectra AFTER their own tools (a coupling channel is processed before its targets,
+ * spectral_to_sample walks the types downwards); NULL / 0 for none.  The noise generator runs across the elements
+ * of an access unit in bitstream order, so the caller orders the calls by HeaacCceFrame.behind_target:
+ *   coupling element first:  tools_ex(cce, PRE | POST) -> tools_ex(target, PRE | POST, cce)
+ *   target first:            tools_ex(target, PRE) -> tools_ex(cce, PRE | POST) -> tools_ex(target, POST, cce)
+ * with d_rng chained from call to call (d_rng / d_pred are only touched by PRE).  All frames of one call share the
+ * order. */
+enum { HEAAC_TOOLS_PRE = 1, HEAAC_TOOLS_POST = 2, HEAAC_TOOLS_ALL = 3 };
+int heaac_spectral_tools_batch_ex(HeaacDevice *dev, int channels, int stages, float *d_coeffs,
+                                  const HeaacToolsFrame *d_tools,
+                                  const int32_t *d_rng_in, int32_t *d_rng_out,
+                                  const HeaacPredictorState *d_pred_in, HeaacPredictorState *d_pred_out,
+                                  const HeaacCceFrame *d_cce, const float *d_cce_coeffs, int n_cce,
+                                  size_t n, void *stream);
+
 /* Host-side helper (no GPU): derive the frequency-band tables of one SBR
  * header -- sbr_make_f_master/f_derived/hf_calc_npatches/f_tablelim
  * (aacsbr.c:146-205, 296-593).  sample_rate is the SBR (output) rate.

@@ -114,7 +114,8 @@ long heaac_adts_split(const uint8_t *buf, size_t size, HeaacAdtsPacket *out, siz
 typedef struct HeaacAacStream {
     uint8_t window_sequence[2];   /* of the previous frame, per channel */
     uint8_t use_kb_window[2];
-    uint8_t pad[4];
+    uint8_t cce_window_sequence[2];   /* the same for the coupling channels in slot 0 / 1 (heaac_aac_parse_frame_ex) */
+    uint8_t cce_use_kb_window[2];
 } HeaacAacStream;
 
 typedef struct HeaacAacFrameInfo {
@@ -123,7 +124,21 @@ typedef struct HeaacAacFrameInfo {
     int sbr_payload_bit;          /* bit offset of an EXT_SBR_DATA(_CRC) fill payload after its 4-bit type, -1: none */
     int sbr_payload_bytes;        /* its length in bytes (the `cnt` of decode_extension_payload) */
     int sbr_crc;
+    int elem_id;                  /* instance tag of the output element */
+    int n_cce;                    /* coupling elements found (heaac_aac_parse_frame_ex) */
 } HeaacAacFrameInfo;
+
+/* What heaac_aac_parse_frame_ex adds for access units that carry coupling channel elements: per slot (ascending
+ * instance tag, HEAAC_MAX_CCE slots) the element's coupling record with its gain lists resolved against the target
+ * element (decode_cce aacdec.c:1503-1570 + the index walk of apply_channel_coupling :1870-1898), its own spectrum
+ * and the side info of ITS spectral tools (a coupling channel is an individual channel stream: noise substitution,
+ * prediction and TNS apply to it before it couples, spectral_to_sample :1907-1916). */
+typedef struct HeaacCceOut {
+    HeaacCceFrame *cce;           /* [HEAAC_MAX_CCE] */
+    float *coeffs;                /* [HEAAC_MAX_CCE][1024] */
+    HeaacIcs *ics;                /* [HEAAC_MAX_CCE] window info of the coupling channels (AFTER_IMDCT ones are transformed) */
+    HeaacToolsFrame *tools;       /* [HEAAC_MAX_CCE]: channel 0 = the coupling channel */
+} HeaacCceOut;
 
 /* One access unit (raw_data_block; an ADTS header in front is skipped as aac_decode_frame does).
  *   coeffs [2][1024]  dequantised spectrum per channel (channel 1 untouched for an SCE); NOISE_BT bands
@@ -135,6 +150,19 @@ int heaac_aac_parse_frame(const HeaacAacConfig *cfg, HeaacAacStream *st,
                           const uint8_t *au, int size,
                           float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
                           HeaacAacFrameInfo *info);
+
+/* The same for everything aac_decode_frame accepts with one SCE or one CPE as the output element: data stream and
+ * fill elements anywhere, program config elements (read past: decode_pce :303-357; the channel layout stays the one
+ * of the configuration), and up to HEAAC_MAX_CCE coupling channel elements into `cce` (NULL: an access unit with a
+ * coupling element is HEAAC_PARSE_ERR_UNSUPPORTED, as in heaac_aac_parse_frame).  A second SCE / CPE / LFE, a
+ * third coupling element, or more than HEAAC_MAX_CCE_LINKS gain lists of one element landing on the target are
+ * HEAAC_PARSE_ERR_UNSUPPORTED.
+ * coeff_channels: 1 or 2 -- the channel stride of `coeffs`, `ics`: 2 = [2][1024] / [2] as above, 1 = [1][1024] /
+ * [1] packed for mono streams (a CPE then fails with HEAAC_PARSE_ERR_ARG). */
+int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
+                             const uint8_t *au, int size, int coeff_channels,
+                             float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
+                             const HeaacCceOut *cce, HeaacAacFrameInfo *info);
 
 /* n independent streams, one access unit each, on `threads` host threads (<= 0: one per online CPU).
  *   au[n], size[n]         access units

@@ -224,12 +224,64 @@ static void or_prediction(const HeaacToolsChannel *ch, float *coef, HeaacPredict
     }
 }
 
+/* apply_dependent_coupling (aacdec.c:1813-1843): dest += gain[idx] * src over the coupling channel's
+ * non-zero bands, band offsets and grouping of the COUPLING channel. */
+static void or_dependent_coupling(float *dest, const float *src, const HeaacCceFrame *cce, const float *gain_list)
+{
+    const HeaacToolsIcs *ics = &cce->ics;
+    const uint16_t *offsets = ics->swb_offset;
+    int idx = 0;
+    for (int g = 0; g < ics->num_window_groups; g++) {
+        for (int i = 0; i < ics->max_sfb; i++, idx++) {
+            if (cce->band_type[idx] != 0) {                            /* ZERO_BT */
+                const float gain = gain_list[idx];
+                for (int group = 0; group < ics->group_len[g]; group++)
+                    for (int k = offsets[i]; k < offsets[i + 1]; k++)
+                        dest[group * 128 + k] += gain * src[group * 128 + k];
+            }
+        }
+        dest += ics->group_len[g] * 128;
+        src  += ics->group_len[g] * 128;
+    }
+}
+
+/* apply_channel_coupling (aacdec.c:1870-1898) for one coupling point: the coupling elements in ascending tag order
+ * (the slots' order), each gain list that lands on the target element (resolved by the parser into links) */
+static void or_channel_coupling(int channels, float *c0, float *c1, const HeaacCceFrame *cce, const float *cce_coeffs,
+                                int n_cce, int point)
+{
+    for (int e = 0; e < n_cce; e++) {
+        if (!cce[e].present || cce[e].coupling_point != point) continue;
+        for (int l = 0; l < cce[e].n_links; l++) {
+            const HeaacCceLink *k = &cce[e].link[l];
+            if (k->target_ch >= channels) continue;
+            or_dependent_coupling(k->target_ch ? c1 : c0, cce_coeffs + (size_t)e * 1024, &cce[e], k->gain);
+        }
+    }
+}
+
 /* decode_cpe's tail (aacdec.c:1483-1492) + spectral_to_sample's TNS calls (:1913-1916);
  * rng_in != NULL: noise substitution first, channel 0 then channel 1 (decode_ics order) */
 void oracle_spectral_tools_batch(int channels, float *coeffs, const HeaacToolsFrame *tools,
                                  const int32_t *rng_in, int32_t *rng_out,
                                  const HeaacPredictorState *pred_in, HeaacPredictorState *pred_out, size_t n)
 {
+    oracle_spectral_tools_batch_ex(channels, HEAAC_TOOLS_ALL, coeffs, tools, rng_in, rng_out, pred_in, pred_out,
+                                   NULL, NULL, 0, n);
+}
+
+/* The same in the two halves the reference runs at different times: PRE = what decode_ics / decode_cpe do while an
+ * element is parsed (noise substitution, prediction, M/S, intensity), POST = what spectral_to_sample does to the
+ * element before its IMDCT (aacdec.c:1911-1918): dependent coupling at BEFORE_TNS, TNS, dependent coupling at
+ * BETWEEN_TNS_AND_IMDCT.  cce [n][n_cce], cce_coeffs [n][n_cce][1024]: the access unit's coupling elements after
+ * their own tools. */
+void oracle_spectral_tools_batch_ex(int channels, int stages, float *coeffs, const HeaacToolsFrame *tools,
+                                    const int32_t *rng_in, int32_t *rng_out,
+                                    const HeaacPredictorState *pred_in, HeaacPredictorState *pred_out,
+                                    const HeaacCceFrame *cce, const float *cce_coeffs, int n_cce, size_t n)
+{
+    const int pre = stages & HEAAC_TOOLS_PRE, post = stages & HEAAC_TOOLS_POST;
+    if (!pre) { rng_in = NULL; pred_in = NULL; }
     if (pred_in && pred_out != pred_in)
         memcpy(pred_out, pred_in, n * (size_t)channels * HEAAC_MAX_PREDICTORS * sizeof(*pred_in));
     for (size_t f = 0; f < n; f++) {
@@ -248,7 +300,7 @@ void oracle_spectral_tools_batch(int channels, float *coeffs, const HeaacToolsFr
             or_prediction(&t->ch[0], c0, p0);
             if (channels == 2) or_prediction(&t->ch[1], c1, p1);
         }
-        if (channels == 2) {
+        if (channels == 2 && pre) {
             if (t->common_window && t->ms_present)
                 or_mid_side(t, c0, c1);
             if (p0 && common) {                    /* decode_cpe, aacdec.c:1486-1489 */
@@ -257,9 +309,16 @@ void oracle_spectral_tools_batch(int channels, float *coeffs, const HeaacToolsFr
             }
             or_intensity(t, c0, c1);
         }
+        if (!post) continue;
+        if (n_cce)
+            or_channel_coupling(channels, c0, c1, cce + f * (size_t)n_cce, cce_coeffs + f * (size_t)n_cce * 1024, n_cce,
+                                HEAAC_CC_BEFORE_TNS);
         if (t->ch[0].tns.present)
             or_tns(c0, &t->ch[0].tns, &t->ch[0].ics);
         if (channels == 2 && t->ch[1].tns.present)
             or_tns(c1, &t->ch[1].tns, &t->ch[1].ics);
+        if (n_cce)
+            or_channel_coupling(channels, c0, c1, cce + f * (size_t)n_cce, cce_coeffs + f * (size_t)n_cce * 1024, n_cce,
+                                HEAAC_CC_BETWEEN_TNS_AND_IMDCT);
     }
 }

@@ -97,6 +97,11 @@ void oracle_spectral_tools_batch(int channels, float *coeffs, const HeaacToolsFr
                                  const int32_t *rng_in, int32_t *rng_out,
                                  const HeaacPredictorState *pred_in, HeaacPredictorState *pred_out, size_t n);
 
+void oracle_spectral_tools_batch_ex(int channels, int stages, float *coeffs, const HeaacToolsFrame *tools,
+                                    const int32_t *rng_in, int32_t *rng_out,
+                                    const HeaacPredictorState *pred_in, HeaacPredictorState *pred_out,
+                                    const HeaacCceFrame *cce, const float *cce_coeffs, int n_cce, size_t n);
+
 int oracle_couple_after_imdct_batch(int channels, float *pcm, const float *cce, const HeaacCoupling *cpl,
                                     int16_t *s16, size_t n);                /* aacdec.c:1849-1862 */
 

@@ -221,6 +221,30 @@ def spectral_tools_batch(channels, coeffs, tools, rng=None, pred=None):
     return res[0] if len(res) == 1 else res
 
 
+TOOLS_PRE, TOOLS_POST, TOOLS_ALL = 1, 2, 3
+
+
+def spectral_tools_batch_ex(channels, stages, coeffs, tools, rng=None, pred=None, cce=None, cce_coeffs=None):
+    """The staged form (PRE / POST halves, dependent coupling in POST): returns (coeffs, rng_out, pred_out), the
+    last two None when not given."""
+    out = np.ascontiguousarray(coeffs, np.float32).copy()
+    tools = np.ascontiguousarray(tools)
+    rin = rout = pin = pout = None
+    if rng is not None:
+        rin = np.ascontiguousarray(rng, np.int32); rout = rin.copy()
+    if pred is not None:
+        pin = np.ascontiguousarray(pred, np.float32); pout = pin.copy()
+    n_cce = 0
+    if cce is not None:
+        cce = np.ascontiguousarray(cce); cce_coeffs = np.ascontiguousarray(cce_coeffs, np.float32)
+        n_cce = cce.shape[1]
+        assert cce_coeffs.shape == (out.shape[0], n_cce, 1024)
+    lib().oracle_spectral_tools_batch_ex(C.c_int(channels), C.c_int(stages), _p(out), _p(tools), _p(rin), _p(rout),
+                                         _p(pin), _p(pout), _p(cce) if n_cce else None,
+                                         _p(cce_coeffs) if n_cce else None, C.c_int(n_cce), C.c_size_t(out.shape[0]))
+    return out, rout, pout
+
+
 def he_decode_batch(cfg, coeffs, ics, sbr, hdr, ps, state_in, pcm_format=PCM_F32, downsampled=False):
     coeffs = _f32(coeffs)
     n = coeffs.shape[0]
