@@ -124,6 +124,8 @@ EXPORTED = [
     "heaac_aac_decoder", "heaac_codec_open", "heaac_codec_decode", "heaac_codec_close",
     # heaac_parse.h
     "heaac_asc_parse", "heaac_ga_specific_config", "heaac_aac_parse_frame_ex", "heaac_spectral_tools_batch_ex", "heaac_codec_get_context_defaults", "heaac_adts_parse_header", "heaac_adts_probe", "heaac_adts_split",
+    "heaac_heaac_parse_frame_ex", "heaac_pipeline_create", "heaac_pipeline_destroy", "heaac_pipeline_submit",
+    "heaac_pipeline_collect", "heaac_pipeline_timing",
     "heaac_multi_shard", "heaac_multi_create", "heaac_multi_destroy", "heaac_multi_devices", "heaac_multi_device",
     "heaac_multi_stream", "heaac_multi_he_decode", "heaac_aac_parse_frame", "heaac_aac_parse_batch",
     "heaac_aac_tables_fingerprint",
@@ -480,6 +482,45 @@ def adts_split(buf):
     m = L.heaac_adts_split(buf, C.c_size_t(len(buf)), out.ctypes.data_as(C.c_void_p), C.c_size_t(n), C.byref(h))
     assert m == n
     return out, (h if (out["kind"] != ADTS_JUNK).any() and ((out["kind"] == ADTS_FRAME) | (out["kind"] == ADTS_TRUNCATED)).any() else None)
+
+
+class Pipeline:
+    """include/heaac_pipeline.h: access units in host memory -> int16 PCM in host memory, ticks overlapped."""
+
+    def __init__(self, aac_cfg, he_cfg, n_streams, threads=0):
+        self._h = C.c_void_p()
+        self.n, self.ch = n_streams, OUT_CH[he_cfg]
+        _check(lib().heaac_pipeline_create(C.byref(self._h), C.byref(aac_cfg), he_cfg, C.c_size_t(n_streams), threads),
+               "heaac_pipeline_create")
+
+    def submit(self, aus):
+        """aus: n_streams access units (bytes).  Returns the parse status per stream."""
+        assert len(aus) == self.n
+        keep = [C.create_string_buffer(bytes(a), len(a)) for a in aus]
+        ptrs = (C.c_char_p * self.n)(*[C.cast(k, C.c_char_p) for k in keep])
+        sizes = (C.c_int * self.n)(*[len(a) for a in aus])
+        status = np.zeros(self.n, np.int32)
+        _check(lib().heaac_pipeline_submit(self._h, ptrs, sizes, status.ctypes.data_as(C.c_void_p)), "heaac_pipeline_submit")
+        return status
+
+    def submit_raw(self, ptrs, sizes):
+        _check(lib().heaac_pipeline_submit(self._h, ptrs, sizes, None), "heaac_pipeline_submit")
+
+    def collect(self):
+        """PCM of the oldest tick in flight: int16 [n][2048][channels] (a view of the pipeline's pinned buffer)."""
+        p = C.POINTER(C.c_int16)()
+        _check(lib().heaac_pipeline_collect(self._h, C.byref(p)), "heaac_pipeline_collect")
+        return np.ctypeslib.as_array(p, shape=(self.n, 2048, self.ch))
+
+    def timing(self):
+        ms = (C.c_float * 4)()
+        lib().heaac_pipeline_timing(self._h, ms)
+        return dict(parse=ms[0], h2d=ms[1], gpu=ms[2], d2h=ms[3])
+
+    def close(self):
+        if self._h:
+            lib().heaac_pipeline_destroy(self._h)
+            self._h = C.c_void_p()
 
 
 class _CceOut(C.Structure):

@@ -1,0 +1,296 @@
+// pipeline.hip -- include/heaac_pipeline.h: access units in host memory -> int16 PCM in host memory, the four
+// stages of consecutive ticks overlapped (host parse || H2D || GPU || D2H).
+//
+//   host parse   persistent pool: worker w owns the streams [n w / W, n (w + 1) / W) (their parser state too)
+//   H2D          stream `in`:  parsed records of buffer set (t & 1), pinned -> device
+//   GPU          stream `run`: heaac_spectral_tools_batch + heaac_he_decode_batch, DSP state in place
+//   D2H          stream `out`: int16 PCM of buffer set (t & 1), device -> pinned
+// Event order per set s = t & 1:  in waits run_done[s] of tick t - 2 (its inputs are free again); run waits
+// in_done[s] and out_done[s] of tick t - 2 (its PCM buffer is free); out waits run_done[s].
+#include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+#include "heaac_pipeline.h"
+
+#define PL_MAX_HDRS 4096
+
+struct Set {
+    // pinned host
+    float *h_coeffs; HeaacIcs *h_ics; HeaacToolsFrame *h_tools; HeaacSbrFrame *h_sbr; HeaacPsFrame *h_ps; int16_t *h_pcm;
+    // device
+    float *d_coeffs; HeaacIcs *d_ics; HeaacToolsFrame *d_tools; HeaacSbrFrame *d_sbr; HeaacPsFrame *d_ps; int16_t *d_pcm;
+    hipEvent_t in_start, in_done, run_done, out_done;
+    int used;                       // a tick has gone through this set
+    float parse_ms;
+};
+
+struct HeaacPipeline {
+    HeaacAacConfig aac;
+    int he_cfg, ncore, nout;
+    size_t n, words;
+    HeaacDevice *dev;
+    hipStream_t in, run, out;
+    Set set[2];
+    float *d_state; int32_t *d_rng;
+    HeaacSbrHeader *d_hdr; size_t hdr_uploaded;
+    HeaacSbrHeaderTable *tab;
+    HeaacAacStream *ast; HeaacSbrStream *sst;
+    unsigned long submitted, collected;
+    float last_ms[4];
+    // pool
+    int threads;
+    pthread_t *tid;
+    pthread_mutex_t mu;
+    pthread_cond_t cv_go, cv_done;
+    unsigned long generation;
+    int pending, quit;
+    const uint8_t *const *job_au; const int *job_size; int *job_status; Set *job_set;
+};
+
+struct WorkerArg { HeaacPipeline *p; int w; };
+
+static void parse_slice(HeaacPipeline *p, int w)
+{
+    const size_t lo = p->n * (size_t)w / (size_t)p->threads, hi = p->n * (size_t)(w + 1) / (size_t)p->threads;
+    Set *s = p->job_set;
+    for (size_t i = lo; i < hi; i++) {
+        const int r = heaac_heaac_parse_frame_ex(&p->aac, &p->ast[i], &p->sst[i], p->tab, p->job_au[i], p->job_size[i],
+                                                 p->ncore, s->h_coeffs + i * (size_t)p->ncore * 1024, s->h_ics + i * p->ncore,
+                                                 &s->h_tools[i], &s->h_sbr[i], s->h_ps ? &s->h_ps[i] : NULL, NULL);
+        if (p->job_status) p->job_status[i] = r;
+    }
+}
+
+static void *worker(void *arg)
+{
+    WorkerArg *a = (WorkerArg *)arg;
+    HeaacPipeline *p = a->p;
+    const int w = a->w;
+    free(a);
+    unsigned long seen = 0;
+    pthread_mutex_lock(&p->mu);
+    for (;;) {
+        while (p->generation == seen && !p->quit) pthread_cond_wait(&p->cv_go, &p->mu);
+        if (p->quit) break;
+        seen = p->generation;
+        pthread_mutex_unlock(&p->mu);
+        parse_slice(p, w);
+        pthread_mutex_lock(&p->mu);
+        if (--p->pending == 0) pthread_cond_signal(&p->cv_done);
+    }
+    pthread_mutex_unlock(&p->mu);
+    return NULL;
+}
+
+static int pinned(void **p, size_t bytes) { return hipHostMalloc(p, bytes, hipHostMallocDefault) == hipSuccess; }
+static int devmem(void **p, size_t bytes) { return hipMalloc(p, bytes) == hipSuccess; }
+
+extern "C" void heaac_pipeline_destroy(HeaacPipeline *p)
+{
+    if (!p) return;
+    if (p->tid) {
+        pthread_mutex_lock(&p->mu);
+        p->quit = 1;
+        pthread_cond_broadcast(&p->cv_go);
+        pthread_mutex_unlock(&p->mu);
+        for (int t = 1; t < p->threads; t++) if (p->tid[t]) pthread_join(p->tid[t], NULL);
+        free(p->tid);
+        pthread_cond_destroy(&p->cv_go); pthread_cond_destroy(&p->cv_done); pthread_mutex_destroy(&p->mu);
+    }
+    if (p->in) (void)hipStreamSynchronize(p->in);
+    if (p->run) (void)hipStreamSynchronize(p->run);
+    if (p->out) (void)hipStreamSynchronize(p->out);
+    for (int k = 0; k < 2; k++) {
+        Set *s = &p->set[k];
+        void *h[] = { s->h_coeffs, s->h_ics, s->h_tools, s->h_sbr, s->h_ps, s->h_pcm };
+        void *d[] = { s->d_coeffs, s->d_ics, s->d_tools, s->d_sbr, s->d_ps, s->d_pcm };
+        for (void *x : h) if (x) (void)hipHostFree(x);
+        for (void *x : d) if (x) (void)hipFree(x);
+        hipEvent_t ev[] = { s->in_start, s->in_done, s->run_done, s->out_done };
+        for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    }
+    if (p->d_state) (void)hipFree(p->d_state);
+    if (p->d_rng) (void)hipFree(p->d_rng);
+    if (p->d_hdr) (void)hipFree(p->d_hdr);
+    if (p->in) (void)hipStreamDestroy(p->in);
+    if (p->run) (void)hipStreamDestroy(p->run);
+    if (p->out) (void)hipStreamDestroy(p->out);
+    heaac_sbr_table_destroy(p->tab);
+    free(p->ast); free(p->sst);
+    heaac_device_destroy(p->dev);
+    free(p);
+}
+
+extern "C" int heaac_pipeline_create(HeaacPipeline **out, const HeaacAacConfig *aac, int he_cfg, size_t n, int threads)
+{
+    if (!out) return HEAAC_ERR_ARG;
+    *out = NULL;
+    if (!aac || !n || (he_cfg != HEAAC_CFG_HEV2 && he_cfg != HEAAC_CFG_HEV1 && he_cfg != HEAAC_CFG_HEV1_MONO) ||
+        aac->sampling_index < 0 || aac->sampling_index > 12)
+        return HEAAC_ERR_ARG;
+    HeaacPipeline *p = (HeaacPipeline *)calloc(1, sizeof(*p));
+    if (!p) return HEAAC_ERR_NOMEM;
+    p->aac = *aac;
+    p->he_cfg = he_cfg;
+    p->ncore = he_cfg == HEAAC_CFG_HEV1 ? 2 : 1;
+    p->nout = he_cfg == HEAAC_CFG_HEV1_MONO ? 1 : 2;
+    p->words = he_cfg == HEAAC_CFG_HEV1 ? HEAAC_STATE_WORDS_HEV1 : he_cfg == HEAAC_CFG_HEV2 ? HEAAC_STATE_WORDS_HEV2
+                                                                                           : HEAAC_STATE_WORDS_HEV1_MONO;
+    p->n = n;
+    int rc = heaac_device_create(&p->dev, n);
+    if (rc != HEAAC_OK) { free(p); return rc; }
+    bool ok = hipStreamCreateWithFlags(&p->in, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&p->run, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&p->out, hipStreamNonBlocking) == hipSuccess;
+    const int with_ps = he_cfg == HEAAC_CFG_HEV2;
+    for (int k = 0; k < 2 && ok; k++) {
+        Set *s = &p->set[k];
+        const size_t nc = n * (size_t)p->ncore;
+        ok = pinned((void **)&s->h_coeffs, nc * 4096) && pinned((void **)&s->h_ics, nc * sizeof(HeaacIcs)) &&
+             pinned((void **)&s->h_tools, n * sizeof(HeaacToolsFrame)) && pinned((void **)&s->h_sbr, n * sizeof(HeaacSbrFrame)) &&
+             (!with_ps || pinned((void **)&s->h_ps, n * sizeof(HeaacPsFrame))) &&
+             pinned((void **)&s->h_pcm, n * (size_t)p->nout * 2048 * 2) &&
+             devmem((void **)&s->d_coeffs, nc * 4096) && devmem((void **)&s->d_ics, nc * sizeof(HeaacIcs)) &&
+             devmem((void **)&s->d_tools, n * sizeof(HeaacToolsFrame)) && devmem((void **)&s->d_sbr, n * sizeof(HeaacSbrFrame)) &&
+             (!with_ps || devmem((void **)&s->d_ps, n * sizeof(HeaacPsFrame))) &&
+             devmem((void **)&s->d_pcm, n * (size_t)p->nout * 2048 * 2) &&
+             hipEventCreate(&s->in_start) == hipSuccess && hipEventCreate(&s->in_done) == hipSuccess &&
+             hipEventCreate(&s->run_done) == hipSuccess && hipEventCreate(&s->out_done) == hipSuccess;
+        if (ok) {
+            memset(s->h_coeffs, 0, nc * 4096); memset(s->h_ics, 0, nc * sizeof(HeaacIcs));
+            memset(s->h_tools, 0, n * sizeof(HeaacToolsFrame)); memset(s->h_sbr, 0, n * sizeof(HeaacSbrFrame));
+            if (with_ps) memset(s->h_ps, 0, n * sizeof(HeaacPsFrame));
+        }
+    }
+    ok = ok && devmem((void **)&p->d_state, n * p->words * 4) && devmem((void **)&p->d_rng, n * 4) &&
+         devmem((void **)&p->d_hdr, PL_MAX_HDRS * sizeof(HeaacSbrHeader)) &&
+         hipMemset(p->d_state, 0, n * p->words * 4) == hipSuccess;
+    if (ok) {
+        int32_t *seed = (int32_t *)malloc(n * 4);
+        ok = seed != NULL;
+        if (ok) {
+            for (size_t i = 0; i < n; i++) seed[i] = 0x1f2e3d4c;       // ac->random_state, aacdec.c:558
+            ok = hipMemcpy(p->d_rng, seed, n * 4, hipMemcpyHostToDevice) == hipSuccess;
+            free(seed);
+        }
+    }
+    p->tab = heaac_sbr_table_create(PL_MAX_HDRS);
+    p->ast = (HeaacAacStream *)calloc(n, sizeof(HeaacAacStream));
+    p->sst = (HeaacSbrStream *)malloc(n * heaac_sbr_stream_bytes());
+    ok = ok && p->tab && p->ast && p->sst;
+    if (ok) {
+        heaac_sbr_stream_init(p->sst, n);
+        // the null header (table entry 0) is what frames before their stream's first header point at
+        ok = hipMemcpy(p->d_hdr, heaac_sbr_table_data(p->tab), sizeof(HeaacSbrHeader), hipMemcpyHostToDevice) == hipSuccess;
+        p->hdr_uploaded = 1;
+    }
+    if (ok) {
+        if (threads <= 0) threads = (int)sysconf(_SC_NPROCESSORS_ONLN);
+        if (threads < 1) threads = 1;
+        if (threads > 256) threads = 256;
+        if ((size_t)threads > n) threads = (int)n;
+        p->threads = threads;
+        pthread_mutex_init(&p->mu, NULL);
+        pthread_cond_init(&p->cv_go, NULL);
+        pthread_cond_init(&p->cv_done, NULL);
+        p->tid = (pthread_t *)calloc(threads, sizeof(pthread_t));
+        ok = p->tid != NULL;
+        for (int t = 1; t < threads && ok; t++) {          // slice 0 is parsed by the submitting thread
+            WorkerArg *a = (WorkerArg *)malloc(sizeof(*a));
+            if (!a) { ok = false; break; }
+            a->p = p; a->w = t;
+            if (pthread_create(&p->tid[t], NULL, worker, a) != 0) { free(a); p->tid[t] = 0; p->threads = t; break; }
+        }
+    }
+    if (!ok) { heaac_pipeline_destroy(p); return HEAAC_ERR_NOMEM; }
+    *out = p;
+    return HEAAC_OK;
+}
+
+static double now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+#define HIP_OK(x) do { if ((x) != hipSuccess) return HEAAC_ERR_HIP; } while (0)
+
+extern "C" int heaac_pipeline_submit(HeaacPipeline *p, const uint8_t *const *au, const int *size, int *status)
+{
+    if (!p || !au || !size) return HEAAC_ERR_ARG;
+    if (p->submitted - p->collected >= 2) return HEAAC_ERR_ARG;
+    Set *s = &p->set[p->submitted & 1];
+    // the pinned inputs of this set are free once the H2D of the tick that used it last has finished
+    if (s->used) HIP_OK(hipEventSynchronize(s->in_done));
+    const double t0 = now_ms();
+    pthread_mutex_lock(&p->mu);
+    p->job_au = au; p->job_size = size; p->job_status = status; p->job_set = s;
+    p->pending = p->threads - 1;
+    p->generation++;
+    pthread_cond_broadcast(&p->cv_go);
+    pthread_mutex_unlock(&p->mu);
+    parse_slice(p, 0);
+    pthread_mutex_lock(&p->mu);
+    while (p->pending > 0) pthread_cond_wait(&p->cv_done, &p->mu);
+    pthread_mutex_unlock(&p->mu);
+    s->parse_ms = (float)(now_ms() - t0);
+
+    const size_t n = p->n, nc = n * (size_t)p->ncore;
+    // new SBR headers of this tick (the table's storage never moves)
+    const size_t have = heaac_sbr_table_count(p->tab);
+    if (have > PL_MAX_HDRS) return HEAAC_ERR_ARG;
+    // H2D
+    if (s->used) HIP_OK(hipStreamWaitEvent(p->in, s->run_done, 0));
+    HIP_OK(hipEventRecord(s->in_start, p->in));
+    if (have > p->hdr_uploaded) {
+        HIP_OK(hipMemcpyAsync(p->d_hdr + p->hdr_uploaded, heaac_sbr_table_data(p->tab) + p->hdr_uploaded,
+                              (have - p->hdr_uploaded) * sizeof(HeaacSbrHeader), hipMemcpyHostToDevice, p->in));
+        p->hdr_uploaded = have;
+    }
+    HIP_OK(hipMemcpyAsync(s->d_coeffs, s->h_coeffs, nc * 4096, hipMemcpyHostToDevice, p->in));
+    HIP_OK(hipMemcpyAsync(s->d_ics, s->h_ics, nc * sizeof(HeaacIcs), hipMemcpyHostToDevice, p->in));
+    HIP_OK(hipMemcpyAsync(s->d_tools, s->h_tools, n * sizeof(HeaacToolsFrame), hipMemcpyHostToDevice, p->in));
+    HIP_OK(hipMemcpyAsync(s->d_sbr, s->h_sbr, n * sizeof(HeaacSbrFrame), hipMemcpyHostToDevice, p->in));
+    if (s->d_ps) HIP_OK(hipMemcpyAsync(s->d_ps, s->h_ps, n * sizeof(HeaacPsFrame), hipMemcpyHostToDevice, p->in));
+    HIP_OK(hipEventRecord(s->in_done, p->in));
+    // GPU
+    HIP_OK(hipStreamWaitEvent(p->run, s->in_done, 0));
+    if (s->used) HIP_OK(hipStreamWaitEvent(p->run, s->out_done, 0));
+    int rc = heaac_spectral_tools_batch(p->dev, p->ncore, s->d_coeffs, s->d_tools, p->d_rng, p->d_rng, NULL, NULL, n,
+                                        (void *)p->run);
+    if (rc == HEAAC_OK)
+        rc = heaac_he_decode_batch(p->dev, p->he_cfg, s->d_coeffs, s->d_ics, s->d_sbr, p->d_hdr, PL_MAX_HDRS, s->d_ps,
+                                   p->d_state, p->d_state, s->d_pcm, HEAAC_PCM_S16_INTERLEAVED, n, (void *)p->run);
+    if (rc != HEAAC_OK) return rc;
+    HIP_OK(hipEventRecord(s->run_done, p->run));
+    // D2H
+    HIP_OK(hipStreamWaitEvent(p->out, s->run_done, 0));
+    HIP_OK(hipMemcpyAsync(s->h_pcm, s->d_pcm, n * (size_t)p->nout * 2048 * 2, hipMemcpyDeviceToHost, p->out));
+    HIP_OK(hipEventRecord(s->out_done, p->out));
+    s->used = 1;
+    p->submitted++;
+    return HEAAC_OK;
+}
+
+extern "C" int heaac_pipeline_collect(HeaacPipeline *p, const int16_t **pcm)
+{
+    if (!p || !pcm || p->collected == p->submitted) return HEAAC_ERR_ARG;
+    Set *s = &p->set[p->collected & 1];
+    HIP_OK(hipEventSynchronize(s->out_done));
+    *pcm = s->h_pcm;
+    p->last_ms[0] = s->parse_ms;
+    (void)hipEventElapsedTime(&p->last_ms[1], s->in_start, s->in_done);
+    (void)hipEventElapsedTime(&p->last_ms[2], s->in_done, s->run_done);
+    (void)hipEventElapsedTime(&p->last_ms[3], s->run_done, s->out_done);
+    p->collected++;
+    return HEAAC_OK;
+}
+
+extern "C" void heaac_pipeline_timing(const HeaacPipeline *p, float ms[4])
+{
+    for (int k = 0; k < 4; k++) ms[k] = p ? p->last_ms[k] : 0.0f;
+}

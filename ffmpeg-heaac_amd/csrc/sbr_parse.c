@@ -865,11 +865,19 @@ int heaac_heaac_parse_frame(const HeaacAacConfig *cfg, HeaacAacStream *st, Heaac
                             float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
                             HeaacSbrFrame *sbr, HeaacPsFrame *ps, HeaacAacFrameInfo *info)
 {
+    return heaac_heaac_parse_frame_ex(cfg, st, sst, tab, au, size, 2, coeffs, ics, tools, sbr, ps, info);
+}
+
+int heaac_heaac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st, HeaacSbrStream *sst,
+                               HeaacSbrHeaderTable *tab, const uint8_t *au, int size, int coeff_channels,
+                               float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
+                               HeaacSbrFrame *sbr, HeaacPsFrame *ps, HeaacAacFrameInfo *info)
+{
     HeaacAacFrameInfo fi;
     memset(&fi, 0, sizeof(fi));
     if (info) *info = fi;
     if (!cfg || !sst || !tab || !sbr) return HEAAC_PARSE_ERR_ARG;
-    const int r = heaac_aac_parse_frame(cfg, st, au, size, coeffs, ics, tools, &fi);
+    const int r = heaac_aac_parse_frame_ex(cfg, st, au, size, coeff_channels, coeffs, ics, tools, NULL, &fi);
     if (r) return r;                                   /* info->channels = 0: the core element failed */
     if (info) *info = fi;
     const int allow_ps = cfg->ps != 0 && fi.channels == 1 && ps != NULL;

@@ -290,6 +290,12 @@ int heaac_heaac_parse_frame(const HeaacAacConfig *cfg, HeaacAacStream *st, Heaac
                             float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
                             HeaacSbrFrame *sbr, HeaacPsFrame *ps, HeaacAacFrameInfo *info);
 
+/* The same with the channel stride of `coeffs` / `ics` chosen (heaac_aac_parse_frame_ex): 1 packs mono streams. */
+int heaac_heaac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st, HeaacSbrStream *sst,
+                               HeaacSbrHeaderTable *tab, const uint8_t *au, int size, int coeff_channels,
+                               float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
+                               HeaacSbrFrame *sbr, HeaacPsFrame *ps, HeaacAacFrameInfo *info);
+
 /* n independent streams, one access unit each, on host threads (see heaac_aac_parse_batch).
  * sbr [n], ps [n] (NULL unless cfg->ps != 0 and the stream is mono). */
 int heaac_heaac_parse_batch(const HeaacAacConfig *cfg, HeaacAacStream *st, HeaacSbrStream *sst,

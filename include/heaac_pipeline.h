@@ -1,0 +1,54 @@
+/* heaac_pipeline.h -- bitstreams in host memory in, int16 PCM in host memory out: the caller that keeps nothing
+ * on the device (SURVEY.md s8f N2 "host-side batched parser ... thousands of concurrent streams").
+ *
+ * n streams advance in lock step, one access unit per stream and tick.  A tick runs through four stages --
+ * host parse (a persistent thread pool), H2D of the parsed records (pinned), spectral tools + decode on the GPU,
+ * D2H of the PCM (pinned) -- and consecutive ticks overlap: while tick t is on the link and on the GPU, the host
+ * parses tick t + 1.  Two sets of pinned / device buffers alternate; three HIP streams (copy in, compute, copy
+ * out) are ordered by events.  The per-stream decoder state (parser state on the host, DSP state records on the
+ * device) lives in the pipeline.
+ *
+ * What it does per tick is exactly heaac_heaac_parse_frame + heaac_spectral_tools_batch + heaac_he_decode_batch
+ * (HEAAC_PCM_S16_INTERLEAVED) for every stream; tests compare it with those calls made one after the other.
+ * The reference has no counterpart: its decoder handles one packet of one stream per call
+ * (avcodec_decode_audio3, libavcodec/utils.c:638-663).
+ */
+#ifndef HEAAC_PIPELINE_H
+#define HEAAC_PIPELINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "heaac_dsp.h"
+#include "heaac_parse.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct HeaacPipeline HeaacPipeline;
+
+/* aac: the configuration all streams share (AudioSpecificConfig as heaac_asc_parse leaves it; sbr = 1).
+ * he_cfg: HEAAC_CFG_HEV2 (mono core + SBR + PS), HEAAC_CFG_HEV1_MONO or HEAAC_CFG_HEV1 (pair).
+ * threads: parser threads (<= 0: one per online CPU, at most 256).
+ * HEAAC_ERR_NODEVICE without a usable device. */
+int heaac_pipeline_create(HeaacPipeline **out, const HeaacAacConfig *aac, int he_cfg, size_t n_streams, int threads);
+void heaac_pipeline_destroy(HeaacPipeline *p);
+
+/* Tick t: au[n_streams] / size[n_streams], one access unit per stream (the buffers are read during the call
+ * only).  Parses on the pool, then enqueues upload, decode and download and returns without waiting for them.
+ * status (may be NULL) receives each stream's parse result (heaac_heaac_parse_frame's).  At most two ticks may
+ * be in flight: a third submit before a collect returns HEAAC_ERR_ARG. */
+int heaac_pipeline_submit(HeaacPipeline *p, const uint8_t *const *au, const int *size, int *status);
+
+/* Waits for the OLDEST tick in flight and hands out its PCM: [n_streams][2048][channels] int16 in pinned memory
+ * owned by the pipeline, valid until the second submit from now. */
+int heaac_pipeline_collect(HeaacPipeline *p, const int16_t **pcm);
+
+/* Per-stage wall time of the last collected tick in milliseconds: host parse, H2D, GPU, D2H (device stages
+ * from HIP events). */
+void heaac_pipeline_timing(const HeaacPipeline *p, float ms[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEAAC_PIPELINE_H */

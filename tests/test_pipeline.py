@@ -1,0 +1,94 @@
+"""include/heaac_pipeline.h: the overlapped host-buffer pipeline.  CPU: argument checks and the loud failure
+without a device.  GPU: several ticks of HE-AACv2 / HE-AACv1 streams through the pipeline give, tick for tick and
+bit for bit, the PCM of the same access units through the batch parser + spectral tools + decode made one call
+after the other (the path the other tests pin to the oracle)."""
+import ctypes as C
+import copy
+
+import numpy as np
+import pytest
+
+import sbr_bitwriter as SW
+import test_parse as TP
+import test_sbr_parse as TS
+
+
+def test_create_checks_arguments_and_fails_loudly_without_a_device(pkg):
+    import torch
+    lib = pkg.lib()
+    h = C.c_void_p(1)
+    cfg = TS._he_cfg(pkg, 1, True)
+    assert lib.heaac_pipeline_create(C.byref(h), C.byref(cfg), pkg.CFG_LC_STEREO, C.c_size_t(4), 1) == -1 and not h.value
+    assert lib.heaac_pipeline_create(C.byref(h), None, pkg.CFG_HEV2, C.c_size_t(4), 1) == -1
+    assert lib.heaac_pipeline_create(C.byref(h), C.byref(cfg), pkg.CFG_HEV2, C.c_size_t(0), 1) == -1
+    if not torch.cuda.is_available():
+        assert lib.heaac_pipeline_create(C.byref(h), C.byref(cfg), pkg.CFG_HEV2, C.c_size_t(4), 1) == -4 and not h.value
+
+
+def _ticks(pkg, rng, channels, ps, n, ticks):
+    writers = [SW.SbrStreamWriter(pkg, channels, ps=ps, ps_modes="20" if ps else "any") for _ in range(n)]
+    out = []
+    for t in range(ticks):
+        aus = []
+        for w in writers:
+            while True:
+                keep = copy.deepcopy((w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling))
+                bits, _ = w.frame(rng, new_header=(t == 3))
+                if (4 + len(bits) + 7) // 8 <= 269:
+                    break
+                w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling = keep
+            aus.append(TP._write_au(rng, 6, 2, channels == 2, extras=False, sbr=(bits, False), quiet=True)[0])
+        out.append(aus)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfgname", ["CFG_HEV2", "CFG_HEV1"])
+def test_pipeline_equals_the_calls_made_one_after_the_other(pkg, dev, cfgname):
+    import torch
+    cfg = getattr(pkg, cfgname)
+    ps = cfg == pkg.CFG_HEV2
+    channels = 1 if ps else 2
+    rng = np.random.default_rng(61 + channels)
+    n, ticks = 37, 7
+    aus = _ticks(pkg, rng, channels, ps, n, ticks)
+    m4 = TS._he_cfg(pkg, channels, ps)
+    pl = pkg.Pipeline(m4, cfg, n, threads=3)
+    # the direct path
+    tab = pkg.SbrHeaderTable(4096)
+    st, sst = np.zeros(n, pkg.AAC_STREAM_DT), pkg.sbr_streams(n)
+    d_state = torch.zeros((n, pkg.STATE_WORDS[cfg]), device="cuda")
+    d_rng = torch.full((n,), 0x1f2e3d4c, dtype=torch.int32, device="cuda")
+    want = []
+    for t in range(ticks):
+        q = pkg.heaac_parse_batch(m4, st, sst, tab, aus[t], threads=2, with_ps=ps)
+        coeffs = torch.from_numpy(np.ascontiguousarray(q["coeffs"][:, :channels])).cuda()
+        dev.spectral_tools(channels, coeffs, pkg.to_device(q["tools"]), rng=d_rng)
+        pcm, d_state = dev.he_decode(cfg, coeffs, pkg.to_device(np.ascontiguousarray(q["ics"][:, :channels])),
+                                     pkg.to_device(q["sbr"]), pkg.to_device(tab.headers()),
+                                     pkg.to_device(q["ps"]) if ps else None, d_state, state_out=d_state, pcm_format=pkg.PCM_S16)
+        torch.cuda.synchronize()
+        want.append((pcm.cpu().numpy(), q["status"].copy()))
+    # the pipeline, two ticks in flight
+    got = []
+    status = [pl.submit(aus[0])]
+    for t in range(1, ticks):
+        status.append(pl.submit(aus[t]))
+        got.append(pl.collect().copy())
+    got.append(pl.collect().copy())
+    with pytest.raises(pkg.HeaacError):
+        pl.collect()                                                   # nothing in flight
+    loud = 0
+    for t in range(ticks):
+        assert np.array_equal(status[t], want[t][1]), t
+        assert np.array_equal(got[t], want[t][0]), "tick %d" % t
+        loud = max(loud, int(np.abs(got[t].astype(int)).max()))
+    assert loud > 50
+    # a third submit without a collect is refused
+    pl.submit(aus[0]); pl.submit(aus[1])
+    with pytest.raises(pkg.HeaacError):
+        pl.submit(aus[2])
+    pl.collect(); pl.collect()
+    tm = pl.timing()
+    assert tm["parse"] > 0 and tm["gpu"] > 0
+    pl.close()
