@@ -2,13 +2,16 @@
 // stages of consecutive ticks overlapped (host parse || H2D || GPU || D2H).
 //
 //   host parse   persistent pool: worker w owns the streams [n w / W, n (w + 1) / W) (their parser state too)
-//   H2D          stream `in`:  parsed records of buffer set (t & 1), pinned -> device
+//   H2D          stream `in`:  parsed records of the tick's buffer set, pinned -> device
 //   GPU          stream `run`: heaac_spectral_tools_batch + heaac_he_decode_batch, DSP state in place
-//   D2H          stream `out`: int16 PCM of buffer set (t & 1), device -> pinned
-// Event order per set s = t & 1:  in waits run_done[s] of tick t - 2 (its inputs are free again); run waits
-// in_done[s] and out_done[s] of tick t - 2 (its PCM buffer is free); out waits run_done[s].
+//   D2H          stream `out`: int16 PCM of the tick's buffer set, device -> pinned
+// PL_DEPTH buffer sets rotate (set = tick % PL_DEPTH): a tick spends parse + H2D + GPU + D2H in flight (about 24 ms for
+// 32 k streams) while the slowest stage takes 7 ms, so four ticks must overlap to keep every stage busy.
+// Event order per set s:  in waits run_done[s] of the tick that used s last (its inputs are free again); run waits
+// in_done[s] and that tick's out_done[s] (its PCM buffer is free); out waits run_done[s].
 #include <hip/hip_runtime.h>
 #include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -16,6 +19,7 @@
 #include "heaac_pipeline.h"
 
 #define PL_MAX_HDRS 4096
+#define PL_DEPTH HEAAC_PIPELINE_DEPTH
 
 struct Set {
     // pinned host
@@ -33,7 +37,7 @@ struct HeaacPipeline {
     size_t n, words;
     HeaacDevice *dev;
     hipStream_t in, run, out;
-    Set set[2];
+    Set set[PL_DEPTH];
     float *d_state; int32_t *d_rng;
     HeaacSbrHeader *d_hdr; size_t hdr_uploaded;
     HeaacSbrHeaderTable *tab;
@@ -85,6 +89,26 @@ static void *worker(void *arg)
     return NULL;
 }
 
+// Parser threads when the caller does not say: the CPUs this process may actually use.  Inside a container the CPU
+// bandwidth quota (cgroup v2 cpu.max) can be far below the online count; threads beyond about twice the quota only
+// get throttled (measured on the GPU box: 256 online, quota 16: 32 threads parse a tick in 6 ms, 256 in 18 ms
+// once the copy engines' helper threads compete).
+static int default_threads(void)
+{
+    long online = sysconf(_SC_NPROCESSORS_ONLN);
+    if (online < 1) online = 1;
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        long long quota = 0, period = 0;
+        if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
+            const long cap = (long)((2 * quota + period - 1) / period);
+            if (cap >= 1 && cap < online) online = cap;
+        }
+        fclose(f);
+    }
+    return (int)online;
+}
+
 static int pinned(void **p, size_t bytes) { return hipHostMalloc(p, bytes, hipHostMallocDefault) == hipSuccess; }
 static int devmem(void **p, size_t bytes) { return hipMalloc(p, bytes) == hipSuccess; }
 
@@ -103,7 +127,7 @@ extern "C" void heaac_pipeline_destroy(HeaacPipeline *p)
     if (p->in) (void)hipStreamSynchronize(p->in);
     if (p->run) (void)hipStreamSynchronize(p->run);
     if (p->out) (void)hipStreamSynchronize(p->out);
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < PL_DEPTH; k++) {
         Set *s = &p->set[k];
         void *h[] = { s->h_coeffs, s->h_ics, s->h_tools, s->h_sbr, s->h_ps, s->h_pcm };
         void *d[] = { s->d_coeffs, s->d_ics, s->d_tools, s->d_sbr, s->d_ps, s->d_pcm };
@@ -146,7 +170,7 @@ extern "C" int heaac_pipeline_create(HeaacPipeline **out, const HeaacAacConfig *
               hipStreamCreateWithFlags(&p->run, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&p->out, hipStreamNonBlocking) == hipSuccess;
     const int with_ps = he_cfg == HEAAC_CFG_HEV2;
-    for (int k = 0; k < 2 && ok; k++) {
+    for (int k = 0; k < PL_DEPTH && ok; k++) {
         Set *s = &p->set[k];
         const size_t nc = n * (size_t)p->ncore;
         ok = pinned((void **)&s->h_coeffs, nc * 4096) && pinned((void **)&s->h_ics, nc * sizeof(HeaacIcs)) &&
@@ -163,6 +187,7 @@ extern "C" int heaac_pipeline_create(HeaacPipeline **out, const HeaacAacConfig *
             memset(s->h_coeffs, 0, nc * 4096); memset(s->h_ics, 0, nc * sizeof(HeaacIcs));
             memset(s->h_tools, 0, n * sizeof(HeaacToolsFrame)); memset(s->h_sbr, 0, n * sizeof(HeaacSbrFrame));
             if (with_ps) memset(s->h_ps, 0, n * sizeof(HeaacPsFrame));
+            ok = hipMemset(s->d_tools, 0, n * sizeof(HeaacToolsFrame)) == hipSuccess;
         }
     }
     ok = ok && devmem((void **)&p->d_state, n * p->words * 4) && devmem((void **)&p->d_rng, n * 4) &&
@@ -188,7 +213,7 @@ extern "C" int heaac_pipeline_create(HeaacPipeline **out, const HeaacAacConfig *
         p->hdr_uploaded = 1;
     }
     if (ok) {
-        if (threads <= 0) threads = (int)sysconf(_SC_NPROCESSORS_ONLN);
+        if (threads <= 0) threads = default_threads();
         if (threads < 1) threads = 1;
         if (threads > 256) threads = 256;
         if ((size_t)threads > n) threads = (int)n;
@@ -222,8 +247,8 @@ static double now_ms(void)
 extern "C" int heaac_pipeline_submit(HeaacPipeline *p, const uint8_t *const *au, const int *size, int *status)
 {
     if (!p || !au || !size) return HEAAC_ERR_ARG;
-    if (p->submitted - p->collected >= 2) return HEAAC_ERR_ARG;
-    Set *s = &p->set[p->submitted & 1];
+    if (p->submitted - p->collected >= PL_DEPTH) return HEAAC_ERR_ARG;
+    Set *s = &p->set[p->submitted % PL_DEPTH];
     // the pinned inputs of this set are free once the H2D of the tick that used it last has finished
     if (s->used) HIP_OK(hipEventSynchronize(s->in_done));
     const double t0 = now_ms();
@@ -253,7 +278,14 @@ extern "C" int heaac_pipeline_submit(HeaacPipeline *p, const uint8_t *const *au,
     }
     HIP_OK(hipMemcpyAsync(s->d_coeffs, s->h_coeffs, nc * 4096, hipMemcpyHostToDevice, p->in));
     HIP_OK(hipMemcpyAsync(s->d_ics, s->h_ics, nc * sizeof(HeaacIcs), hipMemcpyHostToDevice, p->in));
-    HIP_OK(hipMemcpyAsync(s->d_tools, s->h_tools, n * sizeof(HeaacToolsFrame), hipMemcpyHostToDevice, p->in));
+    if (p->ncore == 1) {
+        // a mono stream uses channel 0 of the tools record only: the second channel's 3.5 KB stay on the host
+        // (the device copies were zeroed once and the kernel never reads them for one channel)
+        HIP_OK(hipMemcpy2DAsync(s->d_tools, sizeof(HeaacToolsFrame), s->h_tools, sizeof(HeaacToolsFrame),
+                                offsetof(HeaacToolsFrame, ch) + sizeof(HeaacToolsChannel), n, hipMemcpyHostToDevice, p->in));
+    } else {
+        HIP_OK(hipMemcpyAsync(s->d_tools, s->h_tools, n * sizeof(HeaacToolsFrame), hipMemcpyHostToDevice, p->in));
+    }
     HIP_OK(hipMemcpyAsync(s->d_sbr, s->h_sbr, n * sizeof(HeaacSbrFrame), hipMemcpyHostToDevice, p->in));
     if (s->d_ps) HIP_OK(hipMemcpyAsync(s->d_ps, s->h_ps, n * sizeof(HeaacPsFrame), hipMemcpyHostToDevice, p->in));
     HIP_OK(hipEventRecord(s->in_done, p->in));
@@ -279,7 +311,7 @@ extern "C" int heaac_pipeline_submit(HeaacPipeline *p, const uint8_t *const *au,
 extern "C" int heaac_pipeline_collect(HeaacPipeline *p, const int16_t **pcm)
 {
     if (!p || !pcm || p->collected == p->submitted) return HEAAC_ERR_ARG;
-    Set *s = &p->set[p->collected & 1];
+    Set *s = &p->set[p->collected % PL_DEPTH];
     HIP_OK(hipEventSynchronize(s->out_done));
     *pcm = s->h_pcm;
     p->last_ms[0] = s->parse_ms;

@@ -4,8 +4,8 @@
  * n streams advance in lock step, one access unit per stream and tick.  A tick runs through four stages --
  * host parse (a persistent thread pool), H2D of the parsed records (pinned), spectral tools + decode on the GPU,
  * D2H of the PCM (pinned) -- and consecutive ticks overlap: while tick t is on the link and on the GPU, the host
- * parses tick t + 1.  Two sets of pinned / device buffers alternate; three HIP streams (copy in, compute, copy
- * out) are ordered by events.  The per-stream decoder state (parser state on the host, DSP state records on the
+ * parses tick t + 1.  HEAAC_PIPELINE_DEPTH sets of pinned / device buffers rotate; three HIP streams (copy in,
+ * compute, copy out) are ordered by events.  The per-stream decoder state (parser state on the host, DSP state records on the
  * device) lives in the pipeline.
  *
  * What it does per tick is exactly heaac_heaac_parse_frame + heaac_spectral_tools_batch + heaac_he_decode_batch
@@ -26,22 +26,24 @@ extern "C" {
 #endif
 
 typedef struct HeaacPipeline HeaacPipeline;
+#define HEAAC_PIPELINE_DEPTH 4        /* ticks that may be in flight (submitted, not yet collected) */
 
 /* aac: the configuration all streams share (AudioSpecificConfig as heaac_asc_parse leaves it; sbr = 1).
  * he_cfg: HEAAC_CFG_HEV2 (mono core + SBR + PS), HEAAC_CFG_HEV1_MONO or HEAAC_CFG_HEV1 (pair).
- * threads: parser threads (<= 0: one per online CPU, at most 256).
+ * threads: parser threads (<= 0: the CPUs the process may use -- online CPUs, capped at twice a cgroup CPU quota;
+ *          at most 256).
  * HEAAC_ERR_NODEVICE without a usable device. */
 int heaac_pipeline_create(HeaacPipeline **out, const HeaacAacConfig *aac, int he_cfg, size_t n_streams, int threads);
 void heaac_pipeline_destroy(HeaacPipeline *p);
 
 /* Tick t: au[n_streams] / size[n_streams], one access unit per stream (the buffers are read during the call
  * only).  Parses on the pool, then enqueues upload, decode and download and returns without waiting for them.
- * status (may be NULL) receives each stream's parse result (heaac_heaac_parse_frame's).  At most two ticks may
- * be in flight: a third submit before a collect returns HEAAC_ERR_ARG. */
+ * status (may be NULL) receives each stream's parse result (heaac_heaac_parse_frame's).  At most
+ * HEAAC_PIPELINE_DEPTH ticks may be in flight: one more submit before a collect returns HEAAC_ERR_ARG. */
 int heaac_pipeline_submit(HeaacPipeline *p, const uint8_t *const *au, const int *size, int *status);
 
 /* Waits for the OLDEST tick in flight and hands out its PCM: [n_streams][2048][channels] int16 in pinned memory
- * owned by the pipeline, valid until the second submit from now. */
+ * owned by the pipeline, valid until HEAAC_PIPELINE_DEPTH more ticks have been submitted. */
 int heaac_pipeline_collect(HeaacPipeline *p, const int16_t **pcm);
 
 /* Per-stage wall time of the last collected tick in milliseconds: host parse, H2D, GPU, D2H (device stages

@@ -69,13 +69,15 @@ def test_pipeline_equals_the_calls_made_one_after_the_other(pkg, dev, cfgname):
                                      pkg.to_device(q["ps"]) if ps else None, d_state, state_out=d_state, pcm_format=pkg.PCM_S16)
         torch.cuda.synchronize()
         want.append((pcm.cpu().numpy(), q["status"].copy()))
-    # the pipeline, two ticks in flight
-    got = []
-    status = [pl.submit(aus[0])]
-    for t in range(1, ticks):
+    # the pipeline, as many ticks in flight as it takes
+    got, status = [], []
+    depth = 4
+    for t in range(ticks):
+        if t >= depth:
+            got.append(pl.collect().copy())
         status.append(pl.submit(aus[t]))
+    while len(got) < ticks:
         got.append(pl.collect().copy())
-    got.append(pl.collect().copy())
     with pytest.raises(pkg.HeaacError):
         pl.collect()                                                   # nothing in flight
     loud = 0
@@ -84,11 +86,13 @@ def test_pipeline_equals_the_calls_made_one_after_the_other(pkg, dev, cfgname):
         assert np.array_equal(got[t], want[t][0]), "tick %d" % t
         loud = max(loud, int(np.abs(got[t].astype(int)).max()))
     assert loud > 50
-    # a third submit without a collect is refused
-    pl.submit(aus[0]); pl.submit(aus[1])
+    # one submit more than the depth without a collect is refused
+    for t in range(depth):
+        pl.submit(aus[t])
     with pytest.raises(pkg.HeaacError):
-        pl.submit(aus[2])
-    pl.collect(); pl.collect()
+        pl.submit(aus[depth])
+    for t in range(depth):
+        pl.collect()
     tm = pl.timing()
     assert tm["parse"] > 0 and tm["gpu"] > 0
     pl.close()
