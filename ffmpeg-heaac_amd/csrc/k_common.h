@@ -86,6 +86,59 @@ __device__ __forceinline__ int opaque(int v)
     return v;
 }
 
+// ---------------------------------------------------------------------------
+// Frame feed of a persistent wave.  Frames cost between ~0.8x and ~1.3x the mean (envelope counts, window
+// sequences, DRAM jitter), and a fixed stride also locks the waves' memory traffic in step (measured again in
+// round 3: k_hfps +20 % with 7/8 of the frames by stride), so the waves draw their frames from a queue word.  One
+// atomic per frame runs into the word itself: 262 144 frames in 3.4 ms are 77 M atomics/s on one address, close to
+// what one address serves (~88 M/s), and the tickets then arrive late.  So a ticket is worth Q consecutive frames
+// (k_synth: Q = 2, -4 ... -10 % by box).  The first chunk is the wave's own index; the ticket for the chunk after
+// next is issued at the top of a chunk's first frame and consumed Q frames later.  Everything here is wave-uniform;
+// the ticket travels in lane 0's VGPR until it is consumed.
+// ---------------------------------------------------------------------------
+template <unsigned Q>
+struct FrameFeed {
+    unsigned long long cur, nxt;          // the frame in work and the one after it (>= n: none)
+    unsigned long long base1;             // first frame of the next chunk
+    unsigned long long qoff;              // frames handed out without the queue (the first chunk of every wave)
+    unsigned *queue;
+    unsigned pos;                         // index of `cur` in its chunk
+    unsigned vt;                          // ticket in flight (lane 0)
+
+    // wave: index of this wave in the grid, waves: waves in the grid
+    __device__ __forceinline__ void init(unsigned long long wave, unsigned long long waves, unsigned *q, int lane)
+    {
+        queue = q;
+        qoff = waves * Q;
+        pos = 0;
+        cur = wave * Q;
+        unsigned t = 0;
+        if (lane == 0) t = atomicAdd(queue, Q);
+        base1 = qoff + (unsigned long long)__builtin_amdgcn_readfirstlane(t);
+        nxt = Q > 1 ? cur + 1 : base1;
+        vt = 0;
+    }
+    // call at the top of a frame
+    __device__ __forceinline__ void request(int lane)
+    {
+        if (pos == 0) { vt = 0; if (lane == 0) vt = atomicAdd(queue, Q); }
+    }
+    // call at the end of a frame
+    __device__ __forceinline__ void advance()
+    {
+        cur = nxt;
+        if (pos + 1 < Q) {
+            pos++;
+        } else {
+            pos = 0;
+            base1 = qoff + (unsigned long long)__builtin_amdgcn_readfirstlane(vt);
+        }
+        // the frame after the new `cur`: its neighbour inside the chunk, or the next chunk's first (pos counts
+        // the frames of the chunk `cur` is in; at this point base1 is the chunk after cur's)
+        nxt = pos + 1 < Q ? cur + 1 : base1;
+    }
+};
+
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
     __device__ __forceinline__ void operator()(int) const {}

@@ -236,13 +236,13 @@ void k_hfadj(const float *__restrict__ g_tab,
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
     const HfWave S = hf_wave_view(s_xlow[wave], s_aux[wave], s_rec[wave]);
-    // Units are drawn from a queue two at a time (for a CPE: the two channels of one frame, which
-    // share the frame's side info; one hot address serves < 100 M atomics/s): the first pair is the
-    // wave's own index, the next one is fetched while the current one is processed.
-    unsigned long long ub = ((unsigned long long)blockIdx.x * HF_WAVES + wave) * 2;
-    while (ub < n_units) {
-        unsigned nxt = 0;
-        if (lane == 0) nxt = atomicAdd(g_queue, 2u) + gridDim.x * HF_WAVES * 2;
+    // Units are drawn from a queue two at a time (for a CPE: the two channels of one frame, which share the
+    // frame's side info): FrameFeed over pairs, one pair per ticket (k_common.h).
+    FrameFeed<1> feed;
+    feed.init((unsigned long long)blockIdx.x * HF_WAVES + wave, (unsigned long long)gridDim.x * HF_WAVES, g_queue, lane);
+    while (feed.cur * 2 < n_units) {
+        const unsigned long long ub = feed.cur * 2;
+        feed.request(lane);
       for (int qi = 0; qi < 2 && ub + qi < n_units; qi++) {
         const unsigned long long u = ub + qi;
         const unsigned long long f = u / ncore;
@@ -257,7 +257,7 @@ void k_hfadj(const float *__restrict__ g_tab,
                        __builtin_nontemporal_store(im, X1 + i * 64 + lane);
                    });
       }
-        ub = (unsigned long long)__builtin_amdgcn_readfirstlane(nxt);
+        feed.advance();
     }
 }
 
@@ -435,8 +435,8 @@ __device__ __forceinline__ void synth_channel(const SL &S, SynWave &w, const flo
 }
 
 // k_synth: one wave per frame.  While a channel runs its polyphase sum, the X rows and ring state of
-// the next unit -- the frame's other channel, or the first channel of the wave's next frame (the queue
-// hands indices out one frame ahead) -- are already on their way into registers.
+// the next unit -- the frame's other channel, or the first channel of the wave's next frame (the feed
+// knows indices one frame ahead) -- are already on their way into registers.
 template <int FMT>
 __global__ __launch_bounds__(SYN_WAVES_F32 * WAVE)
 void k_synth(const float *__restrict__ g_tab, const float *g_X,
@@ -457,16 +457,14 @@ void k_synth(const float *__restrict__ g_tab, const float *g_X,
         const float *X0 = g_X + (f * 2 + ch) * (2 * 38 * 64);
         syn_load(X0, X0 + 38 * 64, g_state_in + f * state_words + off_syn0 + ch * HEAAC_ST_SYNTH, lane, d);
     };
-    // two tickets: the frame in work and the next one (first one: the wave's own index)
-    unsigned long long f = (unsigned long long)blockIdx.x * NW + wave;
-    unsigned tk = 0;
-    if (lane == 0) tk = atomicAdd(g_queue, 1u) + gridDim.x * NW;
-    unsigned long long f1 = (unsigned long long)__builtin_amdgcn_readfirstlane(tk);
+    // the frame in work and the next one are known (FrameFeed, k_common.h: two frames per ticket)
+    FrameFeed<2> feed;
+    feed.init((unsigned long long)blockIdx.x * NW + wave, (unsigned long long)gridDim.x * NW, g_queue, lane);
     SynIn cur;
-    if (f < n_frames) load_unit(f, 0, cur);
-    while (f < n_frames) {
-        unsigned nxt = 0;
-        if (lane == 0) nxt = atomicAdd(g_queue, 1u) + gridDim.x * NW;
+    if (feed.cur < n_frames) load_unit(feed.cur, 0, cur);
+    while (feed.cur < n_frames) {
+        const unsigned long long f = feed.cur, f1 = feed.nxt;
+        feed.request(lane);
         float *st_out = g_state_out + f * state_words + off_syn0;
         // one channel: rows from `cur`, then the next unit's loads, then the polyphase sum
         auto channel = [&](int ch, auto emit) {
@@ -497,8 +495,7 @@ void k_synth(const float *__restrict__ g_tab, const float *g_X,
                     syn_st(o + (64 * i + n) * nout + ch, (int16_t)pcm_int16<FMT>(v));
                 });
         }
-        f = f1;
-        f1 = (unsigned long long)__builtin_amdgcn_readfirstlane(nxt);
+        feed.advance();
     }
 }
 

@@ -71,6 +71,7 @@ void k_ps(const float *__restrict__ g_tab, const HeaacPsFrame *__restrict__ g_ps
 // get X written out and are finished by k_ps<true>.
 // ---------------------------------------------------------------------------
 #define HFPS_WAVES 8
+#define HFPS_QUEUE_CHUNK 1      // frames per queue ticket
 #define HFPS_C_WORDS (HF_REC_WORDS > 20 * 33 ? HF_REC_WORDS : 20 * 33)
 
 __global__ __launch_bounds__(HFPS_WAVES * WAVE)
@@ -103,22 +104,18 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
              reinterpret_cast<float (*)[SUB_STRIDE]>(s_a[wave] + (WT::NSUB + 1) * SUB_STRIDE),
              reinterpret_cast<float (*)[33]>(s_c[wave]), s_Hs[wave], s_idx[wave][0], s_idx[wave][1],
              s_idx[wave][0], s_idx[wave][0], s_hyb, s_hyb + 112 };
-    // Frames cost between ~0.8x and ~1.3x the mean (envelope counts, smoothing, patches), so the
-    // waves draw them from a queue instead of a fixed stride: the first one is the wave's own index,
-    // each next one is fetched (one atomic, in flight during the frame) from g_queue.
-    // Two tickets are held: the frame being processed and the next one, whose parameter records are
-    // touched into the caches two thirds into the PS pass of the current frame (the queue hands the next
-    // index out a frame early).  Level 1 = the SBR and PS frame records (1.2 KB): k_hfps -6.8 %.  Level 2
-    // adds W and the SBR state (16 KB) for another 0.3 %, but those lines leave L2 again before they are
-    // used and are fetched twice (measured: +14.5 KiB per frame of FETCH_SIZE) -- not worth the traffic.
+    // Frames cost between ~0.8x and ~1.3x the mean (envelope counts, smoothing, patches): FrameFeed (k_common.h)
+    // draws them from a queue.  The frame in work and the next one are
+    // known; the next one's parameter records are touched into the caches two thirds into the PS pass of the
+    // current frame.  Level 1 = the SBR and PS frame records (1.2 KB): k_hfps -6.8 %.  Level 2 adds W and the SBR
+    // state (16 KB) for another 0.3 %, but those lines leave L2 again before they are used and are fetched twice
+    // (measured: +14.5 KiB per frame of FETCH_SIZE; touched later they cost 3-5 %, profiles/r03_experiments.md E10).
     const unsigned sink = lds_addr(s_dump);
-    unsigned long long f = (unsigned long long)blockIdx.x * HFPS_WAVES + wave;
-    unsigned tk = 0;
-    if (lane == 0) tk = atomicAdd(g_queue, 1u) + gridDim.x * HFPS_WAVES;          // queue starts behind the static ones
-    unsigned long long f1 = (unsigned long long)__builtin_amdgcn_readfirstlane(tk);
-    while (f < n_frames) {
-        unsigned nxt = 0;
-        if (lane == 0) nxt = atomicAdd(g_queue, 1u) + gridDim.x * HFPS_WAVES;
+    FrameFeed<HFPS_QUEUE_CHUNK> feed;
+    feed.init((unsigned long long)blockIdx.x * HFPS_WAVES + wave, (unsigned long long)gridDim.x * HFPS_WAVES, g_queue, lane);
+    while (feed.cur < n_frames) {
+        const unsigned long long f = feed.cur, f1 = feed.nxt;
+        feed.request(lane);
         // slot of the PS loop at which the next frame's SBR and PS records (1.2 KB) are touched into L2
         constexpr int TOUCH_RECORDS_SLOT = 20;
         auto prefetch_next = [&](int n) {
@@ -174,8 +171,7 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
             ps_frame<false, true>(W, g_tab, &g_ps[f], top, st_in + off_ps, st_out + off_ps, Xf, lane, wave, col,
                                   prefetch_next);
         }
-        f = f1;
-        f1 = (unsigned long long)__builtin_amdgcn_readfirstlane(nxt);
+        feed.advance();
     }
     l2_touch_drain();
 }
