@@ -3,7 +3,9 @@
  * Built by tests/test_parse_fuzz.py from the parser SOURCES (aac_parse.c, sbr_parse.c, sbr_header.c) with
  * -fsanitize=address,undefined, so every out-of-bounds access or undefined shift aborts the run.  Input: a file
  * of seed access units (u32 kind, u32 length, bytes; kind 0 = AAC-LC CPE 48 kHz, 1 = HE-AACv1 CPE 24 kHz,
- * 2 = HE-AACv2 SCE 24 kHz).  Each iteration mutates a seed (bit flips, byte noise, truncation, splice of two
+ * 2 = HE-AACv2 SCE 24 kHz, 3 = AAC-LC CPE 48 kHz with coupling / program config elements, 4 = the same around an SCE:
+ * kinds 3 and 4 go through heaac_aac_parse_frame_ex).  Every 16th iteration instead walks a buffer of seeds behind ADTS
+ * headers, mutated the same ways, through heaac_adts_split and checks that the packets tile it.  Each iteration mutates a seed (bit flips, byte noise, truncation, splice of two
  * seeds, pure noise), parses it on a stream that keeps its state across iterations, and checks what the parser
  * promises: whatever the status, the records it wrote pass validate.h.
  */
@@ -49,7 +51,17 @@ int main(int argc, char **argv)
     float *coeffs = malloc(2 * 1024 * sizeof(float));
     HeaacIcs ics[2]; HeaacToolsFrame *tools = malloc(sizeof(*tools));
     HeaacSbrFrame sbr; HeaacPsFrame ps; HeaacAacFrameInfo info;
-    long ok = 0, err = 0, bad_records = 0, started = 0;
+    long ok = 0, err = 0, bad_records = 0, started = 0, coupled = 0, adts_frames = 0, adts_bad = 0;
+    HeaacAacConfig wide[2];
+    memset(wide, 0, sizeof(wide));
+    for (int k = 0; k < 2; k++) { wide[k].object_type = 2; wide[k].sampling_index = 3; wide[k].sample_rate = 48000; wide[k].chan_config = k ? 1 : 2; }
+    HeaacAacStream wst[2];
+    memset(wst, 0, sizeof(wst));
+    HeaacCceFrame *cce = malloc(HEAAC_MAX_CCE * sizeof(*cce));
+    float *cce_coeffs = malloc(HEAAC_MAX_CCE * 1024 * sizeof(float));
+    HeaacIcs cce_ics[HEAAC_MAX_CCE];
+    HeaacToolsFrame *cce_tools = malloc(HEAAC_MAX_CCE * sizeof(*cce_tools));
+    const HeaacCceOut co = { cce, cce_coeffs, cce_ics, cce_tools };
     for (long it = 0; it < iters; it++) {
         const Seed *s = &seed[rnd() % ns];
         const int k = (int)s->kind;
@@ -66,6 +78,58 @@ int main(int argc, char **argv)
                          for (uint32_t i = at; i < len; i++) au[i] = t->data[i % t->len]; }
         if (mode == 5) for (uint32_t i = 0; i < len; i++) au[i] = (uint8_t)rnd();
         /* mode 4: the seed unchanged (keeps streams alive between the damaged frames) */
+        if (it % 16 == 15) {
+            /* the ADTS walk: this unit behind a 7-byte header, junk in front, twice; the packets must tile the buffer */
+            const uint32_t flen = len + 7, total = 3 + 2 * flen;
+            uint8_t *buf = malloc(total);
+            buf[0] = (uint8_t)rnd(); buf[1] = (uint8_t)rnd(); buf[2] = (uint8_t)rnd();
+            for (int rep = 0; rep < 2; rep++) {
+                uint8_t *h = buf + 3 + rep * flen;
+                h[0] = 0xff; h[1] = 0xf1; h[2] = (uint8_t)(0x40 | (3 << 2)); h[3] = (uint8_t)(0x80 | ((flen >> 11) & 3));
+                h[4] = (uint8_t)(flen >> 3); h[5] = (uint8_t)(((flen & 7) << 5) | 0x1f); h[6] = 0xfc;
+                memcpy(h + 7, au, len);
+            }
+            if (rnd() & 1) for (int j = 0; j < 4; j++) buf[rnd() % total] = (uint8_t)rnd();
+            HeaacAdtsPacket pk[64];
+            HeaacAdtsHeader first;
+            const long np = heaac_adts_split(buf, total, pk, 64, &first);
+            size_t at = 0;
+            for (long j = 0; j < np && j < 64; j++) {
+                if (pk[j].offset != at || pk[j].size == 0 || pk[j].kind < 0 || pk[j].kind > 3) adts_bad++;
+                at += pk[j].size;
+                adts_frames += pk[j].kind == HEAAC_ADTS_FRAME;
+            }
+            if (np < 0 || (np <= 64 && at != total)) adts_bad++;
+            (void)heaac_adts_probe(buf, total);
+            free(buf); free(au);
+            continue;
+        }
+        if (k >= 3) {
+            /* coupling / program config elements: the wide entry; whatever the status, a record that says `present`
+             * stays inside its arrays */
+            memset(&info, 0, sizeof(info));
+            const int r = heaac_aac_parse_frame_ex(&wide[k - 3], &wst[k - 3], au, (int)len, 2, coeffs, ics, tools, &co, &info);
+            free(au);
+            if (r >= 0) ok++; else err++;
+            if (r == HEAAC_PARSE_OK) {
+                for (int s2 = 0; s2 < HEAAC_MAX_CCE; s2++) {
+                    const HeaacCceFrame *c = &cce[s2];
+                    if (!c->present) continue;
+                    coupled++;
+                    int v = c->n_links > HEAAC_MAX_CCE_LINKS || (c->coupling_point != 0 && c->coupling_point != 1 && c->coupling_point != 3) ||
+                            c->ics.num_window_groups < 1 || c->ics.num_window_groups > 8 || c->ics.max_sfb > c->ics.num_swb ||
+                            c->ics.num_window_groups * c->ics.max_sfb > 120 || c->seq >= HEAAC_MAX_CCE;
+                    int wins = 0;
+                    for (int g = 0; g < c->ics.num_window_groups && g < 8; g++) wins += c->ics.group_len[g];
+                    v |= wins != c->ics.num_windows;
+                    for (int i = 0; i < c->ics.max_sfb && i < 63; i++) v |= c->ics.swb_offset[i] >= c->ics.swb_offset[i + 1];
+                    v |= c->ics.max_sfb && c->ics.swb_offset[c->ics.max_sfb] > (c->ics.num_windows == 8 ? 128 : 1024);
+                    for (int l = 0; l < c->n_links && l < HEAAC_MAX_CCE_LINKS; l++) v |= c->link[l].target_ch > 1;
+                    if (v) { bad_records++; if (bad_records < 5) printf("iteration %ld: coupling record out of range\n", it); }
+                }
+            }
+            continue;
+        }
         memset(&sbr, 0, sizeof(sbr)); memset(&ps, 0, sizeof(ps));
         const int r = heaac_heaac_parse_frame(&cfg[k], &ast[k], &sst[k], tab, au, (int)len, coeffs, ics, tools,
                                               &sbr, k == 2 ? &ps : NULL, &info);
@@ -81,6 +145,9 @@ int main(int argc, char **argv)
     }
     printf("iterations %ld: parsed %ld, refused %ld, frames with start = 1: %ld, headers %zu, invalid records %ld\n",
            iters, ok, err, started, heaac_sbr_table_count(tab), bad_records);
+    printf("coupling elements parsed %ld, ADTS frames delivered %ld, ADTS walks that did not tile %ld\n", coupled, adts_frames, adts_bad);
+    if (adts_bad) return 1;
+    free(cce); free(cce_coeffs); free(cce_tools);
     heaac_sbr_table_destroy(tab);
     free(sst); free(coeffs); free(tools);
     for (int i = 0; i < ns; i++) free(seed[i].data);
