@@ -281,7 +281,7 @@ struct SynLdsT {
 };
 typedef SynLdsT<SYN_WAVES> SynLds;
 
-#ifdef HEAAC_TUNING
+#ifdef HEAAC_STAMPS
 #define SSTAMP(i) TL_STAMP(i, (i) == 0)
 #else
 #define SSTAMP(i) do {} while (0)
@@ -797,7 +797,7 @@ extern "C" int heaac_launch_qmf_synthesis_ds(const float *d_tab, const float *d_
 }
 
 
-#ifdef HEAAC_TUNING
+#ifdef HEAAC_STAMPS
 // accumulated phase timeline of this translation unit's kernels (k_synth): out[0..31] cycles, out[32] units
 extern "C" int heaac_debug_timeline_he(unsigned long long *out)
 {

@@ -7,8 +7,8 @@
 
 #define ENV_ADJ 2          // ENVELOPE_ADJUSTMENT_OFFSET, aacsbr.c:39
 
-#ifdef HEAAC_TUNING
-// Phase timeline (-DHEAAC_TUNING diagnostic builds only): wave 0 of every 8th workgroup accumulates the cycles
+#ifdef HEAAC_STAMPS
+// Phase timeline (-DHEAAC_STAMPS diagnostic builds only): wave 0 of every 8th workgroup accumulates the cycles
 // between consecutive stamps over all the frames it processes; slot 31 = time between frames.
 static __device__ unsigned long long g_tl_acc[32], g_tl_last[256], g_tl_cnt;
 #define TL_STAMP(i, is_first) do { wave_sync(); \

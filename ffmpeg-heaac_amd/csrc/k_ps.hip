@@ -217,7 +217,7 @@ extern "C" int heaac_launch_hfps(const float *d_tab, const HeaacSbrFrame *d_sbr,
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
 }
 
-#ifdef HEAAC_TUNING
+#ifdef HEAAC_STAMPS
 // accumulated phase timeline of the fused kernel: out[0..31] cycles per phase, out[32] frames
 extern "C" int heaac_debug_timeline(unsigned long long *out)
 {

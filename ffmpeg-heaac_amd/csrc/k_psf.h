@@ -5,7 +5,7 @@
 #include "heaac_dsp.h"
 #include "k_hf.h"
 
-#ifdef HEAAC_TUNING
+#ifdef HEAAC_STAMPS
 #define STAMP(i) TL_STAMP(16 + (i), false)
 #else
 #define STAMP(i) do {} while (0)

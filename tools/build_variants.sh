@@ -15,4 +15,4 @@ build() {   # name, flags, sed script
     if [ -n "$VARIANT_EDIT" ]; then python3 "$VARIANT_EDIT" /tmp/csrc_$1 "$1"; fi
     make -C /tmp/csrc_$1 -j8 -s ROOT=$root EXTRA="$2" OUT=$root/ab/lib$1.so
 }
-if [ -n "$1" ]; then build "$1" "$2" "$VARIANT_SED"; else build stamps "-DHEAAC_TUNING" ""; fi
+if [ -n "$1" ]; then build "$1" "$2" "$VARIANT_SED"; else build stamps "-DHEAAC_STAMPS" ""; fi

@@ -1,4 +1,4 @@
-"""Phase timeline of the fused HF + PS kernel (build with make EXTRA="-DHEAAC_TUNING").
+"""Phase timeline of the fused HF + PS kernel (build with make EXTRA="-DHEAAC_STAMPS": tools/build_variants.sh).
 N=<frames> python3 tools/hfps_stamps.py  -- cycles per frame and phase, averaged over the frames of
 wave 0 of every 8th workgroup, under full load."""
 import ctypes as C, importlib, os, sys
