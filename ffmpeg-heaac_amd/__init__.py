@@ -489,7 +489,7 @@ class Pipeline:
 
     def __init__(self, aac_cfg, he_cfg, n_streams, threads=0):
         self._h = C.c_void_p()
-        self.n, self.ch = n_streams, OUT_CH[he_cfg]
+        self.n, self.ch, self.len = n_streams, OUT_CH[he_cfg], OUT_LEN[he_cfg]
         _check(lib().heaac_pipeline_create(C.byref(self._h), C.byref(aac_cfg), he_cfg, C.c_size_t(n_streams), threads),
                "heaac_pipeline_create")
 
@@ -510,7 +510,7 @@ class Pipeline:
         """PCM of the oldest tick in flight: int16 [n][2048][channels] (a view of the pipeline's pinned buffer)."""
         p = C.POINTER(C.c_int16)()
         _check(lib().heaac_pipeline_collect(self._h, C.byref(p)), "heaac_pipeline_collect")
-        return np.ctypeslib.as_array(p, shape=(self.n, 2048, self.ch))
+        return np.ctypeslib.as_array(p, shape=(self.n, self.len, self.ch))
 
     def timing(self):
         ms = (C.c_float * 4)()

@@ -33,7 +33,7 @@ struct Set {
 
 struct HeaacPipeline {
     HeaacAacConfig aac;
-    int he_cfg, ncore, nout;
+    int he_cfg, ncore, nout, he, out_len;
     size_t n, words;
     HeaacDevice *dev;
     hipStream_t in, run, out;
@@ -61,9 +61,13 @@ static void parse_slice(HeaacPipeline *p, int w)
     const size_t lo = p->n * (size_t)w / (size_t)p->threads, hi = p->n * (size_t)(w + 1) / (size_t)p->threads;
     Set *s = p->job_set;
     for (size_t i = lo; i < hi; i++) {
-        const int r = heaac_heaac_parse_frame_ex(&p->aac, &p->ast[i], &p->sst[i], p->tab, p->job_au[i], p->job_size[i],
-                                                 p->ncore, s->h_coeffs + i * (size_t)p->ncore * 1024, s->h_ics + i * p->ncore,
-                                                 &s->h_tools[i], &s->h_sbr[i], s->h_ps ? &s->h_ps[i] : NULL, NULL);
+        const int r = p->he
+            ? heaac_heaac_parse_frame_ex(&p->aac, &p->ast[i], &p->sst[i], p->tab, p->job_au[i], p->job_size[i],
+                                         p->ncore, s->h_coeffs + i * (size_t)p->ncore * 1024, s->h_ics + i * p->ncore,
+                                         &s->h_tools[i], &s->h_sbr[i], s->h_ps ? &s->h_ps[i] : NULL, NULL)
+            : heaac_aac_parse_frame_ex(&p->aac, &p->ast[i], p->job_au[i], p->job_size[i], p->ncore,
+                                       s->h_coeffs + i * (size_t)p->ncore * 1024, s->h_ics + i * p->ncore, &s->h_tools[i],
+                                       NULL, NULL);
         if (p->job_status) p->job_status[i] = r;
     }
 }
@@ -152,17 +156,21 @@ extern "C" int heaac_pipeline_create(HeaacPipeline **out, const HeaacAacConfig *
 {
     if (!out) return HEAAC_ERR_ARG;
     *out = NULL;
-    if (!aac || !n || (he_cfg != HEAAC_CFG_HEV2 && he_cfg != HEAAC_CFG_HEV1 && he_cfg != HEAAC_CFG_HEV1_MONO) ||
+    const bool lc = he_cfg == HEAAC_CFG_LC_MONO || he_cfg == HEAAC_CFG_LC_STEREO;
+    if (!aac || !n || (!lc && he_cfg != HEAAC_CFG_HEV2 && he_cfg != HEAAC_CFG_HEV1 && he_cfg != HEAAC_CFG_HEV1_MONO) ||
         aac->sampling_index < 0 || aac->sampling_index > 12)
         return HEAAC_ERR_ARG;
     HeaacPipeline *p = (HeaacPipeline *)calloc(1, sizeof(*p));
     if (!p) return HEAAC_ERR_NOMEM;
     p->aac = *aac;
     p->he_cfg = he_cfg;
-    p->ncore = he_cfg == HEAAC_CFG_HEV1 ? 2 : 1;
-    p->nout = he_cfg == HEAAC_CFG_HEV1_MONO ? 1 : 2;
-    p->words = he_cfg == HEAAC_CFG_HEV1 ? HEAAC_STATE_WORDS_HEV1 : he_cfg == HEAAC_CFG_HEV2 ? HEAAC_STATE_WORDS_HEV2
-                                                                                           : HEAAC_STATE_WORDS_HEV1_MONO;
+    p->he = !lc;
+    p->out_len = lc ? 1024 : 2048;
+    p->ncore = (he_cfg == HEAAC_CFG_HEV1 || he_cfg == HEAAC_CFG_LC_STEREO) ? 2 : 1;
+    p->nout = (he_cfg == HEAAC_CFG_HEV1_MONO || he_cfg == HEAAC_CFG_LC_MONO) ? 1 : 2;
+    p->words = he_cfg == HEAAC_CFG_HEV1 ? HEAAC_STATE_WORDS_HEV1 : he_cfg == HEAAC_CFG_HEV2 ? HEAAC_STATE_WORDS_HEV2 :
+               he_cfg == HEAAC_CFG_HEV1_MONO ? HEAAC_STATE_WORDS_HEV1_MONO :
+               he_cfg == HEAAC_CFG_LC_STEREO ? HEAAC_STATE_WORDS_LC_STEREO : HEAAC_STATE_WORDS_LC_MONO;
     p->n = n;
     int rc = heaac_device_create(&p->dev, n);
     if (rc != HEAAC_OK) { free(p); return rc; }
@@ -174,18 +182,21 @@ extern "C" int heaac_pipeline_create(HeaacPipeline **out, const HeaacAacConfig *
         Set *s = &p->set[k];
         const size_t nc = n * (size_t)p->ncore;
         ok = pinned((void **)&s->h_coeffs, nc * 4096) && pinned((void **)&s->h_ics, nc * sizeof(HeaacIcs)) &&
-             pinned((void **)&s->h_tools, n * sizeof(HeaacToolsFrame)) && pinned((void **)&s->h_sbr, n * sizeof(HeaacSbrFrame)) &&
+             pinned((void **)&s->h_tools, n * sizeof(HeaacToolsFrame)) &&
+             (!p->he || pinned((void **)&s->h_sbr, n * sizeof(HeaacSbrFrame))) &&
              (!with_ps || pinned((void **)&s->h_ps, n * sizeof(HeaacPsFrame))) &&
-             pinned((void **)&s->h_pcm, n * (size_t)p->nout * 2048 * 2) &&
+             pinned((void **)&s->h_pcm, n * (size_t)p->nout * p->out_len * 2) &&
              devmem((void **)&s->d_coeffs, nc * 4096) && devmem((void **)&s->d_ics, nc * sizeof(HeaacIcs)) &&
-             devmem((void **)&s->d_tools, n * sizeof(HeaacToolsFrame)) && devmem((void **)&s->d_sbr, n * sizeof(HeaacSbrFrame)) &&
+             devmem((void **)&s->d_tools, n * sizeof(HeaacToolsFrame)) &&
+             (!p->he || devmem((void **)&s->d_sbr, n * sizeof(HeaacSbrFrame))) &&
              (!with_ps || devmem((void **)&s->d_ps, n * sizeof(HeaacPsFrame))) &&
-             devmem((void **)&s->d_pcm, n * (size_t)p->nout * 2048 * 2) &&
+             devmem((void **)&s->d_pcm, n * (size_t)p->nout * p->out_len * 2) &&
              hipEventCreate(&s->in_start) == hipSuccess && hipEventCreate(&s->in_done) == hipSuccess &&
              hipEventCreate(&s->run_done) == hipSuccess && hipEventCreate(&s->out_done) == hipSuccess;
         if (ok) {
             memset(s->h_coeffs, 0, nc * 4096); memset(s->h_ics, 0, nc * sizeof(HeaacIcs));
-            memset(s->h_tools, 0, n * sizeof(HeaacToolsFrame)); memset(s->h_sbr, 0, n * sizeof(HeaacSbrFrame));
+            memset(s->h_tools, 0, n * sizeof(HeaacToolsFrame));
+            if (p->he) memset(s->h_sbr, 0, n * sizeof(HeaacSbrFrame));
             if (with_ps) memset(s->h_ps, 0, n * sizeof(HeaacPsFrame));
             ok = hipMemset(s->d_tools, 0, n * sizeof(HeaacToolsFrame)) == hipSuccess;
         }
@@ -286,7 +297,7 @@ extern "C" int heaac_pipeline_submit(HeaacPipeline *p, const uint8_t *const *au,
     } else {
         HIP_OK(hipMemcpyAsync(s->d_tools, s->h_tools, n * sizeof(HeaacToolsFrame), hipMemcpyHostToDevice, p->in));
     }
-    HIP_OK(hipMemcpyAsync(s->d_sbr, s->h_sbr, n * sizeof(HeaacSbrFrame), hipMemcpyHostToDevice, p->in));
+    if (p->he) HIP_OK(hipMemcpyAsync(s->d_sbr, s->h_sbr, n * sizeof(HeaacSbrFrame), hipMemcpyHostToDevice, p->in));
     if (s->d_ps) HIP_OK(hipMemcpyAsync(s->d_ps, s->h_ps, n * sizeof(HeaacPsFrame), hipMemcpyHostToDevice, p->in));
     HIP_OK(hipEventRecord(s->in_done, p->in));
     // GPU
@@ -295,13 +306,15 @@ extern "C" int heaac_pipeline_submit(HeaacPipeline *p, const uint8_t *const *au,
     int rc = heaac_spectral_tools_batch(p->dev, p->ncore, s->d_coeffs, s->d_tools, p->d_rng, p->d_rng, NULL, NULL, n,
                                         (void *)p->run);
     if (rc == HEAAC_OK)
-        rc = heaac_he_decode_batch(p->dev, p->he_cfg, s->d_coeffs, s->d_ics, s->d_sbr, p->d_hdr, PL_MAX_HDRS, s->d_ps,
-                                   p->d_state, p->d_state, s->d_pcm, HEAAC_PCM_S16_INTERLEAVED, n, (void *)p->run);
+        rc = p->he ? heaac_he_decode_batch(p->dev, p->he_cfg, s->d_coeffs, s->d_ics, s->d_sbr, p->d_hdr, PL_MAX_HDRS, s->d_ps,
+                                           p->d_state, p->d_state, s->d_pcm, HEAAC_PCM_S16_INTERLEAVED, n, (void *)p->run)
+                   : heaac_lc_decode_batch(p->dev, p->ncore, s->d_coeffs, s->d_ics, p->d_state, p->d_state, s->d_pcm,
+                                           HEAAC_PCM_S16_INTERLEAVED, n, (void *)p->run);
     if (rc != HEAAC_OK) return rc;
     HIP_OK(hipEventRecord(s->run_done, p->run));
     // D2H
     HIP_OK(hipStreamWaitEvent(p->out, s->run_done, 0));
-    HIP_OK(hipMemcpyAsync(s->h_pcm, s->d_pcm, n * (size_t)p->nout * 2048 * 2, hipMemcpyDeviceToHost, p->out));
+    HIP_OK(hipMemcpyAsync(s->h_pcm, s->d_pcm, n * (size_t)p->nout * p->out_len * 2, hipMemcpyDeviceToHost, p->out));
     HIP_OK(hipEventRecord(s->out_done, p->out));
     s->used = 1;
     p->submitted++;

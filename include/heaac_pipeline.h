@@ -9,7 +9,8 @@
  * device) lives in the pipeline.
  *
  * What it does per tick is exactly heaac_heaac_parse_frame + heaac_spectral_tools_batch + heaac_he_decode_batch
- * (HEAAC_PCM_S16_INTERLEAVED) for every stream; tests compare it with those calls made one after the other.
+ * (for plain AAC-LC streams: heaac_aac_parse_frame + tools + heaac_lc_decode_batch), HEAAC_PCM_S16_INTERLEAVED, for
+ * every stream; tests compare it with those calls made one after the other.
  * The reference has no counterpart: its decoder handles one packet of one stream per call
  * (avcodec_decode_audio3, libavcodec/utils.c:638-663).
  */
@@ -28,8 +29,10 @@ extern "C" {
 typedef struct HeaacPipeline HeaacPipeline;
 #define HEAAC_PIPELINE_DEPTH 4        /* ticks that may be in flight (submitted, not yet collected) */
 
-/* aac: the configuration all streams share (AudioSpecificConfig as heaac_asc_parse leaves it; sbr = 1).
- * he_cfg: HEAAC_CFG_HEV2 (mono core + SBR + PS), HEAAC_CFG_HEV1_MONO or HEAAC_CFG_HEV1 (pair).
+/* aac: the configuration all streams share (AudioSpecificConfig as heaac_asc_parse leaves it; sbr = 1 for the
+ * HE configurations).
+ * he_cfg: HEAAC_CFG_HEV2 (mono core + SBR + PS), HEAAC_CFG_HEV1_MONO, HEAAC_CFG_HEV1 (pair), or HEAAC_CFG_LC_MONO /
+ *         HEAAC_CFG_LC_STEREO (no SBR: 1024 samples per channel and tick).
  * threads: parser threads (<= 0: the CPUs the process may use -- online CPUs, capped at twice a cgroup CPU quota;
  *          at most 256).
  * HEAAC_ERR_NODEVICE without a usable device. */
@@ -42,7 +45,7 @@ void heaac_pipeline_destroy(HeaacPipeline *p);
  * HEAAC_PIPELINE_DEPTH ticks may be in flight: one more submit before a collect returns HEAAC_ERR_ARG. */
 int heaac_pipeline_submit(HeaacPipeline *p, const uint8_t *const *au, const int *size, int *status);
 
-/* Waits for the OLDEST tick in flight and hands out its PCM: [n_streams][2048][channels] int16 in pinned memory
+/* Waits for the OLDEST tick in flight and hands out its PCM: [n_streams][2048 (LC: 1024)][channels] int16 in pinned memory
  * owned by the pipeline, valid until HEAAC_PIPELINE_DEPTH more ticks have been submitted. */
 int heaac_pipeline_collect(HeaacPipeline *p, const int16_t **pcm);
 

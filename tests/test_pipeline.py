@@ -18,7 +18,7 @@ def test_create_checks_arguments_and_fails_loudly_without_a_device(pkg):
     lib = pkg.lib()
     h = C.c_void_p(1)
     cfg = TS._he_cfg(pkg, 1, True)
-    assert lib.heaac_pipeline_create(C.byref(h), C.byref(cfg), pkg.CFG_LC_STEREO, C.c_size_t(4), 1) == -1 and not h.value
+    assert lib.heaac_pipeline_create(C.byref(h), C.byref(cfg), 99, C.c_size_t(4), 1) == -1 and not h.value
     assert lib.heaac_pipeline_create(C.byref(h), None, pkg.CFG_HEV2, C.c_size_t(4), 1) == -1
     assert lib.heaac_pipeline_create(C.byref(h), C.byref(cfg), pkg.CFG_HEV2, C.c_size_t(0), 1) == -1
     if not torch.cuda.is_available():
@@ -40,6 +40,36 @@ def _ticks(pkg, rng, channels, ps, n, ticks):
             aus.append(TP._write_au(rng, 6, 2, channels == 2, extras=False, sbr=(bits, False), quiet=True)[0])
         out.append(aus)
     return out
+
+
+@pytest.mark.gpu
+def test_pipeline_on_plain_aac_lc_streams(pkg, dev):
+    """AAC-LC stereo streams (no SBR): parse + tools + heaac_lc_decode_batch per tick."""
+    import torch
+    rng = np.random.default_rng(8)
+    n, ticks, si = 29, 6, 3
+    aus = [[TP._write_au(rng, si, 2, True, extras=True, quiet=True)[0] for _ in range(n)] for _ in range(ticks)]
+    cfg = TP._cfg(pkg, 2, si, 2)
+    pl = pkg.Pipeline(cfg, pkg.CFG_LC_STEREO, n, threads=2)
+    st = np.zeros(n, pkg.AAC_STREAM_DT)
+    d_state = torch.zeros((n, 1024), device="cuda")
+    d_rng = torch.full((n,), 0x1f2e3d4c, dtype=torch.int32, device="cuda")
+    got = []
+    for t in range(ticks):
+        pl.submit(aus[t])
+        if t >= 2:
+            got.append(pl.collect().copy())
+    while len(got) < ticks:
+        got.append(pl.collect().copy())
+    for t in range(ticks):
+        q = pkg.aac_parse_batch(cfg, st, aus[t], threads=1)
+        assert q["failed"] == 0
+        coeffs = torch.from_numpy(q["coeffs"]).cuda()
+        dev.spectral_tools(2, coeffs, pkg.to_device(q["tools"]), rng=d_rng)
+        pcm, d_state = dev.lc_decode(2, coeffs, pkg.to_device(q["ics"]), d_state, pcm_format=pkg.PCM_S16)
+        torch.cuda.synchronize()
+        assert got[t].shape == (n, 1024, 2) and np.array_equal(got[t], pcm.cpu().numpy()), t
+    pl.close()
 
 
 @pytest.mark.gpu
