@@ -123,7 +123,7 @@ EXPORTED = [
     # heaac_codec.h
     "heaac_aac_decoder", "heaac_codec_open", "heaac_codec_decode", "heaac_codec_close",
     # heaac_parse.h
-    "heaac_asc_parse", "heaac_ga_specific_config", "heaac_aac_parse_frame_ex", "heaac_spectral_tools_batch_ex", "heaac_codec_get_context_defaults", "heaac_adts_parse_header", "heaac_adts_probe", "heaac_adts_split",
+    "heaac_asc_parse", "heaac_ga_specific_config", "heaac_aac_parse_frame_ex", "heaac_aac_layout_default", "heaac_aac_layout_from_pce", "heaac_asc_layout", "heaac_aac_parse_frame_layout", "heaac_spectral_tools_batch_ex", "heaac_codec_get_context_defaults", "heaac_adts_parse_header", "heaac_adts_probe", "heaac_adts_split",
     "heaac_heaac_parse_frame_ex", "heaac_pipeline_create", "heaac_pipeline_destroy", "heaac_pipeline_submit",
     "heaac_pipeline_collect", "heaac_pipeline_timing",
     "heaac_multi_shard", "heaac_multi_create", "heaac_multi_destroy", "heaac_multi_devices", "heaac_multi_device",
@@ -541,6 +541,56 @@ def aac_parse_frame_ex(cfg, stream, au, coeff_channels=2, with_cce=True):
                                        out["coeffs"].ctypes.data_as(C.c_void_p), out["ics"].ctypes.data_as(C.c_void_p),
                                        out["tools"].ctypes.data_as(C.c_void_p), C.byref(co) if with_cce else None,
                                        out["info"].ctypes.data_as(C.c_void_p))
+    return r, out
+
+
+# ---- channel layouts (several output elements per access unit) ----
+MAX_ELEMENTS = 16
+AAC_ELEM_SLOT_DT = np.dtype([("type", "u1"), ("id", "u1"), ("channels", "u1"), ("first_channel", "u1")])
+AAC_LAYOUT_DT = np.dtype([("chan_config", "<i4"), ("n_elements", "<i4"), ("channels", "<i4"), ("tags_mapped", "<i4"),
+                          ("channel_layout", "<i8"), ("elem", AAC_ELEM_SLOT_DT, (MAX_ELEMENTS,)),
+                          ("slot_of", "i1", (4, 16)), ("tag_map", "i1", (4, 16))])
+AAC_ELEM_INFO_DT = np.dtype([("present", "u1"), ("type", "u1"), ("tag", "u1"), ("seq", "u1"), ("sbr_crc", "u1"),
+                             ("pad", "u1", (3,)), ("sbr_payload_bit", "<i4"), ("sbr_payload_bytes", "<i4")])
+assert AAC_LAYOUT_DT.itemsize == 216 and AAC_ELEM_INFO_DT.itemsize == 16
+
+
+def aac_layout_default(chan_config):
+    """heaac_aac_layout_default: (status, one AAC_LAYOUT_DT record)."""
+    l = np.zeros(1, AAC_LAYOUT_DT)
+    return lib().heaac_aac_layout_default(l.ctypes.data_as(C.c_void_p), int(chan_config)), l
+
+
+def aac_layout_from_pce(buf, bit_offset):
+    """heaac_aac_layout_from_pce: (status, layout, bits used)."""
+    l = np.zeros(1, AAC_LAYOUT_DT)
+    used = C.c_int(0)
+    buf = bytes(buf)
+    r = lib().heaac_aac_layout_from_pce(l.ctypes.data_as(C.c_void_p), buf, len(buf), int(bit_offset), C.byref(used))
+    return r, l, used.value
+
+
+def asc_layout(buf):
+    """heaac_asc_layout: (status, AacConfig, layout)."""
+    c = AacConfig()
+    l = np.zeros(1, AAC_LAYOUT_DT)
+    buf = bytes(buf)
+    return lib().heaac_asc_layout(C.byref(c), l.ctypes.data_as(C.c_void_p), buf, len(buf)), c, l
+
+
+def aac_parse_frame_layout(cfg, layout, streams, au):
+    """heaac_aac_parse_frame_layout on one access unit.  layout: one AAC_LAYOUT_DT record (its tag map is updated),
+    streams: AAC_STREAM_DT [n_elements] (updated).  Returns (status, dict(coeffs [ne][2][1024], ics [ne][2], tools [ne],
+    elem [ne], info))."""
+    au = bytes(au)
+    ne = int(layout[0]["n_elements"])
+    assert streams.dtype == AAC_STREAM_DT and streams.shape[0] >= ne
+    out = dict(coeffs=np.zeros((ne, 2, 1024), np.float32), ics=np.zeros((ne, 2), ICS_DT), tools=np.zeros(ne, TOOLS_FRAME_DT),
+               elem=np.zeros(ne, AAC_ELEM_INFO_DT), info=np.zeros(1, AAC_INFO_DT))
+    r = lib().heaac_aac_parse_frame_layout(C.byref(cfg), layout.ctypes.data_as(C.c_void_p), streams.ctypes.data_as(C.c_void_p),
+                                           au, len(au), out["coeffs"].ctypes.data_as(C.c_void_p),
+                                           out["ics"].ctypes.data_as(C.c_void_p), out["tools"].ctypes.data_as(C.c_void_p),
+                                           out["elem"].ctypes.data_as(C.c_void_p), out["info"].ctypes.data_as(C.c_void_p))
     return r, out
 
 

@@ -472,6 +472,45 @@ static int read_ics(const HeaacAacConfig *cfg, Bits *b, int common_window, Heaac
 enum { TYPE_SCE, TYPE_CPE, TYPE_CCE, TYPE_LFE, TYPE_DSE, TYPE_PCE, TYPE_FIL, TYPE_END };
 enum { EXT_SBR_DATA = 0xd, EXT_SBR_DATA_CRC = 0xe };
 
+/* channel_pair_element behind its instance tag (decode_cpe, :1453-1492) without the spectral tools (GPU stages);
+ * w[2] = the two channels' window history, coeffs [2][1024] */
+static int read_cpe(const HeaacAacConfig *cfg, Bits *b, HeaacToolsFrame *tools, WinInfo *w, float *coeffs)
+{
+    int r;
+    const int common = (int)bit1(b);
+    tools->common_window = (uint8_t)common;
+    if (common) {
+        if ((r = read_ics_info(cfg, b, &tools->ch[0].ics, &tools->ch[0].pred, &w[0])) < 0) return r;
+        /* channel 1 takes channel 0's ics, keeping its own previous window shape (:1462-1464) */
+        const uint8_t kb_prev1 = w[1].use_kb_window[0];
+        w[1] = w[0];
+        w[1].use_kb_window[1] = kb_prev1;
+        tools->ch[1].ics = tools->ch[0].ics;
+        tools->ch[1].pred = tools->ch[0].pred;
+        tools->ms_present = (uint8_t)bits(b, 2);
+        if (tools->ms_present == 3) return HEAAC_PARSE_ERR_DATA;
+        const int nb = tools->ch[0].ics.num_window_groups * tools->ch[0].ics.max_sfb;
+        if (tools->ms_present == 1)
+            for (int i = 0; i < nb; i++) tools->ms_mask[i] = (uint8_t)bit1(b);
+        else if (tools->ms_present == 2)
+            memset(tools->ms_mask, 1, nb);
+    }
+    if ((r = read_ics(cfg, b, common, &tools->ch[0], &w[0], coeffs)) < 0) return r;
+    return read_ics(cfg, b, common, &tools->ch[1], &w[1], coeffs + 1024);
+}
+
+/* data_stream_element behind its tag (skip_data_stream_element, :602-620) */
+static int skip_dse(Bits *b)
+{
+    const int align = (int)bit1(b);
+    int count = (int)bits(b, 8);
+    if (count == 255) count += (int)bits(b, 8);
+    if (align) b->pos = (b->pos + 7) & ~7;
+    if (bits_left(b) < 8 * count) return HEAAC_PARSE_ERR_OVERREAD;
+    b->pos += 8 * count;
+    return HEAAC_PARSE_OK;
+}
+
 /* program_config_element: read past (decode_pce, aacdec.c:303-357).  The reference turns it into a channel
  * layout (output_configure); this slice keeps the layout of the configuration. */
 static int skip_pce(Bits *b)
@@ -650,27 +689,7 @@ int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
         case TYPE_CPE: {
             if (fi.channels) return HEAAC_PARSE_ERR_UNSUPPORTED;
             if (coeff_channels < 2) return HEAAC_PARSE_ERR_ARG;
-            /* decode_cpe (:1453-1492) without the spectral tools (GPU stages) */
-            const int common = (int)bit1(&b);
-            tools->common_window = (uint8_t)common;
-            if (common) {
-                if ((r = read_ics_info(cfg, &b, &tools->ch[0].ics, &tools->ch[0].pred, &w[0])) < 0) return r;
-                /* channel 1 takes channel 0's ics, keeping its own previous window shape (:1462-1464) */
-                const uint8_t kb_prev1 = w[1].use_kb_window[0];
-                w[1] = w[0];
-                w[1].use_kb_window[1] = kb_prev1;
-                tools->ch[1].ics = tools->ch[0].ics;
-                tools->ch[1].pred = tools->ch[0].pred;
-                tools->ms_present = (uint8_t)bits(&b, 2);
-                if (tools->ms_present == 3) return HEAAC_PARSE_ERR_DATA;
-                const int nb = tools->ch[0].ics.num_window_groups * tools->ch[0].ics.max_sfb;
-                if (tools->ms_present == 1)
-                    for (int i = 0; i < nb; i++) tools->ms_mask[i] = (uint8_t)bit1(&b);
-                else if (tools->ms_present == 2)
-                    memset(tools->ms_mask, 1, nb);
-            }
-            if ((r = read_ics(cfg, &b, common, &tools->ch[0], &w[0], coeffs)) < 0) return r;
-            if ((r = read_ics(cfg, &b, common, &tools->ch[1], &w[1], coeffs + 1024)) < 0) return r;
+            if ((r = read_cpe(cfg, &b, tools, w, coeffs)) < 0) return r;
             fi.channels = 2;
             fi.elem_id = elem_id;
             break;
@@ -705,13 +724,7 @@ int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
         case TYPE_LFE:
             return HEAAC_PARSE_ERR_UNSUPPORTED;        /* no LFE in a one- or two-channel layout */
         case TYPE_DSE: {
-            /* skip_data_stream_element (:602-620) */
-            const int align = (int)bit1(&b);
-            int count = (int)bits(&b, 8);
-            if (count == 255) count += (int)bits(&b, 8);
-            if (align) b.pos = (b.pos + 7) & ~7;
-            if (bits_left(&b) < 8 * count) return HEAAC_PARSE_ERR_OVERREAD;
-            b.pos += 8 * count;
+            if ((r = skip_dse(&b)) < 0) return r;
             break;
         }
         case TYPE_PCE:
@@ -766,6 +779,250 @@ int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
     if (info) *info = fi;
     return HEAAC_PARSE_OK;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* channel layouts: several output elements per access unit                                      */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { uint8_t type, id; } ElemRef;
+/* The channel configurations 1..7 twice: the order the elements' channels leave the decoder
+ * (aac_channel_layout_map, aacdectab.h:74-82) and the order the elements arrive in an access unit, which is what
+ * get_che maps by (:138-181: the n-th output element of the stream must have the type standing here; where a
+ * 5.1 / 7.1 layout has its LFE an SCE is taken too).  Mask = aac_channel_layout[] (aacdectab.h:84-93). */
+static const struct ChanConfig {
+    int n;
+    ElemRef out[5], arrive[5];
+    int64_t mask;
+} k_chan_config[8] = {
+    { 0, {{0, 0}}, {{0, 0}}, 0 },
+    { 1, {{TYPE_SCE, 0}},                                                        {{TYPE_SCE, 0}}, 0x4 },
+    { 1, {{TYPE_CPE, 0}},                                                        {{TYPE_CPE, 0}}, 0x3 },
+    { 2, {{TYPE_CPE, 0}, {TYPE_SCE, 0}},                                         {{TYPE_SCE, 0}, {TYPE_CPE, 0}}, 0x7 },
+    { 3, {{TYPE_CPE, 0}, {TYPE_SCE, 0}, {TYPE_SCE, 1}},                          {{TYPE_SCE, 0}, {TYPE_CPE, 0}, {TYPE_SCE, 1}}, 0x107 },
+    { 3, {{TYPE_CPE, 0}, {TYPE_SCE, 0}, {TYPE_CPE, 1}},                          {{TYPE_SCE, 0}, {TYPE_CPE, 0}, {TYPE_CPE, 1}}, 0x37 },
+    { 4, {{TYPE_CPE, 0}, {TYPE_SCE, 0}, {TYPE_LFE, 0}, {TYPE_CPE, 1}},           {{TYPE_SCE, 0}, {TYPE_CPE, 0}, {TYPE_CPE, 1}, {TYPE_LFE, 0}}, 0x3f },
+    { 5, {{TYPE_CPE, 0}, {TYPE_SCE, 0}, {TYPE_LFE, 0}, {TYPE_CPE, 2}, {TYPE_CPE, 1}},
+         {{TYPE_SCE, 0}, {TYPE_CPE, 0}, {TYPE_CPE, 1}, {TYPE_CPE, 2}, {TYPE_LFE, 0}}, 0xff },
+};
+
+static int layout_add(HeaacAacLayout *l, int type, int id)
+{
+    const int nch = type == TYPE_CPE ? 2 : 1;
+    if (l->n_elements >= HEAAC_MAX_ELEMENTS || l->channels + nch > HEAAC_MAX_LAYOUT_CHANNELS) return HEAAC_PARSE_ERR_UNSUPPORTED;
+    HeaacAacElementSlot *e = &l->elem[l->n_elements];
+    e->type = (uint8_t)type; e->id = (uint8_t)id; e->channels = (uint8_t)nch; e->first_channel = (uint8_t)l->channels;
+    l->slot_of[type][id] = (int8_t)(l->n_elements + 1);
+    l->n_elements++;
+    l->channels += nch;
+    return 0;
+}
+
+int heaac_aac_layout_default(HeaacAacLayout *l, int chan_config)
+{
+    if (!l) return HEAAC_PARSE_ERR_ARG;
+    memset(l, 0, sizeof(*l));
+    if (chan_config < 1 || chan_config > 7) return HEAAC_PARSE_ERR_DATA;   /* "invalid default channel configuration" */
+    const struct ChanConfig *c = &k_chan_config[chan_config];
+    l->chan_config = chan_config;
+    for (int i = 0; i < c->n; i++) layout_add(l, c->out[i].type, c->out[i].id);
+    l->channel_layout = c->mask;
+    return 0;
+}
+
+int heaac_aac_layout_from_pce(HeaacAacLayout *l, const uint8_t *buf, int size, int bit_offset, int *bits_used)
+{
+    if (!l || !buf || size <= 0 || bit_offset < 0) return HEAAC_PARSE_ERR_ARG;
+    Bits b;
+    bits_init(&b, buf, size);
+    skip(&b, bit_offset);
+    uint8_t have[4][16];
+    memset(have, 0, sizeof(have));
+    bits(&b, 2);                                       /* object_type */
+    bits(&b, 4);                                       /* sampling_index (a mismatch with the configuration only warns) */
+    const int num[3] = { (int)bits(&b, 4), (int)bits(&b, 4), (int)bits(&b, 4) };   /* front, side, back */
+    const int num_lfe = (int)bits(&b, 2), num_assoc = (int)bits(&b, 3), num_cc = (int)bits(&b, 4);
+    if (bit1(&b)) bits(&b, 4);                         /* mono_mixdown_tag */
+    if (bit1(&b)) bits(&b, 4);                         /* stereo_mixdown_tag */
+    if (bit1(&b)) bits(&b, 3);                         /* mixdown_coeff_index, pseudo_surround */
+    for (int g = 0; g < 3; g++)
+        for (int i = 0; i < num[g]; i++) {
+            const int pair = (int)bit1(&b);
+            have[pair ? TYPE_CPE : TYPE_SCE][bits(&b, 4)] = 1;
+        }
+    for (int i = 0; i < num_lfe; i++) have[TYPE_LFE][bits(&b, 4)] = 1;
+    skip(&b, 4 * num_assoc);
+    skip(&b, 5 * num_cc);                              /* coupling elements: not part of the output order */
+    b.pos = (b.pos + 7) & ~7;
+    const int comment = 8 * (int)bits(&b, 8);
+    if (b.over || bits_left(&b) < comment) return HEAAC_PARSE_ERR_OVERREAD;
+    skip(&b, comment);
+    memset(l, 0, sizeof(*l));
+    /* output_configure without a channel configuration (:253-268): ids ascending, per id SCE, CPE, (CCE,) LFE */
+    for (int id = 0; id < 16; id++) {
+        static const int order[3] = { TYPE_SCE, TYPE_CPE, TYPE_LFE };
+        for (int t = 0; t < 3; t++)
+            if (have[order[t]][id] && layout_add(l, order[t], id) < 0) return HEAAC_PARSE_ERR_UNSUPPORTED;
+    }
+    memcpy(l->tag_map, l->slot_of, sizeof(l->tag_map));      /* tag_che_map = che: elements are found by their tag */
+    l->tags_mapped = 4 * 16;
+    if (bits_used) *bits_used = b.pos - bit_offset;
+    return 0;
+}
+
+int heaac_asc_layout(HeaacAacConfig *c, HeaacAacLayout *l, const uint8_t *buf, int size)
+{
+    if (!c || !l) return HEAAC_PARSE_ERR_ARG;
+    const int specific = heaac_asc_parse(c, buf, size);
+    if (specific < 0) return specific;
+    /* decode_ga_specific_config (:401-452) */
+    Bits b;
+    bits_init(&b, buf, size);
+    skip(&b, specific);
+    if (bit1(&b)) return HEAAC_PARSE_ERR_UNSUPPORTED;          /* frameLengthFlag: 960/120 MDCT window */
+    if (bit1(&b)) skip(&b, 14);                                /* dependsOnCoreCoder: coreCoderDelay */
+    bit1(&b);                                                  /* extensionFlag (no ER object types here) */
+    if (b.over) return HEAAC_PARSE_ERR_OVERREAD;
+    if (c->chan_config) return heaac_aac_layout_default(l, c->chan_config);
+    skip(&b, 4);                                               /* element_instance_tag of the program config element */
+    if (b.over) return HEAAC_PARSE_ERR_OVERREAD;
+    return heaac_aac_layout_from_pce(l, buf, size, b.pos, NULL);
+}
+
+/* get_che (:113-183): the slot of the layout a bitstream element (type, tag) lands in, or -1 */
+static int layout_find(HeaacAacLayout *l, uint8_t seen[4][16], int type, int *tag_io)
+{
+    int tag = *tag_io;
+    /* "Some buggy encoders appear to set all elem_ids to zero": a tag met twice in one access unit moves up */
+    while (tag < 16 && seen[type][tag]) tag++;
+    if (tag == 16) return -1;
+    seen[type][tag] = 1;
+    *tag_io = tag;
+    if (l->tag_map[type][tag]) return l->tag_map[type][tag] - 1;
+    if (l->chan_config < 1 || l->chan_config > 7) return -1;
+    const struct ChanConfig *c = &k_chan_config[l->chan_config];
+    if (l->tags_mapped >= c->n) return -1;
+    const ElemRef want = c->arrive[l->tags_mapped];
+    if (type != want.type && !(want.type == TYPE_LFE && type == TYPE_SCE)) return -1;
+    const int slot = l->slot_of[want.type][want.id] - 1;
+    l->tag_map[type][tag] = (int8_t)(slot + 1);
+    l->tags_mapped++;
+    return slot;
+}
+
+int heaac_aac_parse_frame_layout(const HeaacAacConfig *cfg, HeaacAacLayout *layout, HeaacAacStream *st,
+                                 const uint8_t *au, int size,
+                                 float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
+                                 HeaacAacElementInfo *elem, HeaacAacFrameInfo *info)
+{
+    if (!cfg || !layout || !st || !au || size <= 0 || !coeffs || !ics || !tools || !elem ||
+        cfg->sampling_index < 0 || cfg->sampling_index > 12 ||
+        layout->n_elements < 1 || layout->n_elements > HEAAC_MAX_ELEMENTS)
+        return HEAAC_PARSE_ERR_ARG;
+    pthread_once(&g_once, tables_init);
+    if (g_tables_bad) return HEAAC_PARSE_ERR_ARG;
+    Bits b;
+    bits_init(&b, au, size);
+    if (peek(&b, 12) == 0xfff) {
+        HeaacAdtsHeader h;
+        const int hs = heaac_adts_parse_header(&h, au, size);
+        if (hs < 0) return HEAAC_PARSE_ERR_DATA;
+        if (h.num_aac_frames != 1) return HEAAC_PARSE_ERR_UNSUPPORTED;
+        if (h.sampling_index != cfg->sampling_index || h.object_type != cfg->object_type) return HEAAC_PARSE_ERR_DATA;
+        b.pos = hs * 8;
+    }
+    const int ne = layout->n_elements;
+    WinInfo w[HEAAC_MAX_ELEMENTS][2];
+    for (int e = 0; e < ne; e++)
+        for (int c = 0; c < 2; c++) {
+            w[e][c].window_sequence[0] = st[e].window_sequence[c];
+            w[e][c].use_kb_window[0] = st[e].use_kb_window[c];
+            w[e][c].window_sequence[1] = w[e][c].use_kb_window[1] = 0;
+        }
+    memset(elem, 0, (size_t)ne * sizeof(*elem));
+    for (int e = 0; e < ne; e++) elem[e].sbr_payload_bit = -1;
+    uint8_t seen[4][16];
+    memset(seen, 0, sizeof(seen));
+    int n_seen = 0, prev_slot = -1, prev_is_output = 0, type, r;
+    while ((type = (int)bits(&b, 3)) != TYPE_END) {
+        int tag = (int)bits(&b, 4);
+        int slot = -1;
+        switch (type) {
+        case TYPE_SCE:
+        case TYPE_CPE:
+        case TYPE_LFE: {
+            slot = layout_find(layout, seen, type, &tag);
+            if (slot < 0) return HEAAC_PARSE_ERR_DATA;                 /* "channel element %d.%d is not allocated" */
+            /* the element decodes as what the bitstream says it is; a pair needs a pair's slot */
+            if ((type == TYPE_CPE) != (layout->elem[slot].channels == 2)) return HEAAC_PARSE_ERR_DATA;
+            HeaacToolsFrame *t = &tools[slot];
+            memset(t, 0, sizeof(*t));
+            float *co = coeffs + (size_t)slot * 2048;
+            if (type == TYPE_CPE) r = read_cpe(cfg, &b, t, w[slot], co);
+            else r = read_ics(cfg, &b, 0, &t->ch[0], &w[slot][0], co);
+            if (r < 0) return r;
+            elem[slot].present = 1;
+            elem[slot].type = (uint8_t)type;
+            elem[slot].tag = (uint8_t)tag;
+            elem[slot].seq = (uint8_t)n_seen++;
+            break;
+        }
+        case TYPE_CCE:
+            return HEAAC_PARSE_ERR_UNSUPPORTED;
+        case TYPE_DSE:
+            if ((r = skip_dse(&b)) < 0) return r;
+            break;
+        case TYPE_PCE:
+            if ((r = skip_pce(&b)) < 0) return r;
+            break;
+        case TYPE_FIL: {
+            int cnt = tag;
+            if (cnt == 15) cnt += (int)bits(&b, 8) - 1;
+            if (bits_left(&b) < 8 * cnt) return HEAAC_PARSE_ERR_OVERREAD;
+            if (cnt > 0) {
+                const int ext = (int)bits(&b, 4);
+                if (ext == EXT_SBR_DATA || ext == EXT_SBR_DATA_CRC) {
+                    /* decode_extension_payload (:1650-1690) hands the payload to the element in front of it */
+                    if (prev_slot < 0) return HEAAC_PARSE_ERR_DATA;    /* "SBR was found before the first channel element" */
+                    if (!prev_is_output) return HEAAC_PARSE_ERR_UNSUPPORTED;
+                    if (elem[prev_slot].type != TYPE_LFE) {
+                        elem[prev_slot].sbr_payload_bit = b.pos;
+                        elem[prev_slot].sbr_payload_bytes = cnt;
+                        elem[prev_slot].sbr_crc = ext == EXT_SBR_DATA_CRC;
+                    }
+                }
+                b.pos += 8 * cnt - 4;
+            }
+            break;
+        }
+        default:
+            return HEAAC_PARSE_ERR_UNSUPPORTED;
+        }
+        if (slot >= 0) prev_slot = slot;
+        prev_is_output = slot >= 0;
+        if (b.over) return HEAAC_PARSE_ERR_OVERREAD;
+        if (bits_left(&b) < 3) return HEAAC_PARSE_ERR_OVERREAD;
+    }
+    if (!n_seen) return HEAAC_PARSE_ERR_DATA;
+    for (int e = 0; e < ne; e++) {
+        if (!elem[e].present) continue;
+        for (int c = 0; c < layout->elem[e].channels; c++) {
+            HeaacIcs *o = &ics[e * 2 + c];
+            o->window_sequence[0] = w[e][c].window_sequence[0];
+            o->window_sequence[1] = w[e][c].window_sequence[1];
+            o->use_kb_window[0] = w[e][c].use_kb_window[0];
+            o->use_kb_window[1] = w[e][c].use_kb_window[1];
+            st[e].window_sequence[c] = w[e][c].window_sequence[0];
+            st[e].use_kb_window[c] = w[e][c].use_kb_window[0];
+        }
+    }
+    if (info) {
+        memset(info, 0, sizeof(*info));
+        info->channels = layout->channels;
+        info->bits_consumed = b.pos;
+        info->sbr_payload_bit = -1;
+    }
+    return HEAAC_PARSE_OK;
+}
+
 
 /* ------------------------------------------------------------------------------------------ */
 /* batch over streams                                                                            */

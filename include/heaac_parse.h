@@ -164,6 +164,86 @@ int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
                              float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
                              const HeaacCceOut *cce, HeaacAacFrameInfo *info);
 
+/* ---- channel layouts: several output elements per access unit (widened) ------------------
+ *   heaac_aac_layout_default      set_default_channel_config + output_configure     aacdec.c:359-398, :224-276
+ *   heaac_aac_layout_from_pce     decode_pce + output_configure (channel_config 0)  :303-357
+ *   heaac_aac_parse_frame_layout  aac_decode_frame's element loop with get_che      :113-183, :1999-2075
+ * A layout is the list of the output elements (SCE / CPE / LFE) in the order their channels leave the decoder
+ * (che_configure: `output_data[channels++]`), plus what get_che needs to find an element of the bitstream in it:
+ * for the channel configurations 1..7 the elements are taken BY POSITION -- the n-th output element of a stream must
+ * be of the type the configuration has there, whatever its instance tag, and keeps that tag from then on -- for a
+ * program config element by (type, tag).  Coupling channel elements are not part of a layout here
+ * (HEAAC_PARSE_ERR_UNSUPPORTED in heaac_aac_parse_frame_layout; heaac_aac_parse_frame_ex has them for one- and
+ * two-channel streams). */
+enum { HEAAC_ELEM_SCE = 0, HEAAC_ELEM_CPE = 1, HEAAC_ELEM_CCE = 2, HEAAC_ELEM_LFE = 3 };
+#define HEAAC_MAX_ELEMENTS 16     /* output elements of one layout (channel configuration 7 has five) */
+#define HEAAC_MAX_LAYOUT_CHANNELS 16
+
+typedef struct HeaacAacElementSlot {
+    uint8_t type;                 /* HEAAC_ELEM_SCE / _CPE / _LFE */
+    uint8_t id;                   /* which element of that type (the index into the reference's che[type][]) */
+    uint8_t channels;             /* 1 or 2 */
+    uint8_t first_channel;        /* position of its first channel in the interleaved output */
+} HeaacAacElementSlot;
+
+typedef struct HeaacAacLayout {
+    int32_t chan_config;          /* 1..7, or 0: from a program config element */
+    int32_t n_elements;
+    int32_t channels;             /* avctx->channels */
+    int32_t tags_mapped;          /* get_che: output elements of the stream met so far (configurations 1..7) */
+    int64_t channel_layout;       /* avctx->channel_layout: aac_channel_layout[] (aacdectab.h:84-93), 0 for a PCE */
+    HeaacAacElementSlot elem[HEAAC_MAX_ELEMENTS];   /* in output order */
+    int8_t  slot_of[4][16];       /* (type, id) -> index into elem[] + 1; 0: not in the layout */
+    int8_t  tag_map[4][16];       /* get_che's tag_che_map: (type, instance tag) -> index into elem[] + 1; 0: not met yet */
+} HeaacAacLayout;
+
+/* The layout of channel configuration 1..7 (SCE = centre, CPE 0 = left / right ... in the reference's output order:
+ * 5.1 leaves as L R C LFE Ls Rs).  Returns 0, or HEAAC_PARSE_ERR_DATA for another value. */
+int heaac_aac_layout_default(HeaacAacLayout *l, int chan_config);
+
+/* The layout a program_config_element describes: `bit_offset` = the element's first bit behind its 4-bit instance
+ * tag (in an access unit: behind the 3-bit element type and the tag; in a GASpecificConfig: where
+ * heaac_ga_specific_config found channel configuration 0 -- use heaac_asc_layout).  Output order as
+ * output_configure builds it: ids ascending, for every id SCE, CPE, then LFE.  *bits_used (may be NULL) receives the
+ * element's length.  HEAAC_PARSE_ERR_OVERREAD when the buffer ends inside it, HEAAC_PARSE_ERR_UNSUPPORTED for more
+ * than HEAAC_MAX_LAYOUT_CHANNELS channels. */
+int heaac_aac_layout_from_pce(HeaacAacLayout *l, const uint8_t *buf, int size, int bit_offset, int *bits_used);
+
+/* AudioSpecificConfig -> configuration and layout in one step (decode_audio_specific_config, aacdec.c:462-493):
+ * heaac_asc_parse, the GASpecificConfig checks, and the layout of its channel configuration or of the program
+ * config element it carries.  Returns 0 or a negative HEAAC_PARSE_ERR_*. */
+int heaac_asc_layout(HeaacAacConfig *c, HeaacAacLayout *l, const uint8_t *buf, int size);
+
+/* One output element of an access unit, as heaac_aac_parse_frame_layout found it */
+typedef struct HeaacAacElementInfo {
+    uint8_t present;              /* the access unit carried this element */
+    uint8_t type;                 /* its type in the bitstream (an SCE may stand where a 5.1 / 7.1 layout has its LFE, :146-152) */
+    uint8_t tag;                  /* its instance tag in the bitstream */
+    uint8_t seq;                  /* position among the access unit's output elements (bitstream order: the order the
+                                   * noise generator of heaac_spectral_tools_batch has to run through them) */
+    uint8_t sbr_crc;
+    uint8_t pad[3];
+    int32_t sbr_payload_bit;      /* as in HeaacAacFrameInfo: the EXT_SBR_DATA fill payload DIRECTLY behind the element,
+                                   * -1: none.  Behind an LFE the reference's SBR reader refuses the payload and the
+                                   * element stays "pure upsampling" (aacsbr.c:989-1000): reported as none. */
+    int32_t sbr_payload_bytes;
+} HeaacAacElementInfo;
+
+/* One access unit of a multi-element stream.  Everything is per slot of the layout (index into layout->elem[]):
+ *   st [n_elements]              window history per element (zero-initialise for a new stream)
+ *   coeffs [n_elements][2][1024], ics [n_elements][2], tools [n_elements], elem [n_elements]
+ * The layout's tag map is updated as get_che updates tag_che_map.  An in-band program config element is read
+ * past (the reference ignores it too once the layout is settled, :2041-2043).  info->channels = the layout's.
+ * Returns HEAAC_PARSE_OK; HEAAC_PARSE_ERR_DATA for an element the layout has no place for ("channel element is
+ * not allocated", :2006-2010); HEAAC_PARSE_ERR_UNSUPPORTED for a coupling channel element and for an SBR payload
+ * that does not directly follow its element (the reference hands such a payload to its SBR reader with the type of
+ * the data / fill element in between, which switches that element's SBR off); other errors as heaac_aac_parse_frame.  On error the stream states are left as they were (the tag map keeps what it learned, as
+ * the reference's does). */
+int heaac_aac_parse_frame_layout(const HeaacAacConfig *cfg, HeaacAacLayout *layout, HeaacAacStream *st,
+                                 const uint8_t *au, int size,
+                                 float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
+                                 HeaacAacElementInfo *elem, HeaacAacFrameInfo *info);
+
 /* n independent streams, one access unit each, on `threads` host threads (<= 0: one per online CPU).
  *   au[n], size[n]         access units
  *   coeffs [n][2][1024], ics [n][2], tools [n], info [n] (may be NULL), status [n] per-frame result

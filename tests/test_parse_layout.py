@@ -1,0 +1,337 @@
+"""Channel layouts with several output elements per access unit (csrc/aac_parse.c: heaac_aac_layout_default,
+heaac_aac_layout_from_pce, heaac_asc_layout, heaac_aac_parse_frame_layout) against what the reference does
+(aacdec.c:113-183 get_che, :192-276 che_configure / output_configure, :303-357 decode_pce, :359-398
+set_default_channel_config; aacdectab.h:72-93): the expectations below are stated from those tables and rules, the
+access units come from the test bit writer."""
+import numpy as np
+import pytest
+
+import aac_bitwriter as W
+import test_parse as TP
+
+SCE, CPE, CCE, LFE = 0, 1, 2, 3
+# channel configuration -> (elements in output order, channel mask, elements in bitstream order)
+CONFIGS = {
+    1: ([(SCE, 0)], 0x4, [(SCE, 0)]),
+    2: ([(CPE, 0)], 0x3, [(CPE, 0)]),
+    3: ([(CPE, 0), (SCE, 0)], 0x7, [(SCE, 0), (CPE, 0)]),
+    4: ([(CPE, 0), (SCE, 0), (SCE, 1)], 0x107, [(SCE, 0), (CPE, 0), (SCE, 1)]),
+    5: ([(CPE, 0), (SCE, 0), (CPE, 1)], 0x37, [(SCE, 0), (CPE, 0), (CPE, 1)]),
+    6: ([(CPE, 0), (SCE, 0), (LFE, 0), (CPE, 1)], 0x3f, [(SCE, 0), (CPE, 0), (CPE, 1), (LFE, 0)]),
+    7: ([(CPE, 0), (SCE, 0), (LFE, 0), (CPE, 2), (CPE, 1)], 0xff, [(SCE, 0), (CPE, 0), (CPE, 1), (CPE, 2), (LFE, 0)]),
+}
+
+
+def slots(l):
+    return [(int(e["type"]), int(e["id"])) for e in l[0]["elem"][:int(l[0]["n_elements"])]]
+
+
+def test_default_layouts_have_the_reference_order(pkg):
+    for cc, (out, mask, _) in CONFIGS.items():
+        r, l = pkg.aac_layout_default(cc)
+        assert r == 0 and slots(l) == out and int(l[0]["channel_layout"]) == mask
+        first = 0
+        for e, (t, _) in zip(l[0]["elem"], out):
+            assert int(e["first_channel"]) == first and int(e["channels"]) == (2 if t == CPE else 1)
+            first += 2 if t == CPE else 1
+        assert int(l[0]["channels"]) == first == (8 if cc == 7 else cc)
+    for bad in (0, 8, -1, 15):
+        assert pkg.aac_layout_default(bad)[0] == -1
+
+
+def write_elem(bw, rng, si, aot, typ, tag, quiet=True):
+    """One SCE / CPE / LFE; returns (channel dicts, expected scalefactors, common_window info)."""
+    ch = [W.random_ics(rng, si, aot, allow_intensity=False, quiet=quiet)]
+    bw.put(typ, 3); bw.put(tag, 4)
+    if typ != CPE:
+        return ch, [W.put_ics(bw, ch[0], si, aot, 0)], None
+    common = int(rng.integers(0, 2))
+    bw.put(common, 1)
+    cw = dict(common=common, ms_present=0, ms_mask=np.zeros(128, np.uint8))
+    if common:
+        ch.append(TP._redraw_like(rng, ch[0], si, aot, quiet))
+        W.put_ics_info(bw, ch[0], si, aot)
+        cw["ms_present"] = int(rng.integers(0, 3))
+        bw.put(cw["ms_present"], 2)
+        nb = len(ch[0]["group_len"]) * ch[0]["max_sfb"]
+        if cw["ms_present"] == 1:
+            cw["ms_mask"][:nb] = rng.integers(0, 2, nb)
+            for v in cw["ms_mask"][:nb]:
+                bw.put(int(v), 1)
+        elif cw["ms_present"] == 2:
+            cw["ms_mask"][:nb] = 1
+    else:
+        ch.append(W.random_ics(rng, si, aot, allow_intensity=True, quiet=quiet))
+    return ch, [W.put_ics(bw, ch[0], si, aot, common), W.put_ics(bw, ch[1], si, aot, common)], cw
+
+
+def write_fill(bw, rng, ext, cnt):
+    """fill_element with `cnt` payload bytes of extension type `ext`; returns the bit position behind the type."""
+    bw.put(6, 3)
+    if cnt >= 15:
+        bw.put(15, 4); bw.put(cnt - 14, 8)
+    else:
+        bw.put(cnt, 4)
+    if not cnt:
+        return -1
+    bw.put(ext, 4)
+    at = len(bw.bits)
+    for _ in range(8 * cnt - 4):
+        bw.put(int(rng.integers(0, 2)), 1)
+    return at
+
+
+def write_dse(bw, rng):
+    bw.put(4, 3); bw.put(int(rng.integers(0, 16)), 4)
+    align = int(rng.integers(0, 2)); cnt = int(rng.integers(0, 5))
+    bw.put(align, 1); bw.put(cnt, 8)
+    if align:
+        bw.align()
+    for _ in range(cnt):
+        bw.put(int(rng.integers(0, 256)), 8)
+
+
+def build(rng, si, aot, elems, sbr_prob=0.0, extras=True):
+    """elems: [(type, tag)] in bitstream order.  Returns (bytes, [per element dict])."""
+    bw = W.BitWriter()
+    out = []
+    if extras and rng.random() < 0.3:
+        write_dse(bw, rng)
+    for typ, tag in elems:
+        ch, sf, cw = write_elem(bw, rng, si, aot, typ, tag)
+        e = dict(type=typ, tag=tag, ch=ch, sf=sf, cw=cw, sbr_bit=-1, sbr_bytes=0, sbr_crc=0)
+        if rng.random() < sbr_prob:
+            crc = int(rng.integers(0, 2))
+            cnt = int(rng.integers(1, 24))
+            e.update(sbr_bit=write_fill(bw, rng, 0xe if crc else 0xd, cnt), sbr_bytes=cnt, sbr_crc=crc)
+            if rng.random() < 0.3:
+                write_fill(bw, rng, 0x1, int(rng.integers(0, 6)))       # plain fill behind the SBR payload
+        elif extras and rng.random() < 0.2:
+            write_dse(bw, rng)
+        out.append(e)
+    bw.put(7, 3)
+    return bw.bytes(), out
+
+
+def check_slot(got, slot, e, si, seq):
+    rec = got["elem"][slot]
+    assert (int(rec["present"]), int(rec["type"]), int(rec["tag"]), int(rec["seq"])) == (1, e["type"], e["tag"], seq)
+    lfe_sbr = e["type"] == LFE
+    assert int(rec["sbr_payload_bit"]) == (-1 if lfe_sbr else e["sbr_bit"])
+    if e["sbr_bit"] >= 0 and not lfe_sbr:
+        assert int(rec["sbr_payload_bytes"]) == e["sbr_bytes"] and int(rec["sbr_crc"]) == e["sbr_crc"]
+    wrapped = dict(tools=got["tools"][slot:slot + 1], ics=got["ics"][slot:slot + 1], coeffs=got["coeffs"][slot:slot + 1])
+    for c, d in enumerate(e["ch"]):
+        TP._check_channel(wrapped, 0, c, d, e["sf"][c], si)
+    if e["cw"] is not None:
+        t = got["tools"][slot]
+        assert int(t["common_window"]) == e["cw"]["common"] and int(t["ms_present"]) == e["cw"]["ms_present"]
+        nb = len(e["ch"][0]["group_len"]) * e["ch"][0]["max_sfb"]
+        assert np.array_equal(t["ms_mask"][:nb], e["cw"]["ms_mask"][:nb])
+
+
+@pytest.mark.parametrize("cc", [3, 4, 5, 6, 7])
+def test_elements_are_taken_by_position_and_keep_their_tags(pkg, cc):
+    rng = np.random.default_rng(900 + cc)
+    si, aot = 3, 2
+    cfg = TP._cfg(pkg, aot, si, cc)
+    out_order, _, arrive = CONFIGS[cc]
+    for trial in range(12):
+        r, l = pkg.aac_layout_default(cc)
+        st = np.zeros(pkg.MAX_ELEMENTS, pkg.AAC_STREAM_DT)
+        # tags of the stream: anything, distinct per type
+        tags = {}
+        for t in (SCE, CPE, LFE):
+            n = sum(1 for a in arrive if a[0] == t)
+            tags[t] = [int(x) for x in rng.choice(16, n, replace=False)]
+        used = {SCE: 0, CPE: 0, LFE: 0}
+        elems = []
+        for t, _ in arrive:
+            elems.append((t, tags[t][used[t]])); used[t] += 1
+        want_slot = [out_order.index(a) for a in arrive]
+        prev = None
+        for frame in range(4):
+            order = list(range(len(elems)))
+            if frame >= 2:
+                rng.shuffle(order)                                 # once mapped, the tag decides, not the position
+            au, exp = build(rng, si, aot, [elems[i] for i in order], sbr_prob=0.5)
+            r, got = pkg.aac_parse_frame_layout(cfg, l, st, au)
+            assert r == 0, (cc, trial, frame, r)
+            assert int(got["info"][0]["channels"]) == (8 if cc == 7 else cc)
+            for seq, (i, e) in enumerate(zip(order, exp)):
+                check_slot(got, want_slot[i], e, si, seq)
+                if prev is not None:
+                    for c, d in enumerate(e["ch"]):
+                        # a common window hands channel 1 channel 0's whole ics_info, its previous window sequence
+                        # included; only the previous window SHAPE stays channel 1's own (decode_cpe, :1462-1464)
+                        src = 0 if (c == 1 and e["cw"]["common"]) else c
+                        assert int(got["ics"][want_slot[i], c]["window_sequence"][1]) == prev[i]["ch"][src]["window_sequence"]
+                        assert int(got["ics"][want_slot[i], c]["use_kb_window"][1]) == prev[i]["ch"][c]["window_shape"]
+            prev = {i: e for i, e in zip(order, exp)}
+            assert int(l[0]["tags_mapped"]) == len(elems)
+
+
+def test_duplicate_tags_move_up_and_an_sce_may_stand_for_the_lfe(pkg):
+    rng = np.random.default_rng(31)
+    si, aot = 3, 2
+    # "Some buggy encoders appear to set all elem_ids to zero" (:115-127): the second pair with tag 0 becomes tag 1
+    r, l = pkg.aac_layout_default(5)
+    st = np.zeros(pkg.MAX_ELEMENTS, pkg.AAC_STREAM_DT)
+    au, exp = build(rng, si, aot, [(SCE, 0), (CPE, 0), (CPE, 0)], extras=False)
+    r, got = pkg.aac_parse_frame_layout(TP._cfg(pkg, aot, si, 5), l, st, au)
+    assert r == 0
+    exp[2]["tag"] = 1
+    for seq, (slot, e) in enumerate(zip([1, 0, 2], exp)):
+        check_slot(got, slot, e, si, seq)
+    # 5.1 coded as SCE CPE CPE SCE (:146-152): the last SCE lands on the LFE's place, and may carry SBR as an SCE
+    r, l = pkg.aac_layout_default(6)
+    au, exp = build(rng, si, aot, [(SCE, 0), (CPE, 0), (CPE, 1), (SCE, 1)], sbr_prob=1.0, extras=False)
+    r, got = pkg.aac_parse_frame_layout(TP._cfg(pkg, aot, si, 6), l, st, au)
+    assert r == 0
+    for seq, (slot, e) in enumerate(zip([1, 0, 3, 2], exp)):
+        check_slot(got, slot, e, si, seq)
+    assert int(got["elem"][2]["sbr_payload_bit"]) >= 0
+    # a real LFE with a payload behind it: the reference's SBR reader refuses it, the element stays without SBR
+    r, l = pkg.aac_layout_default(6)
+    au, exp = build(rng, si, aot, [(SCE, 0), (CPE, 0), (CPE, 1), (LFE, 0)], sbr_prob=1.0, extras=False)
+    r, got = pkg.aac_parse_frame_layout(TP._cfg(pkg, aot, si, 6), l, st, au)
+    assert r == 0 and int(got["elem"][2]["sbr_payload_bit"]) == -1 and int(got["elem"][3]["sbr_payload_bit"]) >= 0
+
+
+def test_what_a_layout_has_no_place_for_is_refused(pkg):
+    rng = np.random.default_rng(32)
+    si, aot = 3, 2
+    st = np.zeros(pkg.MAX_ELEMENTS, pkg.AAC_STREAM_DT)
+
+    def parse(cc, elems, **kw):
+        r, l = pkg.aac_layout_default(cc)
+        au, _ = build(rng, si, aot, elems, extras=False, **kw)
+        return pkg.aac_parse_frame_layout(TP._cfg(pkg, aot, si, cc), l, st.copy(), au)[0]
+    assert parse(3, [(CPE, 0), (SCE, 0)]) == -1            # the pair where the centre belongs
+    assert parse(3, [(SCE, 0), (CPE, 0), (CPE, 1)]) == -1  # a third element
+    assert parse(5, [(SCE, 0), (CPE, 0), (SCE, 1)]) == -1  # 4.0's back centre in a 5.0 stream
+    assert parse(6, [(SCE, 0), (CPE, 0), (LFE, 0)]) == -1  # the LFE before the back pair
+    assert parse(2, [(SCE, 0)]) == -1
+    assert parse(5, [(SCE, 0), (CPE, 0)]) == 0             # an access unit may leave elements out
+    # a coupling element: outside this entry
+    bw = W.BitWriter()
+    write_elem(bw, rng, si, aot, SCE, 0)
+    import test_parse_wide as TW
+    TW.write_cce(bw, rng, si, aot, 0, [(0, 0, 2)], 0)
+    bw.put(7, 3)
+    r, l = pkg.aac_layout_default(3)
+    assert pkg.aac_parse_frame_layout(TP._cfg(pkg, aot, si, 3), l, st.copy(), bw.bytes())[0] == -3
+    # an SBR payload in front of every element, and one behind a data stream element
+    bw = W.BitWriter()
+    write_fill(bw, rng, 0xd, 5); write_elem(bw, rng, si, aot, SCE, 0); bw.put(7, 3)
+    r, l = pkg.aac_layout_default(3)
+    assert pkg.aac_parse_frame_layout(TP._cfg(pkg, aot, si, 3), l, st.copy(), bw.bytes())[0] == -1
+    bw = W.BitWriter()
+    write_elem(bw, rng, si, aot, SCE, 0); write_dse(bw, rng); write_fill(bw, rng, 0xd, 5); bw.put(7, 3)
+    r, l = pkg.aac_layout_default(3)
+    assert pkg.aac_parse_frame_layout(TP._cfg(pkg, aot, si, 3), l, st.copy(), bw.bytes())[0] == -3
+    # a failed unit leaves the window history alone
+    r, l = pkg.aac_layout_default(3)
+    s0 = st.copy(); s0["window_sequence"][:] = 2; s0["use_kb_window"][:] = 1
+    au, _ = build(rng, si, aot, [(SCE, 0), (CPE, 0)], extras=False)
+    s1 = s0.copy()
+    assert pkg.aac_parse_frame_layout(TP._cfg(pkg, aot, si, 3), l, s1, au[:len(au) // 2])[0] < 0
+    assert s1.tobytes() == s0.tobytes()
+
+
+def write_pce_body(bw, rng, front, side, back, lfe, cc=()):
+    """program_config_element behind its instance tag; front / side / back: [(is_cpe, tag)], lfe: [tag]."""
+    bw.put(int(rng.integers(0, 4)), 2); bw.put(3, 4)
+    for g in (front, side, back):
+        bw.put(len(g), 4)
+    assoc = int(rng.integers(0, 3))
+    bw.put(len(lfe), 2); bw.put(assoc, 3); bw.put(len(cc), 4)
+    for _ in range(2):
+        f = int(rng.integers(0, 2)); bw.put(f, 1)
+        if f:
+            bw.put(int(rng.integers(0, 16)), 4)
+    f = int(rng.integers(0, 2)); bw.put(f, 1)
+    if f:
+        bw.put(int(rng.integers(0, 8)), 3)
+    for g in (front, side, back):
+        for is_cpe, tag in g:
+            bw.put(is_cpe, 1); bw.put(tag, 4)
+    for tag in lfe:
+        bw.put(tag, 4)
+    for _ in range(assoc):
+        bw.put(int(rng.integers(0, 16)), 4)
+    for ind, tag in cc:
+        bw.put(ind, 1); bw.put(tag, 4)
+    bw.align()
+    n = int(rng.integers(0, 6))
+    bw.put(n, 8)
+    for _ in range(n):
+        bw.put(int(rng.integers(0, 256)), 8)
+
+
+def test_a_program_config_element_gives_the_layout(pkg):
+    rng = np.random.default_rng(33)
+    si, aot = 3, 2
+    for trial in range(40):
+        # distinct tags per type
+        sce = [int(x) for x in rng.choice(16, int(rng.integers(0, 4)), replace=False)]
+        cpe = [int(x) for x in rng.choice(16, int(rng.integers(0, 4)), replace=False)]
+        lfe = [int(x) for x in rng.choice(16, int(rng.integers(0, 3)), replace=False)]
+        if not sce and not cpe:
+            sce = [2]
+        members = [(0, t) for t in sce] + [(1, t) for t in cpe]
+        rng.shuffle(members)
+        cut = sorted(int(x) for x in rng.integers(0, len(members) + 1, 2))
+        front, side, back = members[:cut[0]], members[cut[0]:cut[1]], members[cut[1]:]
+        lead = int(rng.integers(0, 9))
+        bw = W.BitWriter()
+        for _ in range(lead):
+            bw.put(int(rng.integers(0, 2)), 1)
+        write_pce_body(bw, rng, front, side, back, lfe, cc=[(1, 3)] * int(rng.integers(0, 2)))
+        end = len(bw.bits)
+        bw.put(0x5a, 8)
+        r, l, used = pkg.aac_layout_from_pce(bw.bytes(), lead)
+        assert r == 0 and used == end - lead
+        # output_configure without a channel configuration (:253-268): ids ascending; per id SCE, CPE, LFE
+        want = []
+        for i in range(16):
+            for t, have in ((SCE, sce), (CPE, cpe), (LFE, lfe)):
+                if i in have:
+                    want.append((t, i))
+        assert slots(l) == want and int(l[0]["channel_layout"]) == 0 and int(l[0]["chan_config"]) == 0
+        assert int(l[0]["channels"]) == len(sce) + 2 * len(cpe) + len(lfe)
+        # elements are found by (type, tag), in any order; one the element does not name is refused
+        st = np.zeros(pkg.MAX_ELEMENTS, pkg.AAC_STREAM_DT)
+        order = list(range(len(want)))
+        rng.shuffle(order)
+        au, exp = build(rng, si, aot, [want[i] for i in order], sbr_prob=0.3)
+        r, got = pkg.aac_parse_frame_layout(TP._cfg(pkg, aot, si, 0), l, st, au)
+        assert r == 0
+        for seq, (i, e) in enumerate(zip(order, exp)):
+            check_slot(got, i, e, si, seq)
+        missing = [(t, i) for t in (SCE, CPE, LFE) for i in range(16) if (t, i) not in want]
+        au, _ = build(rng, si, aot, [want[0], missing[int(rng.integers(0, len(missing)))]], extras=False)
+        assert pkg.aac_parse_frame_layout(TP._cfg(pkg, aot, si, 0), l, st, au)[0] == -1
+    # truncated
+    assert pkg.aac_layout_from_pce(bw.bytes()[:3], lead)[0] == -2
+
+
+def test_audio_specific_config_with_and_without_a_program_config_element(pkg):
+    rng = np.random.default_rng(34)
+    for cc in range(1, 8):
+        bw = W.BitWriter()
+        bw.put(2, 5); bw.put(3, 4); bw.put(cc, 4); bw.put(0, 3)
+        r, c, l = pkg.asc_layout(bw.bytes())
+        assert r == 0 and c.chan_config == cc and slots(l) == CONFIGS[cc][0]
+    bw = W.BitWriter()
+    bw.put(2, 5); bw.put(4, 4); bw.put(0, 4)              # AAC-LC, 44.1 kHz, channel configuration 0
+    bw.put(0, 1); bw.put(1, 1); bw.put(0x155, 14); bw.put(0, 1)      # 1024 samples, core coder delay, no extension
+    bw.put(9, 4)                                           # element_instance_tag
+    write_pce_body(bw, rng, [(0, 0), (1, 0)], [], [(1, 1)], [0])
+    r, c, l = pkg.asc_layout(bw.bytes())
+    assert r == 0 and c.chan_config == 0 and c.sampling_index == 4
+    assert slots(l) == [(SCE, 0), (CPE, 0), (LFE, 0), (CPE, 1)] and int(l[0]["channels"]) == 6     # C L R LFE Ls Rs (:246-250)
+    # 960-sample frames are refused as at aac_decode_init
+    bw = W.BitWriter()
+    bw.put(2, 5); bw.put(3, 4); bw.put(6, 4); bw.put(1, 1); bw.put(0, 2)
+    assert pkg.asc_layout(bw.bytes())[0] == -3
