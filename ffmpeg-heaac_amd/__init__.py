@@ -123,7 +123,7 @@ EXPORTED = [
     # heaac_codec.h
     "heaac_aac_decoder", "heaac_codec_open", "heaac_codec_decode", "heaac_codec_close",
     # heaac_parse.h
-    "heaac_asc_parse", "heaac_ga_specific_config", "heaac_aac_parse_frame_ex", "heaac_aac_layout_default", "heaac_aac_layout_from_pce", "heaac_asc_layout", "heaac_aac_parse_frame_layout", "heaac_spectral_tools_batch_ex", "heaac_codec_get_context_defaults", "heaac_adts_parse_header", "heaac_adts_probe", "heaac_adts_split",
+    "heaac_asc_parse", "heaac_ga_specific_config", "heaac_aac_parse_frame_ex", "heaac_pcm_interleave_batch", "heaac_aac_layout_default", "heaac_aac_layout_from_pce", "heaac_asc_layout", "heaac_aac_parse_frame_layout", "heaac_spectral_tools_batch_ex", "heaac_codec_get_context_defaults", "heaac_adts_parse_header", "heaac_adts_probe", "heaac_adts_split",
     "heaac_heaac_parse_frame_ex", "heaac_pipeline_create", "heaac_pipeline_destroy", "heaac_pipeline_submit",
     "heaac_pipeline_collect", "heaac_pipeline_timing",
     "heaac_multi_shard", "heaac_multi_create", "heaac_multi_destroy", "heaac_multi_devices", "heaac_multi_device",
@@ -341,6 +341,24 @@ class Device:
                "heaac_couple_after_imdct_batch")
         return out
 
+    def pcm_interleave(self, planes, length, pcm_format=None):
+        """heaac_pcm_interleave_batch.  planes: one (tensor, element offset, frame stride in floats) per output channel,
+        each tensor float32 on the device holding that channel of all n frames; returns int16 [n][length][channels]."""
+        import torch
+        fmt = PCM_S16 if pcm_format is None else pcm_format
+        ch = len(planes)
+        t0, off0, stride0 = planes[0]
+        n = (t0.numel() - off0 - length) // stride0 + 1 if stride0 else 1
+        refs = (_PlaneRef * ch)()
+        for c, (t, off, stride) in enumerate(planes):
+            assert t.dtype == torch.float32 and off + (n - 1) * stride + length <= t.numel(), "plane %d" % c
+            refs[c].d_base = t.data_ptr() + 4 * off
+            refs[c].frame_stride = stride
+        out = torch.empty((n, length, ch), dtype=torch.int16, device=t0.device)
+        _check(lib().heaac_pcm_interleave_batch(self._h, ch, refs, int(length), int(fmt), _ptr(out), C.c_size_t(n), _stream()),
+               "heaac_pcm_interleave_batch")
+        return out
+
     def he_check(self, cfg, sbr, hdr, ps=None):
         """heaac_he_check_batch on device-resident records (byte tensors as he_decode takes them):
         returns None if every frame is valid, else (first bad frame index, rule name)."""
@@ -427,6 +445,10 @@ class Device:
 # ---------------------------------------------------------------------------------------------------
 # host-side AAC parser (include/heaac_parse.h)
 # ---------------------------------------------------------------------------------------------------
+class _PlaneRef(C.Structure):
+    _fields_ = [("d_base", C.c_void_p), ("frame_stride", C.c_size_t)]
+
+
 class AacConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("object_type", "sampling_index", "sample_rate", "chan_config", "sbr",
                                        "ext_object_type", "ext_sampling_index", "ext_sample_rate",

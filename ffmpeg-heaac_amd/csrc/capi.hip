@@ -378,6 +378,19 @@ extern "C" int heaac_couple_after_imdct_batch(HeaacDevice *dev, int channels, fl
     return heaac_launch_couple(channels, d_pcm, d_cce, d_coupling, d_s16, n, (hipStream_t)stream);
 }
 
+extern "C" int heaac_pcm_interleave_batch(HeaacDevice *dev, int channels, const HeaacPlaneRef *planes, int len,
+                                          int pcm_format, int16_t *d_out, size_t n, void *stream)
+{
+    if (!dev || channels < 1 || channels > HEAAC_MAX_PCM_PLANES || len <= 0 || (len & 3) ||
+        (pcm_format != HEAAC_PCM_S16_INTERLEAVED && pcm_format != HEAAC_PCM_S16_INTERLEAVED_SSE2))
+        return HEAAC_ERR_ARG;
+    if (n == 0) return HEAAC_OK;
+    if (!planes || !d_out) return HEAAC_ERR_ARG;
+    for (int c = 0; c < channels; c++)
+        if (!planes[c].d_base || ((uintptr_t)planes[c].d_base & 15) || (planes[c].frame_stride & 3)) return HEAAC_ERR_ARG;
+    return heaac_launch_interleave(channels, planes, len, pcm_format, d_out, n, (hipStream_t)stream);
+}
+
 // Debug/test hook: device pointers of the stage workspace of the LAST chunk
 // (W[chunk][2][32][32][2], X[chunk][2][2][38][64]).  Not part of include/*.h.
 extern "C" int heaac_debug_workspace(HeaacDevice *dev, float **d_W, float **d_X, size_t *chunk)

@@ -334,6 +334,49 @@ void k_couple(float *__restrict__ g_pcm, const float *__restrict__ g_cce, const 
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_interleave: float_to_int16_interleave (dsputil.c:3989-4001) for the planes of a channel layout, elementwise and
+// HBM-bound: one lane = four consecutive samples of one frame in every channel (a float4 per plane in, 8 x channels
+// consecutive bytes out; neighbouring lanes write neighbouring pieces).
+// ---------------------------------------------------------------------------
+struct PlaneArgs {
+    const float *base[HEAAC_MAX_PCM_PLANES];
+    unsigned long long stride[HEAAC_MAX_PCM_PLANES];
+};
+template <int FMT>
+__global__ __launch_bounds__(256)
+void k_interleave(PlaneArgs p, int channels, int len, int16_t *__restrict__ g_out, unsigned long long n)
+{
+    const unsigned long long quads = (unsigned long long)(len >> 2);
+    const unsigned long long t = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long f = t / quads;
+    if (f >= n) return;
+    const unsigned long long q = t - f * quads;
+    int16_t *o = g_out + (f * (unsigned long long)len + 4 * q) * channels;
+    for (int c = 0; c < channels; c++) {
+        const float4 v = *reinterpret_cast<const float4 *>(p.base[c] + f * p.stride[c] + 4 * q);
+        o[c]                = (int16_t)pcm_int16<FMT>(v.x);
+        o[channels + c]     = (int16_t)pcm_int16<FMT>(v.y);
+        o[2 * channels + c] = (int16_t)pcm_int16<FMT>(v.z);
+        o[3 * channels + c] = (int16_t)pcm_int16<FMT>(v.w);
+    }
+}
+
+extern "C" int heaac_launch_interleave(int channels, const HeaacPlaneRef *planes, int len, int pcm_format,
+                                       int16_t *d_out, size_t n, hipStream_t stream)
+{
+    PlaneArgs a = {};
+    for (int c = 0; c < channels; c++) { a.base[c] = planes[c].d_base; a.stride[c] = planes[c].frame_stride; }
+    const unsigned long long lanes = (unsigned long long)n * (unsigned)(len >> 2);
+    const unsigned long long blocks = (lanes + 255) / 256;
+    if (blocks > 0x7fffffffull) return HEAAC_ERR_ARG;
+    if (pcm_format == HEAAC_PCM_S16_INTERLEAVED_SSE2)
+        k_interleave<HEAAC_PCM_S16_INTERLEAVED_SSE2><<<(unsigned)blocks, 256, 0, stream>>>(a, channels, len, d_out, n);
+    else
+        k_interleave<HEAAC_PCM_S16_INTERLEAVED><<<(unsigned)blocks, 256, 0, stream>>>(a, channels, len, d_out, n);
+    return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
+}
+
 extern "C" int heaac_launch_couple(int channels, float *d_pcm, const float *d_cce, const HeaacCoupling *d_cpl,
                         int16_t *d_s16, size_t n, hipStream_t stream)
 {

@@ -17,6 +17,9 @@ int heaac_launch_imdct_half(const float *d_tab, const uint16_t *d_rev, int which
 
 int heaac_launch_couple(int channels, float *d_pcm, const float *d_cce, const HeaacCoupling *d_cpl,
                         int16_t *d_s16, size_t n, hipStream_t s);
+
+int heaac_launch_interleave(int channels, const HeaacPlaneRef *planes, int len, int pcm_format, int16_t *d_out,
+                            size_t n, hipStream_t s);
 }
 
 extern "C" {

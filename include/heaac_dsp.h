@@ -292,6 +292,21 @@ typedef struct HeaacCoupling {
     uint8_t pad[2];
 } HeaacCoupling;                  /* 12 bytes */
 
+/* ------------------------------------------------------------------------
+ * float_to_int16_interleave for any channel count (dsputil.c:3989-4001 as aac_decode_frame calls it, aacdec.c:2096-2097:
+ * `output_data[]` = one plane per output channel in layout order).  The planes are the F32 outputs of the decode
+ * calls of a layout's elements (heaac_lc_decode_batch / heaac_he_decode_batch with HEAAC_PCM_F32_PLANAR: bias
+ * included): channel c of frame f starts at planes[c].d_base + f * planes[c].frame_stride and has `len` floats
+ * (1024, or 2048 behind SBR; a multiple of 4, bases and strides 16-byte aligned).
+ *   d_out [n][len][channels] int16;  pcm_format: HEAAC_PCM_S16_INTERLEAVED or HEAAC_PCM_S16_INTERLEAVED_SSE2. */
+#define HEAAC_MAX_PCM_PLANES 16
+typedef struct HeaacPlaneRef {
+    const float *d_base;
+    size_t frame_stride;          /* floats between the same channel of consecutive frames */
+} HeaacPlaneRef;
+int heaac_pcm_interleave_batch(HeaacDevice *dev, int channels, const HeaacPlaneRef *planes, int len,
+                               int pcm_format, int16_t *d_out, size_t n, void *stream);
+
 int heaac_couple_after_imdct_batch(HeaacDevice *dev, int channels, float *d_pcm, const float *d_cce,
                                    const HeaacCoupling *d_coupling, int16_t *d_s16,
                                    size_t n, void *stream);

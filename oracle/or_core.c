@@ -540,6 +540,23 @@ int oracle_float_to_int16_sse2(float f)
     return v < -32768 ? -32768 : v > 32767 ? 32767 : (int)v;
 }
 
+/* dsputil.c:3989-4001 */
+void oracle_float_to_int16_interleave(int16_t *dst, const float *const *src, long len, int channels, int sse2)
+{
+    long i, j;
+    int c;
+    if (channels == 2) {
+        for (i = 0; i < len; i++) {
+            dst[2 * i]     = (int16_t)(sse2 ? oracle_float_to_int16_sse2(src[0][i]) : oracle_float_to_int16_one(src[0][i]));
+            dst[2 * i + 1] = (int16_t)(sse2 ? oracle_float_to_int16_sse2(src[1][i]) : oracle_float_to_int16_one(src[1][i]));
+        }
+    } else {
+        for (c = 0; c < channels; c++)
+            for (i = 0, j = c; i < len; i++, j += channels)
+                dst[j] = (int16_t)(sse2 ? oracle_float_to_int16_sse2(src[c][i]) : oracle_float_to_int16_one(src[c][i]));
+    }
+}
+
 static void store_pcm(void *pcm, int fmt, size_t frame, int nch, int len,
                       float *const *ch_ret)
 {

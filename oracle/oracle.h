@@ -77,6 +77,8 @@ void oracle_imdct_and_windowing(const float *coeffs, const HeaacIcs *ics,
 /* ---- float -> int16 (a27) ---- */
 int  oracle_float_to_int16_one(float f);
 int  oracle_float_to_int16_sse2(float f);                          /* x86/dsputil_mmx.c:2356-2372 */
+/* ff_float_to_int16_interleave_c (dsputil.c:3989-4001); sse2 != 0: the conversion above instead (same order) */
+void oracle_float_to_int16_interleave(int16_t *dst, const float *const *src, long len, int channels, int sse2);
 
 /* ---- SBR stages on plain arrays (a11, a20), for stage tests ---- */
 void oracle_qmf_analysis(const float *in /*1024*/, float *xhist /*288 in/out*/,

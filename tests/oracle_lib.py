@@ -171,6 +171,16 @@ def float_to_int16(a):
     return np.array([f(C.c_float(float(v))) for v in a.ravel()], np.int16).reshape(a.shape)
 
 
+def float_to_int16_interleave(planes, sse2=False):
+    """planes: [channels][len] float32 -> [len][channels] int16 (ff_float_to_int16_interleave_c)."""
+    planes = [_f32(p) for p in planes]
+    ch, n = len(planes), planes[0].shape[0]
+    ptrs = (C.c_void_p * ch)(*[p.ctypes.data for p in planes])
+    out = np.zeros((n, ch), np.int16)
+    lib().oracle_float_to_int16_interleave(_p(out), ptrs, C.c_long(n), C.c_int(ch), C.c_int(1 if sse2 else 0))
+    return out
+
+
 def lc_decode_batch(channels, coeffs, ics, state_in, pcm_format=PCM_F32):
     coeffs = _f32(coeffs)
     n = coeffs.shape[0]
