@@ -702,6 +702,13 @@ def sbr_parse_payload(stream, table, sample_rate, payload, channels, allow_ps, c
     return r, sbr, ps, info[0]
 
 
+def sbr_no_payload(stream, channels):
+    """heaac_sbr_no_payload: the record of an access unit without an SBR payload for ONE stream record."""
+    sbr = np.zeros(1, SBR_FRAME_DT)
+    lib().heaac_sbr_no_payload(stream.ctypes.data_as(C.c_void_p), C.c_int(channels), sbr.ctypes.data_as(C.c_void_p), None)
+    return sbr
+
+
 def heaac_parse_batch(cfg, streams, sbr_st, table, aus, threads=0, with_ps=False):
     """heaac_heaac_parse_batch: whole HE-AAC access units, one per stream.  streams: AAC_STREAM_DT [n],
     sbr_st: sbr_streams(n); both updated in place.  Returns the dict of aac_parse_batch plus sbr [n], ps [n]."""

@@ -303,6 +303,7 @@ extern "C" void av_fft_end(FFTContext *s) { if (s) { ff_fft_end(s); free(s); } }
 // AVCodec-shaped decoder
 // ---------------------------------------------------------------------------
 #define MAX_HDRS 64
+#include "codec_layout.h"
 
 typedef struct HeaacDecoderPriv {
     HeaacDevice *dev;
@@ -328,6 +329,10 @@ typedef struct HeaacDecoderPriv {
     HeaacToolsFrame *h_tools;
     // access units with coupling channel elements (AAC-LC / Main): allocated by the first one
     struct HeaacCoupled *cpl;
+    // streams with several output elements per access unit (channel configurations 3..7, program config elements)
+    int have_layout;
+    HeaacAacLayout layout;
+    struct HeaacLayoutDec *lay;
 } HeaacDecoderPriv;
 
 // Host and device side of the coupling elements of one access unit (dec_frame_coupled)
@@ -374,12 +379,12 @@ static int dec_init_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p)
 {
     p->bitstream = 1;
     if (avctx->extradata && avctx->extradata_size > 0) {
-        const int specific = heaac_asc_parse(&p->m4ac, avctx->extradata, avctx->extradata_size);
-        if (specific < 0) return -1;
-        // decode_ga_specific_config (aacdec.c:401-452): 960-sample frames are refused at init
-        if (heaac_ga_specific_config(&p->m4ac, avctx->extradata, avctx->extradata_size, specific) < 0) return -1;
-        if (p->m4ac.chan_config != 1 && p->m4ac.chan_config != 2) return -1;      // this slice: one SCE or one CPE
+        // decode_audio_specific_config (aacdec.c:462-493): 960-sample frames are refused at init; the channel
+        // configuration, or the program config element standing in for it, gives the output layout
+        if (heaac_asc_layout(&p->m4ac, &p->layout, avctx->extradata, avctx->extradata_size) < 0) return -1;
         if (p->m4ac.object_type != HEAAC_AOT_AAC_LC && p->m4ac.object_type != HEAAC_AOT_AAC_MAIN) return -1;
+        // one SCE or one CPE: the single-element path (with Parametric Stereo and coupling elements); else the layout path
+        p->have_layout = p->m4ac.chan_config != 1 && p->m4ac.chan_config != 2;
         p->have_m4ac = 1;
     }
     const size_t words = HEAAC_STATE_WORDS_HEV2 > HEAAC_STATE_WORDS_HEV1 ? HEAAC_STATE_WORDS_HEV2 : HEAAC_STATE_WORDS_HEV1;
@@ -407,7 +412,15 @@ static int dec_init_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p)
     const hipError_t e = hipMemcpy(p->d_pred, ps, 2 * HEAAC_MAX_PREDICTORS * sizeof(*ps), hipMemcpyHostToDevice);
     free(ps);
     if (e != hipSuccess) return -1;
-    if (p->have_m4ac) {
+    if (p->have_m4ac && p->have_layout) {
+        if (!(p->lay = heaac_layout_dec_create(p->dev, &p->m4ac, &p->layout))) return -1;
+        // tentative (output_configure with OC_GLOBAL_HDR); the first access unit settles implicit SBR
+        const int he = p->m4ac.sbr == 1;
+        avctx->channels = p->layout.channels;
+        avctx->channel_layout = p->layout.channel_layout;
+        avctx->frame_size = he ? 2048 : 1024;
+        avctx->sample_rate = he ? 2 * p->m4ac.sample_rate : p->m4ac.sample_rate;
+    } else if (p->have_m4ac) {
         // tentative, as decode_audio_specific_config leaves it; the first access unit settles implicit SBR
         const int he = p->m4ac.sbr == 1;
         set_cfg(p, he ? (p->m4ac.chan_config == 2 ? HEAAC_CFG_HEV1 : (p->m4ac.ps != 0 ? HEAAC_CFG_HEV2 : HEAAC_CFG_HEV1_MONO))
@@ -429,8 +442,8 @@ static int dec_frame_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p, vo
     if (!p->have_m4ac) {
         // parse_adts_frame_header (aacdec.c:1935-1971): the stream configures itself
         HeaacAdtsHeader ah;
-        if (heaac_adts_parse_header(&ah, buf, size) < 0) return -1;
-        if (ah.chan_config != 1 && ah.chan_config != 2) return -1;
+        const int hs = heaac_adts_parse_header(&ah, buf, size);
+        if (hs < 0) return -1;
         memset(&p->m4ac, 0, sizeof(p->m4ac));
         p->m4ac.object_type = ah.object_type;
         p->m4ac.sampling_index = ah.sampling_index;
@@ -439,7 +452,32 @@ static int dec_frame_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p, vo
         p->m4ac.sbr = -1;
         p->m4ac.ps = -1;
         if (p->m4ac.object_type != HEAAC_AOT_AAC_LC && p->m4ac.object_type != HEAAC_AOT_AAC_MAIN) return -1;
+        if (ah.chan_config != 1 && ah.chan_config != 2) {
+            // set_default_channel_config (:1946), or -- channel configuration 0 -- the program config element the
+            // raw data block starts with (:2036-2046, OC_TRIAL_PCE)
+            if (ah.chan_config) {
+                if (heaac_aac_layout_default(&p->layout, ah.chan_config) < 0) return -1;
+            } else {
+                if (size < hs + 2 || (buf[hs] >> 5) != 5) return -1;              // id_syn_ele PCE
+                if (heaac_aac_layout_from_pce(&p->layout, buf, size, hs * 8 + 7, NULL) < 0) return -1;
+            }
+            if (!(p->lay = heaac_layout_dec_create(p->dev, &p->m4ac, &p->layout))) return -1;
+            p->have_layout = 1;
+        }
         p->have_m4ac = 1;
+    }
+    if (p->have_layout) {
+        HeaacLayoutOut lo;
+        const int used = heaac_layout_dec_frame(p->lay, buf, size, data, data_size, &lo);
+        if (used < 0) return -1;
+        if (!p->configured) {
+            avctx->channels = lo.channels;
+            avctx->channel_layout = lo.channel_layout;
+            avctx->frame_size = lo.frame_size;
+            avctx->sample_rate = lo.sample_rate;
+            p->configured = 1;
+        }
+        return used;
     }
     HeaacIcs ics[2];
     HeaacSbrFrame sbr;
@@ -678,6 +716,7 @@ static int dec_close(HeaacCodecContext *avctx)
     if (p->d_pred) (void)hipFree(p->d_pred);
     heaac_sbr_table_destroy(p->tab);
     coupled_free(p->cpl);
+    heaac_layout_dec_destroy(p->lay);
     free(p->h_coeffs);
     free(p->h_tools);
     heaac_device_destroy(p->dev);
@@ -741,9 +780,9 @@ static int dec_frame(HeaacCodecContext *avctx, void *data, int *data_size, Heaac
     return (int)need;            // bytes consumed (aacdec.c:2102-2107)
 }
 
-// aacdec.c:2128-2142 (channel layouts: the two this path decodes)
+// aacdec.c:2128-2142 (channel layouts: aac_channel_layout[], aacdectab.h:84-93)
 static const int dec_sample_fmts[] = { HEAAC_SAMPLE_FMT_S16, HEAAC_SAMPLE_FMT_NONE };
-static const int64_t dec_channel_layouts[] = { HEAAC_CH_LAYOUT_MONO, HEAAC_CH_LAYOUT_STEREO, 0 };
+static const int64_t dec_channel_layouts[] = { HEAAC_CH_LAYOUT_MONO, HEAAC_CH_LAYOUT_STEREO, 0x7, 0x107, 0x37, 0x3f, 0xff, 0 };   // aac_channel_layout[], aacdectab.h:84-93
 extern "C" HeaacCodec heaac_aac_decoder = {
     "aac", 1, HEAAC_CODEC_ID_AAC, (int)sizeof(HeaacDecoderPriv), dec_init, NULL, dec_close, dec_frame,
     0, NULL, NULL, NULL, NULL, "Advanced Audio Coding (HE-AAC DSP on gfx950)", NULL,

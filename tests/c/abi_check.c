@@ -101,8 +101,12 @@ static int cpu_checks(void)
     CHECK(sizeof(HeaacCodecContext) == REF_AVCTX_SIZE && sizeof(union ref_AVCodecContext) == REF_AVCTX_SIZE);
     CHECK(!strcmp(heaac_aac_decoder.name, "aac") && heaac_aac_decoder.type == 1);
     CHECK(heaac_aac_decoder.sample_fmts[0] == HEAAC_SAMPLE_FMT_S16 && heaac_aac_decoder.sample_fmts[1] == -1);
-    CHECK(heaac_aac_decoder.channel_layouts[0] == 4 && heaac_aac_decoder.channel_layouts[1] == 3 &&
-          heaac_aac_decoder.channel_layouts[2] == 0);
+    {
+        /* .channel_layouts = aac_channel_layout (aacdec.c:2140; aacdectab.h:84-93 with avcodec.h:386-427): mono, stereo,
+         * 3.0, 4.0, 5.0 (back), 5.1 (back), 7.1 (wide), 0 */
+        static const int64_t want[8] = { 0x4, 0x3, 0x7, 0x107, 0x37, 0x3f, 0xff, 0 };
+        for (int i = 0; i < 8; i++) CHECK(heaac_aac_decoder.channel_layouts[i] == want[i]);
+    }
     CHECK(sizeof(HeaacSbrHeader) == 532 && sizeof(HeaacSbrFrame) == 680 && sizeof(HeaacPsFrame) == 532);
 
     HeaacSbrHeader h;

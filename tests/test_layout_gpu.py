@@ -51,3 +51,160 @@ def test_interleave_refuses_what_it_cannot_do(pkg, dev):
     assert args(2, 1024, pkg.PCM_S16) == -1
     assert args(1, 1022, pkg.PCM_S16) == -1 and args(1, 1024, pkg.PCM_F32) == -1 and args(17, 1024, pkg.PCM_S16) == -1
     assert args(1, 1024, pkg.PCM_S16) == 0
+
+
+SCE, CPE, CCE, LFE = 0, 1, 2, 3
+
+
+def _asc(aot, si, cc, he=False, pce=None):
+    """AudioSpecificConfig (mpeg4audio.c:79-143): explicit SBR puts object type 5 and the extension rate in front."""
+    import aac_bitwriter as W
+    bw = W.BitWriter()
+    if he:
+        bw.put(5, 5); bw.put(si, 4); bw.put(cc, 4); bw.put(si - 3, 4); bw.put(aot, 5)
+    else:
+        bw.put(aot, 5); bw.put(si, 4); bw.put(cc, 4)
+    bw.put(0, 3)                                                       # GASpecificConfig: 1024 samples, no core coder, no extension
+    if pce is not None:
+        bw.put(0, 4)
+        pce(bw)
+    return bw.bytes()
+
+
+MODES = {
+    # name: (channel configuration, elements in bitstream order, SBR, how the stream configures itself)
+    "lc_3_0": (3, [(SCE, 0), (CPE, 0)], False, "asc"),
+    "lc_5_1": (6, [(SCE, 0), (CPE, 0), (CPE, 1), (LFE, 0)], False, "asc"),
+    "lc_7_1_adts": (7, [(SCE, 0), (CPE, 0), (CPE, 1), (CPE, 2), (LFE, 0)], False, "adts"),
+    "main_5_0": (5, [(SCE, 3), (CPE, 1), (CPE, 0)], False, "asc"),      # tags as the encoder pleases: taken by position
+    "he_5_1": (6, [(SCE, 0), (CPE, 0), (CPE, 1), (LFE, 0)], True, "asc"),
+    "he_5_1_implicit": (6, [(SCE, 0), (CPE, 0), (CPE, 1), (LFE, 0)], True, "asc_implicit"),
+    "lc_pce_asc": (0, [(CPE, 1), (LFE, 2), (SCE, 0), (CPE, 0)], False, "asc"),
+    "lc_pce_adts": (0, [(SCE, 0), (CPE, 0), (CPE, 1), (LFE, 0)], False, "adts"),
+}
+
+
+@pytest.mark.parametrize("mode", sorted(MODES))
+def test_codec_decodes_multichannel_streams(pkg, oracle, dev, mode):
+    """aac_decode_frame for layouts with several output elements, through heaac_codec_decode on the reference's own
+    AVCodecContext / AVPacket records: 3.0, 5.0, 5.1, 7.1, a program config element in the extradata and one at the
+    head of the first ADTS frame, AAC-Main prediction, explicit and implicit SBR per element.  The checker parses the
+    same units with the layout parser (pinned by tests/test_parse_layout.py), runs the ORACLE's spectral tools through
+    the elements in bitstream order (one noise generator), the oracle's decode per element on its own state, and
+    ff_float_to_int16_interleave_c over the planes in layout order."""
+    import copy
+    import sbr_bitwriter as SW
+    import test_parse as TP
+    import test_parse_layout as TL
+    from test_shim_gpu import HeaacCodecContext, HeaacPacket, _adts
+    lib = pkg.lib()
+    cc, elems, he, how = MODES[mode]
+    rng = np.random.default_rng(sum(map(ord, mode)))
+    aot = 1 if mode.startswith("main") else 2
+    si = 6 if he else 3
+    pce_elems = None
+    if cc == 0:
+        front = [(int(t == CPE), g) for t, g in elems if t in (SCE, CPE) and not (t == CPE and g == 1)]
+        back = [(1, 1)] if (CPE, 1) in elems else []
+        pce_elems = (front, [], back, [g for t, g in elems if t == LFE])
+    pce = (lambda bw: TL.write_pce_body(bw, rng, *pce_elems)) if cc == 0 else None
+    asc = None if how == "adts" else _asc(aot, si, cc, he=he and how == "asc", pce=pce)
+    ctx = HeaacCodecContext(cfg=-1, extradata=asc, extradata_size=len(asc) if asc else 0)
+    codec = C.c_void_p.in_dll(lib, "heaac_aac_decoder")
+    assert lib.heaac_codec_open(C.byref(ctx), C.c_void_p(C.addressof(codec))) == 0
+    # the checker's own configuration, layout and per-element streams
+    m4 = TP._cfg(pkg, aot, si, cc)
+    if cc:
+        r, layout = pkg.aac_layout_default(cc)
+    else:
+        bw = __import__("aac_bitwriter").BitWriter()
+        TL.write_pce_body(bw, np.random.default_rng(1), *pce_elems)
+        r, layout, _ = pkg.aac_layout_from_pce(bw.bytes(), 0)
+    assert r == 0
+    ne, nch = int(layout[0]["n_elements"]), int(layout[0]["channels"])
+    if asc is not None:
+        assert ctx.channels == nch and ctx.channel_layout == int(layout[0]["channel_layout"])
+    st = np.zeros(pkg.MAX_ELEMENTS, pkg.AAC_STREAM_DT)
+    length = 2048 if he else 1024
+    slot_ch = [int(layout[0]["elem"][e]["channels"]) for e in range(ne)]
+    state = [np.zeros((1, pkg.STATE_WORDS[(pkg.CFG_HEV1 if c == 2 else pkg.CFG_HEV1_MONO) if he else
+                                          (pkg.CFG_LC_STEREO if c == 2 else pkg.CFG_LC_MONO)]), np.float32) for c in slot_ch]
+    pred = [np.tile(np.array([0, 0, 1, 1, 0, 0], np.float32), (1, c * pkg.MAX_PREDICTORS, 1)).reshape(1, -1) for c in slot_ch]
+    ref_rng = np.full(1, 0x1f2e3d4c, np.int32)
+    tab = pkg.SbrHeaderTable(64)
+    sst = pkg.sbr_streams(ne)
+    writers = {k: SW.SbrStreamWriter(pkg, 2 if t == CPE else 1) for k, (t, _) in enumerate(elems) if t != LFE}
+    out = (C.c_int16 * (192000 // 2))()
+    loud = 0
+    for t in range(5):
+        payloads = None
+        if he:
+            payloads = []
+            for k, (typ, _) in enumerate(elems):
+                if typ == LFE:
+                    payloads.append(None)
+                    continue
+                w = writers[k]
+                while True:
+                    keep = copy.deepcopy((w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling))
+                    bits, _ = w.frame(rng, new_header=(t == 3 and k == 1), respec=(t == 3 and k == 1))
+                    if (4 + len(bits) + 7) // 8 <= 269:
+                        break
+                    w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling = keep
+                payloads.append(bits)
+        lead = None
+        if how == "adts" and cc == 0:
+            lead = lambda bw: (bw.put(5, 3), bw.put(0, 4), TL.write_pce_body(bw, np.random.default_rng(1), *pce_elems))
+        au, _ = TL.build(rng, si, aot, elems, extras=t & 1, payloads=payloads, lead=lead)
+        pkt_bytes = _adts(au, aot, si, cc) if how == "adts" else au
+        buf = C.create_string_buffer(pkt_bytes, len(pkt_bytes))
+        pkt = HeaacPacket(C.cast(buf, C.c_void_p), len(pkt_bytes))
+        size = C.c_int(192000)
+        used = lib.heaac_codec_decode(C.byref(ctx), out, C.byref(size), C.byref(pkt))
+        assert used == len(pkt_bytes), (t, used)
+        assert (ctx.channels, ctx.frame_size, ctx.sample_rate) == (nch, length, 48000), t
+        assert ctx.channel_layout == int(layout[0]["channel_layout"]) and size.value == length * nch * 2
+        got = np.frombuffer(out, np.int16, size.value // 2).reshape(length, nch).copy()
+        # ---- the checker ----
+        r, p = pkg.aac_parse_frame_layout(m4, layout, st, pkt_bytes)
+        assert r == 0
+        order = sorted(range(ne), key=lambda e: int(p["elem"][e]["seq"]))
+        spec = [None] * ne
+        for e in order:
+            c = slot_ch[e]
+            co = np.ascontiguousarray(p["coeffs"][e:e + 1, :c])
+            if aot == 1:
+                spec[e], ref_rng, pred[e] = oracle.spectral_tools_batch(c, co, p["tools"][e:e + 1], rng=ref_rng, pred=pred[e])
+            else:
+                spec[e], ref_rng = oracle.spectral_tools_batch(c, co, p["tools"][e:e + 1], rng=ref_rng)
+        planes = [None] * nch
+        for e in range(ne):
+            c = slot_ch[e]
+            ics = np.ascontiguousarray(p["ics"][e:e + 1, :c])
+            if he:
+                ei = p["elem"][e]
+                if int(ei["sbr_payload_bit"]) >= 0:
+                    rr, sbr, _, _ = pkg.sbr_parse_payload(sst[e], tab, 24000, pkt_bytes, c, False, bit=int(ei["sbr_payload_bit"]),
+                                                          cnt=int(ei["sbr_payload_bytes"]))
+                    assert rr == 0
+                else:
+                    sbr = pkg.sbr_no_payload(sst[e], c)              # an LFE: never started ("pure upsampling")
+                    assert int(layout[0]["elem"][e]["type"]) == LFE
+                pcm, state[e] = oracle.he_decode_batch(pkg.CFG_HEV1 if c == 2 else pkg.CFG_HEV1_MONO, spec[e], ics, sbr,
+                                                       tab.headers(), None, state[e], oracle.PCM_F32)
+            else:
+                pcm, state[e] = oracle.lc_decode_batch(c, spec[e], ics, state[e], oracle.PCM_F32)
+            for j in range(c):
+                planes[int(layout[0]["elem"][e]["first_channel"]) + j] = pcm[0, j]
+        want = oracle.float_to_int16_interleave(planes)
+        assert np.array_equal(got, want), ("frame %d" % t, np.argwhere(got != want)[:4])
+        loud = max(loud, int(np.abs(got.astype(int)).max()))
+    assert loud > 50
+    # an access unit that leaves an element out is refused (the reference would transform stale buffers)
+    au, _ = TL.build(rng, si, aot, elems[:-1], extras=False)
+    pkt_bytes = _adts(au, aot, si, cc) if how == "adts" else au
+    buf = C.create_string_buffer(pkt_bytes, len(pkt_bytes))
+    pkt = HeaacPacket(C.cast(buf, C.c_void_p), len(pkt_bytes))
+    size = C.c_int(192000)
+    assert lib.heaac_codec_decode(C.byref(ctx), out, C.byref(size), C.byref(pkt)) < 0
+    assert lib.heaac_codec_close(C.byref(ctx)) == 0

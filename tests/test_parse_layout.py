@@ -91,16 +91,31 @@ def write_dse(bw, rng):
         bw.put(int(rng.integers(0, 256)), 8)
 
 
-def build(rng, si, aot, elems, sbr_prob=0.0, extras=True):
-    """elems: [(type, tag)] in bitstream order.  Returns (bytes, [per element dict])."""
+def build(rng, si, aot, elems, sbr_prob=0.0, extras=True, payloads=None, lead=None):
+    """elems: [(type, tag)] in bitstream order; payloads: per element the bits of a real SBR payload (or None);
+    lead: a function writing something in front (a program config element).  Returns (bytes, [per element dict])."""
     bw = W.BitWriter()
     out = []
+    if lead is not None:
+        lead(bw)
     if extras and rng.random() < 0.3:
         write_dse(bw, rng)
-    for typ, tag in elems:
+    for k, (typ, tag) in enumerate(elems):
         ch, sf, cw = write_elem(bw, rng, si, aot, typ, tag)
         e = dict(type=typ, tag=tag, ch=ch, sf=sf, cw=cw, sbr_bit=-1, sbr_bytes=0, sbr_crc=0)
-        if rng.random() < sbr_prob:
+        if payloads is not None and payloads[k] is not None:
+            bits = payloads[k]
+            cnt = (4 + len(bits) + 7) // 8
+            bw.put(6, 3)
+            if cnt >= 15:
+                bw.put(15, 4); bw.put(cnt - 14, 8)
+            else:
+                bw.put(cnt, 4)
+            bw.put(0xd, 4)
+            e.update(sbr_bit=len(bw.bits), sbr_bytes=cnt)
+            bw.bits.extend(bits)
+            bw.bits.extend([0] * (8 * cnt - 4 - len(bits)))
+        elif rng.random() < sbr_prob:
             crc = int(rng.integers(0, 2))
             cnt = int(rng.integers(1, 24))
             e.update(sbr_bit=write_fill(bw, rng, 0xe if crc else 0xd, cnt), sbr_bytes=cnt, sbr_crc=crc)
