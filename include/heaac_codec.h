@@ -132,7 +132,9 @@ HEAAC_LAYOUT_ASSERT(offsetof(HeaacCodecContext, extradata) == 32 && offsetof(Hea
  * or from the first ADTS header (parse_adts_frame_header, :1935-1971); SBR from the AudioSpecificConfig or,
  * signalled implicitly, from a payload in the FIRST access unit (a first occurrence later is refused,
  * :1666-1669); a mono stream with SBR decodes as Parametric Stereo (:1670-1673, two output channels).
- * Scope of the parser slices: one SCE or one CPE per access unit, AAC-LC / AAC-Main.  A context keeps up to 63
+ * Scope of the parser slices: AAC-LC / AAC-Main; one SCE or one CPE per access unit (with Parametric Stereo and coupling
+ * channel elements), or the several output elements of channel configuration 3 .. 7 / of a program config element
+ * (output_configure, aacdec.c:224-276; SBR per element; no coupling, no Parametric Stereo).  A context keeps up to 63
  * distinct SBR headers of its stream (the derived tables stay on the device); a stream that sends more than that
  * gets -1 from the frame that brings the 64th. */
 

@@ -1,7 +1,8 @@
 /* heaac_parse.h -- host-side AAC bitstream parser feeding the batched GPU path.
  *
  * First slice: AAC-LC / AAC-Main access units made of ONE single_channel_element or ONE
- * channel_pair_element (channel configurations 1 and 2), with data_stream and fill elements skipped.
+ * channel_pair_element (channel configurations 1 and 2), with data_stream and fill elements skipped; the layout
+ * entries further down take the access units of channel configurations 3 .. 7 and of program config elements.
  * What it replaces in the reference (libavcodec):
  *
  *   heaac_asc_parse          ff_mpeg4audio_get_config            mpeg4audio.c:79-143
@@ -35,8 +36,8 @@ enum {
     HEAAC_PARSE_OK          =  0,
     HEAAC_PARSE_ERR_DATA    = -1,   /* invalid or reserved value in the bitstream (the reference returns -1) */
     HEAAC_PARSE_ERR_OVERREAD = -2,  /* ran past the end of the access unit */
-    HEAAC_PARSE_ERR_UNSUPPORTED = -3, /* valid AAC outside this slice: CCE, PCE, LTP, SSR gain control,
-                                         more than one SCE / CPE per access unit */
+    HEAAC_PARSE_ERR_UNSUPPORTED = -3, /* valid AAC outside the entry it was handed to: LTP, SSR gain control; a coupling
+                                         element or a second SCE / CPE in heaac_aac_parse_frame, ... */
     HEAAC_PARSE_ERR_ARG     = -4,
 };
 

@@ -4,7 +4,8 @@
  * -fsanitize=address,undefined, so every out-of-bounds access or undefined shift aborts the run.  Input: a file
  * of seed access units (u32 kind, u32 length, bytes; kind 0 = AAC-LC CPE 48 kHz, 1 = HE-AACv1 CPE 24 kHz,
  * 2 = HE-AACv2 SCE 24 kHz, 3 = AAC-LC CPE 48 kHz with coupling / program config elements, 4 = the same around an SCE:
- * kinds 3 and 4 go through heaac_aac_parse_frame_ex).  Every 16th iteration instead walks a buffer of seeds behind ADTS
+ * kinds 3 and 4 go through heaac_aac_parse_frame_ex; 5 = a 5.1 access unit (SCE CPE CPE LFE, some with SBR payloads) through
+ * heaac_aac_parse_frame_layout, its bytes also read as a program config element at a random bit offset).  Every 16th iteration instead walks a buffer of seeds behind ADTS
  * headers, mutated the same ways, through heaac_adts_split and checks that the packets tile it.  Each iteration mutates a seed (bit flips, byte noise, truncation, splice of two
  * seeds, pure noise), parses it on a stream that keeps its state across iterations, and checks what the parser
  * promises: whatever the status, the records it wrote pass validate.h.
@@ -62,6 +63,19 @@ int main(int argc, char **argv)
     HeaacIcs cce_ics[HEAAC_MAX_CCE];
     HeaacToolsFrame *cce_tools = malloc(HEAAC_MAX_CCE * sizeof(*cce_tools));
     const HeaacCceOut co = { cce, cce_coeffs, cce_ics, cce_tools };
+    /* a 5.1 stream (kind 5) */
+    HeaacAacConfig lcfg;
+    memset(&lcfg, 0, sizeof(lcfg));
+    lcfg.object_type = 2; lcfg.sampling_index = 3; lcfg.sample_rate = 48000; lcfg.chan_config = 6;
+    HeaacAacLayout lay;
+    heaac_aac_layout_default(&lay, 6);
+    HeaacAacStream lst[HEAAC_MAX_ELEMENTS];
+    memset(lst, 0, sizeof(lst));
+    float *lcoeffs = malloc(HEAAC_MAX_ELEMENTS * 2048 * sizeof(float));
+    HeaacIcs lics[HEAAC_MAX_ELEMENTS][2];
+    HeaacToolsFrame *ltools = malloc(HEAAC_MAX_ELEMENTS * sizeof(*ltools));
+    HeaacAacElementInfo lelem[HEAAC_MAX_ELEMENTS];
+    long layouts_ok = 0, layout_units = 0, layout_bad = 0;
     for (long it = 0; it < iters; it++) {
         const Seed *s = &seed[rnd() % ns];
         const int k = (int)s->kind;
@@ -102,6 +116,46 @@ int main(int argc, char **argv)
             if (np < 0 || (np <= 64 && at != total)) adts_bad++;
             (void)heaac_adts_probe(buf, total);
             free(buf); free(au);
+            continue;
+        }
+        if (k == 5) {
+            memset(&info, 0, sizeof(info));
+            const int r = heaac_aac_parse_frame_layout(&lcfg, &lay, lst, au, (int)len, lcoeffs, &lics[0][0], ltools, lelem, &info);
+            if (r >= 0) ok++; else err++;
+            if (r == HEAAC_PARSE_OK) {
+                layout_units++;
+                int seen = 0;
+                for (int e = 0; e < lay.n_elements; e++) {
+                    const HeaacAacElementInfo *ei = &lelem[e];
+                    if (!ei->present) continue;
+                    seen++;
+                    int v = ei->seq >= lay.n_elements || ei->tag > 15 || ei->type > 3;
+                    if (ei->sbr_payload_bit >= 0)
+                        v |= ei->sbr_payload_bytes < 1 || (long)ei->sbr_payload_bit + 8L * ei->sbr_payload_bytes - 4 > 8L * (long)len;
+                    const HeaacToolsIcs *ic = &ltools[e].ch[0].ics;
+                    v |= ic->num_window_groups < 1 || ic->num_window_groups > 8 || ic->max_sfb > ic->num_swb ||
+                         ic->num_window_groups * ic->max_sfb > 120;
+                    if (v) { layout_bad++; if (layout_bad < 5) printf("iteration %ld: layout element out of range\n", it); }
+                }
+                if (!seen || lay.tags_mapped > 4) layout_bad++;
+            }
+            if (it % 1024 == 1023) heaac_aac_layout_default(&lay, 6);        /* the stream starts over: tags are learned again */
+            /* the same bytes as a program config element somewhere inside them */
+            HeaacAacLayout pl;
+            int used = 0;
+            const int pr = heaac_aac_layout_from_pce(&pl, au, (int)len, (int)(rnd() % (8 * len)), &used);
+            if (pr == 0) {
+                layouts_ok++;
+                int chs = 0, v = pl.n_elements < 0 || pl.n_elements > HEAAC_MAX_ELEMENTS || used <= 0 || used > 8 * (int)len;
+                for (int e = 0; e < pl.n_elements && e < HEAAC_MAX_ELEMENTS; e++) {
+                    v |= pl.elem[e].first_channel != chs || pl.elem[e].channels != (pl.elem[e].type == HEAAC_ELEM_CPE ? 2 : 1);
+                    v |= pl.slot_of[pl.elem[e].type][pl.elem[e].id] != e + 1;
+                    chs += pl.elem[e].channels;
+                }
+                v |= chs != pl.channels || chs > HEAAC_MAX_LAYOUT_CHANNELS;
+                if (v) { layout_bad++; if (layout_bad < 5) printf("iteration %ld: layout out of range\n", it); }
+            }
+            free(au);
             continue;
         }
         if (k >= 3) {
@@ -146,7 +200,9 @@ int main(int argc, char **argv)
     printf("iterations %ld: parsed %ld, refused %ld, frames with start = 1: %ld, headers %zu, invalid records %ld\n",
            iters, ok, err, started, heaac_sbr_table_count(tab), bad_records);
     printf("coupling elements parsed %ld, ADTS frames delivered %ld, ADTS walks that did not tile %ld\n", coupled, adts_frames, adts_bad);
-    if (adts_bad) return 1;
+    printf("5.1 units parsed %ld, program config layouts accepted %ld, out of range %ld\n", layout_units, layouts_ok, layout_bad);
+    if (adts_bad || layout_bad) return 1;
+    free(lcoeffs); free(ltools);
     free(cce); free(cce_coeffs); free(cce_tools);
     heaac_sbr_table_destroy(tab);
     free(sst); free(coeffs); free(tools);

@@ -38,6 +38,11 @@ def test_parsers_survive_damaged_access_units():
                      bool(rng.integers(0, 2))) for t in rng.choice(16, int(rng.integers(1, 3)), replace=False)]
             b, _ = TW.build_au(rng, 3, 2, cpe, cces, pce=bool(i % 3 == 0))
             f.write(struct.pack("<II", 3 if cpe else 4, len(b)) + b)
+        # 5.1 access units (the layout parser), some elements with payloads behind them
+        import test_parse_layout as TL
+        for i in range(24):
+            b, _ = TL.build(rng, 3, 2, [(0, 0), (1, 0), (1, 1), (3 if i & 1 else 0, int(i & 2))], sbr_prob=0.5)
+            f.write(struct.pack("<II", 5, len(b)) + b)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     p = subprocess.run([EXE, seeds, "400000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-4000:]
@@ -48,3 +53,5 @@ def test_parsers_survive_damaged_access_units():
     assert int(m.group(1)) > 60000 and int(m.group(2)) > 60000 and int(m.group(3)) > 10000, m.group(0)
     m = re.search(r"coupling elements parsed (\d+), ADTS frames delivered (\d+)", p.stdout)
     assert int(m.group(1)) > 5000 and int(m.group(2)) > 10000, m.group(0)
+    m = re.search(r"5.1 units parsed (\d+), program config layouts accepted (\d+), out of range (\d+)", p.stdout)
+    assert int(m.group(1)) > 3000 and int(m.group(2)) > 1000 and int(m.group(3)) == 0, m.group(0)
