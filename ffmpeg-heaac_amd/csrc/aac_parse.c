@@ -951,6 +951,7 @@ int heaac_aac_parse_frame_layout(const HeaacAacConfig *cfg, HeaacAacLayout *layo
         case TYPE_LFE: {
             slot = layout_find(layout, seen, type, &tag);
             if (slot < 0) return HEAAC_PARSE_ERR_DATA;                 /* "channel element %d.%d is not allocated" */
+            if (slot >= ne) return HEAAC_PARSE_ERR_ARG;                /* a layout record not made by the layout functions */
             /* the element decodes as what the bitstream says it is; a pair needs a pair's slot */
             if ((type == TYPE_CPE) != (layout->elem[slot].channels == 2)) return HEAAC_PARSE_ERR_DATA;
             HeaacToolsFrame *t = &tools[slot];

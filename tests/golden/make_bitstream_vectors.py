@@ -24,6 +24,93 @@ STREAMS = {
 }
 
 
+# multi-element layouts (tests/test_parse_layout.py writes the units; elements in bitstream order)
+SCE, CPE, LFE = 0, 1, 3
+LAYOUT_STREAMS = {
+    # name: (asc bytes, sampling index, channel configuration, elements, SBR, frames, seed)
+    "lc_5_1_48k": (bytes([0x11, 0xB0]), 3, 6, [(SCE, 0), (CPE, 0), (CPE, 1), (LFE, 0)], False, 6, 811),
+    "hev1_5_1_24k": (bytes([0x2B, 0x31, 0x88, 0x00]), 6, 6, [(SCE, 0), (CPE, 0), (CPE, 1), (LFE, 0)], True, 6, 812),
+}
+
+
+def write_layout_stream(pkg, name):
+    import copy
+    import sbr_bitwriter as SW
+    import test_parse_layout as TL
+    asc, si, cc, elems, he, frames, seed = LAYOUT_STREAMS[name]
+    rng = np.random.default_rng(seed)
+    writers = {k: SW.SbrStreamWriter(pkg, 2 if t == CPE else 1) for k, (t, _) in enumerate(elems) if t != LFE}
+    aus = []
+    for t in range(frames):
+        payloads = None
+        if he:
+            payloads = []
+            for k, (typ, _) in enumerate(elems):
+                if typ == LFE:
+                    payloads.append(None)
+                    continue
+                w = writers[k]
+                while True:
+                    keep = copy.deepcopy((w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling))
+                    bits, _ = w.frame(rng, new_header=(t == frames // 2 and k == 1), respec=(t == frames // 2 and k == 1))
+                    if (4 + len(bits) + 7) // 8 <= 269:
+                        break
+                    w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling = keep
+                payloads.append(bits)
+        aus.append(TL.build(rng, si, 2, elems, extras=bool(t & 1), payloads=payloads)[0])
+    return aus
+
+
+def decode_layout_stream(pkg, oracle, name, aus):
+    """Layout parser + oracle per element + ff_float_to_int16_interleave_c; returns (record hashes, PCM hash, shape)."""
+    asc, si, cc, elems, he, frames, seed = LAYOUT_STREAMS[name]
+    r, m4, layout = pkg.asc_layout(asc)
+    assert r == 0 and m4.chan_config == cc
+    ne, nch = int(layout[0]["n_elements"]), int(layout[0]["channels"])
+    slot_ch = [int(layout[0]["elem"][e]["channels"]) for e in range(ne)]
+    st = np.zeros(pkg.MAX_ELEMENTS, pkg.AAC_STREAM_DT)
+    state = [np.zeros((1, pkg.STATE_WORDS[(pkg.CFG_HEV1 if c == 2 else pkg.CFG_HEV1_MONO) if he else
+                                          (pkg.CFG_LC_STEREO if c == 2 else pkg.CFG_LC_MONO)]), np.float32) for c in slot_ch]
+    rng_state = np.full(1, 0x1f2e3d4c, np.int32)
+    tab, sst = pkg.SbrHeaderTable(64), pkg.sbr_streams(ne)
+    rec, pcm = [], hashlib.sha256()
+    for au in aus:
+        r, p = pkg.aac_parse_frame_layout(m4, layout, st, au)
+        assert r == 0
+        m = hashlib.sha256(p["tools"].tobytes())
+        m.update(p["elem"].tobytes())
+        spec = [None] * ne
+        for e in sorted(range(ne), key=lambda e: int(p["elem"][e]["seq"])):
+            c = slot_ch[e]
+            spec[e], rng_state = oracle.spectral_tools_batch(c, np.ascontiguousarray(p["coeffs"][e:e + 1, :c]),
+                                                             p["tools"][e:e + 1], rng=rng_state)
+        planes = [None] * nch
+        for e in range(ne):
+            c = slot_ch[e]
+            ics = np.ascontiguousarray(p["ics"][e:e + 1, :c])
+            if he:
+                ei = p["elem"][e]
+                if int(ei["sbr_payload_bit"]) >= 0:
+                    rr, sbr, _, _ = pkg.sbr_parse_payload(sst[e], tab, m4.sample_rate, au, c, False,
+                                                          bit=int(ei["sbr_payload_bit"]), cnt=int(ei["sbr_payload_bytes"]))
+                    assert rr == 0
+                else:
+                    sbr = pkg.sbr_no_payload(sst[e], c)
+                m.update(sbr.tobytes())
+                m.update(tab.headers()[int(sbr["hdr"][0])].tobytes())
+                f32, state[e] = oracle.he_decode_batch(pkg.CFG_HEV1 if c == 2 else pkg.CFG_HEV1_MONO, spec[e], ics, sbr,
+                                                       tab.headers(), None, state[e], oracle.PCM_F32)
+            else:
+                f32, state[e] = oracle.lc_decode_batch(c, spec[e], ics, state[e], oracle.PCM_F32)
+            assert np.isfinite(f32).all() and np.abs(f32 - 385.0).max() < 4.0, name
+            for j in range(c):
+                planes[int(layout[0]["elem"][e]["first_channel"]) + j] = f32[0, j]
+        out = oracle.float_to_int16_interleave(planes)
+        rec.append(m.hexdigest())
+        pcm.update(out.tobytes())
+    return rec, pcm.hexdigest(), list(out.shape)
+
+
 def write_stream(pkg, name):
     import copy
     import sbr_bitwriter as SW
@@ -99,6 +186,12 @@ def main():
         aus = [bytes.fromhex(a) for a in stored[name]["access_units"]] if stored else write_stream(pkg, name)
         rec, pcm, shape = decode_stream(pkg, oracle, name, aus)
         out[name] = dict(asc=STREAMS[name][0].hex(), access_units=[a.hex() for a in aus], records_sha256=rec,
+                         pcm_s16_sha256=pcm, frame_shape=shape)
+        print(name, len(aus), "units,", sum(len(a) for a in aus), "bytes, pcm", pcm[:16])
+    for name in LAYOUT_STREAMS:
+        aus = [bytes.fromhex(a) for a in stored[name]["access_units"]] if stored and name in stored else write_layout_stream(pkg, name)
+        rec, pcm, shape = decode_layout_stream(pkg, oracle, name, aus)
+        out[name] = dict(asc=LAYOUT_STREAMS[name][0].hex(), access_units=[a.hex() for a in aus], records_sha256=rec,
                          pcm_s16_sha256=pcm, frame_shape=shape)
         print(name, len(aus), "units,", sum(len(a) for a in aus), "bytes, pcm", pcm[:16])
     json.dump(out, open(path, "w"), indent=0)

@@ -68,8 +68,18 @@ def test_stored_bitstreams_parse_and_decode_to_the_stored_hashes(pkg, oracle, na
     assert [a.hex() for a in B.write_stream(pkg, name)] == v["access_units"]
 
 
+@pytest.mark.parametrize("name", sorted(B.LAYOUT_STREAMS))
+def test_stored_multichannel_bitstreams_parse_and_decode_to_the_stored_hashes(pkg, oracle, name):
+    """The same for the stored 5.1 streams: layout parser + the oracle per element + the reference's interleave."""
+    v = json.load(open(BPATH))[name]
+    aus = [bytes.fromhex(a) for a in v["access_units"]]
+    rec, pcm, shape = B.decode_layout_stream(pkg, oracle, name, aus)
+    assert rec == v["records_sha256"] and pcm == v["pcm_s16_sha256"] and shape == v["frame_shape"]
+    assert [a.hex() for a in B.write_layout_stream(pkg, name)] == v["access_units"]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", sorted(B.STREAMS))
+@pytest.mark.parametrize("name", sorted(B.STREAMS) + sorted(B.LAYOUT_STREAMS))
 def test_codec_decodes_stored_bitstreams_to_the_stored_pcm(pkg, name):
     """heaac_codec_open / _decode on the committed bytes (cfg from the stream): the int16 PCM hashes to the
     stored value.  No oracle in this test."""
