@@ -233,11 +233,16 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
     // reference's, two products or sums per packed instruction.
     // Delay line: s[k][n - D] with D = 2 (all-pass input), 14 or 1: the lane's own column
     // for n >= D, before that the state tail hst[j] = s[k][j - 14].
+    // Only the 14-slot bands read all of their tail; an all-pass band reads its last two slots, a one-slot band its
+    // last.  The other lanes aim the load at their slot 13 again (one line instead of fourteen: 6 KB less per frame).
     v2f hst[14];
+    const int first_slot = allpass ? 12 : d14 ? 0 : 13;
 #pragma unroll
     for (int j = HEAVY ? 0 : 13; j < 14; j++) {
         const int kv = opaque(kh * 8);
-        const v2f t = SI.ldb2(kv, HEAAC_PS_DELAY + j * dl_stride);
+        const int js = (HEAVY && j < 13 && j < first_slot) ? 13 : j;
+        const v2f t = (HEAVY && j < 13) ? SI.ldb2(kv + js * (dl_stride * 4), HEAAC_PS_DELAY)
+                                        : SI.ldb2(kv, HEAAC_PS_DELAY + j * dl_stride);
         hst[j] = clear_state ? zero : t;
     }
     // all-pass history: ring of 5 per link, position = time mod 5 (state j = time j - 5)
