@@ -11,12 +11,17 @@
 #include "kernels.h"
 
 #define HE_MAX_LANES 4
+#define HE_ZERO_BYTES (2 * 38 * 64 * 4)      // one channel's X record of +0: what k_synth reads for bands that were not stored
 struct HeaacDevice {
     int device;
     float *d_tab;
     uint16_t *d_rev;
     void *d_work;
     unsigned *d_queue;      // frame-queue heads of the kernels that draw frames dynamically (one set per lane)
+    // X hand-over side data: a page of zeros, then per workspace set one byte per frame = the number of QMF bands of
+    // the frame's X rows the HF / PS stage has stored (the bands above are +0 and are not written; the synthesis
+    // kernel reads them from the zero page instead)
+    unsigned char *d_aux;
     size_t work_bytes;
     size_t max_frames;
     size_t chunk;
@@ -151,10 +156,12 @@ extern "C" int heaac_device_create(HeaacDevice **out, size_t max_frames)
     if (hipMalloc((void **)&d->d_tab, sizeof(t->f)) != hipSuccess ||
         hipMalloc((void **)&d->d_rev, sizeof(t->rev)) != hipSuccess ||
         hipMalloc((void **)&d->d_queue, 64 * HE_MAX_LANES) != hipSuccess ||
+        hipMalloc((void **)&d->d_aux, HE_ZERO_BYTES + (size_t)(d->sets > 0 ? d->sets : 1) * (d->chunk ? d->chunk : 1)) != hipSuccess ||
         (d->work_bytes && hipMalloc(&d->d_work, d->work_bytes) != hipSuccess))
         rc = HEAAC_ERR_NOMEM;
     if (rc == HEAAC_OK &&
-        (hipMemcpy(d->d_tab, t->f, sizeof(t->f), hipMemcpyHostToDevice) != hipSuccess ||
+        (hipMemset(d->d_aux, 0, HE_ZERO_BYTES) != hipSuccess ||
+         hipMemcpy(d->d_tab, t->f, sizeof(t->f), hipMemcpyHostToDevice) != hipSuccess ||
          hipMemcpy(d->d_rev, t->rev, sizeof(t->rev), hipMemcpyHostToDevice) != hipSuccess))
         rc = HEAAC_ERR_HIP;
     free(t);
@@ -181,6 +188,7 @@ extern "C" void heaac_device_destroy(HeaacDevice *d)
     if (d->d_rev) (void)hipFree(d->d_rev);
     if (d->d_work) (void)hipFree(d->d_work);
     if (d->d_queue) (void)hipFree(d->d_queue);
+    if (d->d_aux) (void)hipFree(d->d_aux);
     for (int k = 0; k < HE_MAX_LANES; k++) {
         if (d->lane[k]) (void)hipStreamDestroy(d->lane[k]);
         if (d->join[k]) (void)hipEventDestroy(d->join[k]);
@@ -321,7 +329,9 @@ extern "C" int heaac_he_decode_batch_ex(HeaacDevice *dev, int cfg, int flags,
                              d_sbr + f0, d_hdr, (unsigned)(n_hdr > 0xffffu ? 0x10000u : n_hdr), d_ps ? d_ps + f0 : NULL,
                              d_state_in + f0 * words, d_state_out + f0 * words,
                              (char *)d_pcm + f0 * pcm_bytes, pcm_format,
-                             ws_W, ws_X, dev->d_queue + 16 * k, nc, 0, flags, lanes ? dev->lane[k] : s);
+                             ws_W, ws_X, dev->d_queue + 16 * k,
+                             dev->d_aux + HE_ZERO_BYTES + (size_t)k * dev->chunk, (const float *)dev->d_aux,
+                             nc, 0, flags, lanes ? dev->lane[k] : s);
     }
     if (lanes) {
         // always rejoin, also after a failed launch (a capture must not be left forked)

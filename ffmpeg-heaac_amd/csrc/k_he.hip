@@ -442,7 +442,8 @@ __global__ __launch_bounds__(SYN_WAVES_F32 * WAVE)
 void k_synth(const float *__restrict__ g_tab, const float *g_X,
              const float *g_state_in, float *g_state_out, int state_words, int off_syn0,
              int nout, void *__restrict__ g_pcm, float scale, float bias,
-             unsigned long long n_frames, unsigned long long pcm_frame0, unsigned *g_queue)
+             unsigned long long n_frames, unsigned long long pcm_frame0, unsigned *g_queue,
+             const unsigned char *__restrict__ g_xtop, const float *__restrict__ g_zero)
 {
     constexpr int NW = SYN_WAVES_F32;
     __shared__ SynLdsT<NW> S;
@@ -453,8 +454,11 @@ void k_synth(const float *__restrict__ g_tab, const float *g_X,
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
     SynWave &w = S.w[wave];
+    // Bands the HF / PS stage did not store (they are +0: g_xtop, one byte per frame) come from a page of zeros: the
+    // lanes that would load them aim at that page instead (an address select, no branch around the loads).
     auto load_unit = [&](unsigned long long f, int ch, SynIn &d) {
-        const float *X0 = g_X + (f * 2 + ch) * (2 * 38 * 64);
+        const int xt = __builtin_amdgcn_readfirstlane((int)g_xtop[f]);
+        const float *X0 = (lane & 15) * 4 < xt ? g_X + (f * 2 + ch) * (2 * 38 * 64) : g_zero;
         syn_load(X0, X0 + 38 * 64, g_state_in + f * state_words + off_syn0 + ch * HEAAC_ST_SYNTH, lane, d);
     };
     // the frame in work and the next one are known (FrameFeed, k_common.h: two frames per ticket)
@@ -691,6 +695,7 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
                                const float *d_state_in, float *d_state_out,
                                void *d_pcm, int pcm_format,
                                float *d_ws_W, float *d_ws_X, unsigned *d_queue,
+                               unsigned char *d_xtop, const float *d_zero,
                                size_t n, size_t pcm_frame0, int flags, hipStream_t s)
 {
     const int ncore = cfg == HEAAC_CFG_HEV1 ? 2 : 1;
@@ -712,6 +717,8 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
     // queue heads of the kernels that draw frames dynamically (k_hfps: [0], k_synth: [2]); the static
     // stride stays where it measured faster (k_core_ana, k_hfadj: neighbouring waves share lines)
     if (hipMemsetAsync(d_queue, 0, 64, s) != hipSuccess) return HEAAC_ERR_HIP;
+    // every frame's X rows are whole (64 bands) unless the fused HF + PS kernel says otherwise
+    if (hipMemsetAsync(d_xtop, 64, n, s) != hipSuccess) return HEAAC_ERR_HIP;
     hipLaunchKernelGGL(k_core_ana, dim3(he_grid((units + 1) / 2, CA_WAVES)), dim3(CA_WAVES * WAVE), 0, s,
                        d_tab, d_rev, d_coeffs, d_ics, d_state_in, d_state_out, words, ncore,
                        off_saved0, off_sbr0, d_ws_W, 1 / (-1024 * sf_scale), units);
@@ -720,7 +727,7 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
         // frames with another PS layout (it skips the rest)
         const int off_ps = off_syn0 + 2 * HEAAC_ST_SYNTH;
         int rc = heaac_launch_hfps(d_tab, d_sbr, d_hdr, n_hdr, d_ps, d_ws_W, d_state_in, d_state_out, words,
-                                   off_sbr0, off_ps, d_ws_X, n, d_queue, s);
+                                   off_sbr0, off_ps, d_ws_X, n, d_queue, d_xtop, s);
         if (rc != HEAAC_OK) return rc;
         rc = heaac_launch_ps(d_tab, d_ps, d_sbr, d_hdr, n_hdr, d_state_in, d_state_out, words, off_ps, d_ws_X, n, 2, s);
         if (rc != HEAAC_OK) return rc;
@@ -753,15 +760,15 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
     if (pcm_format == HEAAC_PCM_F32_PLANAR)
         hipLaunchKernelGGL((k_synth<HEAAC_PCM_F32_PLANAR>), g, b, 0, s, d_tab, d_ws_X, d_state_in, d_state_out,
                            words, off_syn0, nout, d_pcm, scale, bias,
-                           (unsigned long long)n, (unsigned long long)pcm_frame0, d_queue + 2);
+                           (unsigned long long)n, (unsigned long long)pcm_frame0, d_queue + 2, d_xtop, d_zero);
     else if (pcm_format == HEAAC_PCM_S16_INTERLEAVED)
         hipLaunchKernelGGL((k_synth<HEAAC_PCM_S16_INTERLEAVED>), g, b, 0, s, d_tab, d_ws_X, d_state_in, d_state_out,
                            words, off_syn0, nout, d_pcm, scale, bias,
-                           (unsigned long long)n, (unsigned long long)pcm_frame0, d_queue + 2);
+                           (unsigned long long)n, (unsigned long long)pcm_frame0, d_queue + 2, d_xtop, d_zero);
     else if (simd)
         hipLaunchKernelGGL((k_synth<HEAAC_PCM_S16_INTERLEAVED_SSE2>), g, b, 0, s, d_tab, d_ws_X, d_state_in, d_state_out,
                            words, off_syn0, nout, d_pcm, scale, bias,
-                           (unsigned long long)n, (unsigned long long)pcm_frame0, d_queue + 2);
+                           (unsigned long long)n, (unsigned long long)pcm_frame0, d_queue + 2, d_xtop, d_zero);
     else
         return HEAAC_ERR_ARG;
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;

@@ -78,7 +78,8 @@ __global__ __launch_bounds__(HFPS_WAVES * WAVE)
 void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g_sbr,
             const HeaacSbrHeader *__restrict__ g_hdr, unsigned n_hdr, const HeaacPsFrame *__restrict__ g_ps,
             const float *g_W, const float *g_state_in, float *g_state_out, int state_words,
-            int off_sbr, int off_ps, float *g_X, unsigned long long n_frames, unsigned *g_queue)
+            int off_sbr, int off_ps, float *g_X, unsigned long long n_frames, unsigned *g_queue,
+            unsigned char *__restrict__ g_xtop)
 {
     using WT = PsWaveT<false>;
     static_assert(WT::SCR <= HF_XLOW_WORDS, "|s|^2 / subL / subR lie over X_low");
@@ -168,8 +169,13 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
         } else {
             // ff_ps_apply(..., sbr->kx[1] + sbr->m[1]): the header is still in the HF stage's LDS
             const int top = __builtin_amdgcn_readfirstlane(H.h.kx + H.h.m);
+            // sbr_x_gen's first i_Temp slots follow the previous frame's range (aacsbr.c:1419-1432): X is +0 above `top`
+            // in EVERY slot if there are no such slots or that range ends inside this one
+            const int t_old = H.c[0].t_env_num_env_old;
+            const bool x_zero_above = __builtin_amdgcn_readfirstlane(
+                2 * t_old - 32 <= 0 || (int)g_sbr[f].kx_old + (int)g_sbr[f].m_old <= ((top + 15) & ~15));
             ps_frame<false, true>(W, g_tab, &g_ps[f], top, st_in + off_ps, st_out + off_ps, Xf, lane, wave, col,
-                                  prefetch_next);
+                                  prefetch_next, g_xtop + f, x_zero_above);
         }
         feed.advance();
     }
@@ -206,14 +212,14 @@ extern "C" int heaac_launch_hfps(const float *d_tab, const HeaacSbrFrame *d_sbr,
                                  unsigned n_hdr, const HeaacPsFrame *d_ps, const float *d_ws_W,
                                  const float *d_state_in, float *d_state_out, int state_words,
                                  int off_sbr, int off_ps, float *d_ws_X, size_t n, unsigned *d_queue,
-                                 hipStream_t s)
+                                 unsigned char *d_xtop, hipStream_t s)
 {
     if (!n) return HEAAC_OK;
     unsigned long long g = (n + HFPS_WAVES - 1) / HFPS_WAVES;
     if (g > 256) g = 256;
     hipLaunchKernelGGL(k_hfps, dim3((unsigned)g), dim3(HFPS_WAVES * WAVE), 0, s, d_tab, d_sbr, d_hdr, n_hdr, d_ps,
                        d_ws_W, d_state_in, d_state_out, state_words, off_sbr, off_ps, d_ws_X,
-                       (unsigned long long)n, d_queue);
+                       (unsigned long long)n, d_queue, d_xtop);
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
 }
 

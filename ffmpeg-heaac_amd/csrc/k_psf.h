@@ -212,7 +212,7 @@ __device__ __forceinline__ void hybrid_fir(const float *in, const float *filt, f
 // they are needed, late enough to survive in L2 until then.
 typedef GBufT<2> GBufSO;          // the state record out (aux 2 = non-temporal): written once per frame, read by the next launch
 typedef GBufT<0> GBufXR;          // the X rows of the slot loop (nt measured +1.5 %: the hybrid synthesis completes these lines later)
-template <bool HEAVY, bool ALIGNED8, bool DUAL, class W, class Hook = NoHook>
+template <bool HEAVY, bool ALIGNED8, bool DUAL, int X_BANDS = 64, class W, class Hook = NoHook>
 __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, const signed char *kti,
                                         int is34, int kh, bool clear_state,
                                         const GBuf &SI, const GBufSO &SO, const GBufXR &X,
@@ -394,7 +394,11 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
             lv = dual ? lv2 : lv;
             rr = dual ? rr2 : rr;
         }
-        {
+        // Bands from X_BANDS on are +0 in every slot and are not stored (ps_frame).  X_BANDS is a template parameter: as a
+        // run-time value the lane mask lives in a scalar register pair across the whole unrolled loop and is spilled and
+        // restored around every slot (+4 % kernel time); aiming the lanes past the buffer's range instead (the bounds
+        // check drops the store) saves a quarter of what masking them saves.
+        if (X_BANDS == 64 || q < X_BANDS) {
             const int qb = opaque(qs4);
             X.stb(lv.x, qb, n * 64);          X.stb(lv.y, qb, XP + n * 64);
             X.stb(rr.x, qb, 2 * XP + n * 64); X.stb(rr.y, qb, 3 * XP + n * 64);
@@ -480,7 +484,8 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
                                          const HeaacPsFrame *g_p, int top_qmf,
                                          const float *st_in, float *st_out,
                                          float *Xrec /* [2][2][38][64]: in: mono in [0], out: left, right */,
-                                         int lane_in, int wave, const v2f (&hfcol)[32], Hook hook = Hook())
+                                         int lane_in, int wave, const v2f (&hfcol)[32], Hook hook = Hook(),
+                                         unsigned char *x_bands_out = nullptr, bool x_zero_above_top = false)
 {
     static_assert(!(GENERAL && FUSED), "the fused path is the baseline layout only");
     // `lane` is redefined opaquely at every phase: values derived from it (LDS addresses,
@@ -756,10 +761,16 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
         }
     }
     wave_sync();
+    bool h_ok = true;
+    float h_prev[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
     if (lane < nr_par) {
         const int b = lane;
         int opd_hist = opd_hist0, ipd_hist = ipd_hist0;
         if (switched && b < 17) { opd_hist = 0; ipd_hist = 0; }        // ipdopd_reset
+        if constexpr (FUSED) {
+            // row 0 = the previous frame's matrices: the first end of the first envelope's interpolation
+            h_prev[0] = w.Hs[0][0][b]; h_prev[1] = w.Hs[0][1][b]; h_prev[2] = w.Hs[0][2][b]; h_prev[3] = w.Hs[0][3][b];
+        }
         // (the LUT rows hl[e] of every envelope were fetched ahead; the IPD/OPD history
         // chain runs over them)
 #pragma unroll
@@ -780,6 +791,18 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
                 h12i = h12 * ipd_adj_im; h12 = h12 * ipd_adj_re;
                 h21i = h21 * opd_im;     h21 = h21 * opd_re;
                 h22i = h22 * ipd_adj_im; h22 = h22 * ipd_adj_re;
+            }
+            if constexpr (FUSED) {
+                // (see x_bands below) one factor of h11 / h21 and one of h12 / h22 safely positive over the envelope
+                const float hn[4] = { h11, h12, h21, h22 };
+                bool bounded = true;
+#pragma unroll
+                for (int j = 0; j < 4; j++) bounded = bounded && fabsf(hn[j]) <= 16.0f && fabsf(h_prev[j]) <= 16.0f;
+                const bool left = (h_prev[0] > 1e-3f && hn[0] > 1e-3f) || (h_prev[2] > 1e-3f && hn[2] > 1e-3f);
+                const bool right = (h_prev[1] > 1e-3f && hn[1] > 1e-3f) || (h_prev[3] > 1e-3f && hn[3] > 1e-3f);
+                h_ok = h_ok && bounded && left && right;
+#pragma unroll
+                for (int j = 0; j < 4; j++) h_prev[j] = hn[j];
             }
             if constexpr (GENERAL) {
                 w.Hs[e + 1][0][b] = h11; w.Hs[e + 1][1][b] = h11i;
@@ -833,6 +856,25 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     bool aligned8 = true;
     for (int e = 1; e <= p.num_env; e++) aligned8 = aligned8 && ((p.border_position[e] & 7) == 7);
     aligned8 = __builtin_amdgcn_readfirstlane(aligned8);
+    // ---- which X bands leave the wave (fused kernel, baseline layout) ----
+    // Above `top` the mono signal is +0 (sbr_x_gen writes the literal there; the caller says whether the first slots,
+    // which follow the PREVIOUS frame's range, agree) and so is its delay line (cleared, aacps.c:980-983); none of those
+    // bands runs the all-pass chain once top >= 23.  What the mixing makes of them is h11 (+0) + h21 (+0): +0 unless
+    // BOTH factors are negative (or not finite), and likewise h12 / h22 for the right channel.  If, for every
+    // parameter band that covers such a band and every envelope, one factor of each pair stays above 1e-3 at both ends
+    // of its interpolation (and all four inside +-16, so that 32 rounded steps cannot carry it below zero: h_ok, formed
+    // with the matrices above), every X value of the bands from top (rounded up to 64 bytes of a row) on is exactly
+    // +0: they are not stored, the frame's byte in x_bands_out says so, and k_synth reads them from a page of zeros.
+    int x_bands = 64;
+    if constexpr (FUSED) {
+        const int top16 = (top_qmf + 15) & ~15;
+        // (only the straight-line slot loop has the store variants: every border at 8k - 1, what frame class 0 gives)
+        if (x_zero_above_top && aligned8 && top16 < 64 && top16 >= 32 && p.num_env >= 1) {
+            const bool bad = lane < nr_par && lane >= kMem20.kti[top16 + 7] && !h_ok;
+            if (__builtin_amdgcn_readfirstlane(__ballot(bad) == 0ull)) x_bands = top16;
+        }
+        if (x_bands_out && x_bands != 64 && lane == 0) *x_bands_out = (unsigned char)x_bands;
+    }
     // ---- pass 1: hybrid bands 0..63 = all sub-subbands + the first QMF bands ----
     {
         const int kh = GENERAL ? lane : (lane < 3 ? lane : lane >= 57 ? lane - 54 : lane + 7);
@@ -849,7 +891,13 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
             // lanes 57..63 also carry the bands 64..70 of their own columns
             const bool dual = lane >= 57;
             const int kh2 = lane + 7;
-            if (aligned8)
+            if (aligned8 && x_bands == 48)
+                ps_band<true, true, true, 48>(w, g_tab, M.kti, is34, kh, kh >= top, SI, SO, XR, is_sub, qcol, col,
+                                              dual, kh2, kh2 >= top, hook);
+            else if (aligned8 && x_bands == 32)
+                ps_band<true, true, true, 32>(w, g_tab, M.kti, is34, kh, kh >= top, SI, SO, XR, is_sub, qcol, col,
+                                              dual, kh2, kh2 >= top, hook);
+            else if (aligned8)
                 ps_band<true, true, true>(w, g_tab, M.kti, is34, kh, kh >= top, SI, SO, XR, is_sub, qcol, col,
                                           dual, kh2, kh2 >= top, hook);
             else

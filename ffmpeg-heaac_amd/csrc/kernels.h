@@ -30,6 +30,7 @@ int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cfg,
                     const float *d_state_in, float *d_state_out,
                     void *d_pcm, int pcm_format,
                     float *d_ws_W, float *d_ws_X, unsigned *d_queue,
+                    unsigned char *d_xtop, const float *d_zero,
                     size_t n, size_t pcm_frame0, int flags, hipStream_t s);
 
 int heaac_launch_ps(const float *d_tab, const HeaacPsFrame *d_ps, const HeaacSbrFrame *d_sbr,
@@ -39,7 +40,8 @@ int heaac_launch_ps(const float *d_tab, const HeaacPsFrame *d_ps, const HeaacSbr
 int heaac_launch_hfps(const float *d_tab, const HeaacSbrFrame *d_sbr, const HeaacSbrHeader *d_hdr,
                       unsigned n_hdr, const HeaacPsFrame *d_ps, const float *d_ws_W,
                       const float *d_state_in, float *d_state_out, int state_words,
-                      int off_sbr, int off_ps, float *d_ws_X, size_t n, unsigned *d_queue, hipStream_t s);
+                      int off_sbr, int off_ps, float *d_ws_X, size_t n, unsigned *d_queue, unsigned char *d_xtop,
+                      hipStream_t s);
 
 int heaac_launch_qmf_analysis(const float *d_tab, const float *d_in, const float *d_xh_in,
                               float *d_xh_out, float *d_W, float scale, size_t n, hipStream_t s);
