@@ -485,3 +485,51 @@ def test_simd_float_to_int16_configuration(pkg, oracle, dev, cfgname):
             assert _mismatch(d_state.cpu().numpy(), state)[0] == 0
             sat |= bool((ref == 32767).any() and (ref == -32768).any())
         assert sat
+
+
+def test_unstored_x_bands_are_never_read(pkg, oracle, dev):
+    """The fused HF + PS kernel leaves out the X bands it has proved to be +0 (k_psf.h: x_bands) and k_synth takes them
+    from a page of zeros.  With the hand-over workspace poisoned by NaN beforehand, PCM and state still equal the
+    oracle's bit for bit, some frames do leave bands unwritten (the NaN is still there afterwards: the mechanism is
+    exercised), and others -- where both mixing factors of a channel can be negative -- write all of them."""
+    import ctypes as C
+    import torch
+    synth = _synth()
+    cfg = pkg.CFG_HEV2
+    n = 192
+    hdr = synth.default_headers(pkg)                       # kx + m = 45: bands 48..63 are candidates
+    rng = np.random.default_rng(2024)
+    frames = list(synth.he_stream(rng, cfg, n, 3, hdr))
+    small = pkg.Device(n)
+    try:
+        pW, pX, chunk = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        assert pkg.lib().heaac_debug_workspace(small._h, C.byref(pW), C.byref(pX), C.byref(chunk)) == 0
+        assert chunk.value >= n
+        xrec = 2 * 2 * 38 * 64
+        state = np.zeros((n, pkg.STATE_WORDS[cfg]), np.float32)
+        d_state = torch.from_numpy(state).cuda()
+        d_hdr = pkg.to_device(hdr)
+        skipped = full = 0
+        for fr in frames:
+            # poison X of every frame of the chunk (device to device: kind 3)
+            poison = torch.full((n * xrec,), float("nan"), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            hip = C.CDLL("libamdhip64.so")
+            assert hip.hipMemcpy(C.c_void_p(pX.value), C.c_void_p(poison.data_ptr()), C.c_size_t(n * xrec * 4), 3) == 0
+            ref_pcm, state = oracle.he_decode_batch(cfg, fr["coeffs"], fr["ics"], fr["sbr"], hdr, fr["ps"], state)
+            pcm, d_state = small.he_decode(cfg, torch.from_numpy(fr["coeffs"]).cuda(), pkg.to_device(fr["ics"]),
+                                           pkg.to_device(fr["sbr"]), d_hdr, pkg.to_device(fr["ps"]), d_state)
+            torch.cuda.synchronize()
+            assert np.array_equal(pcm.cpu().numpy().view(np.uint32), ref_pcm.view(np.uint32))
+            assert np.array_equal(d_state.cpu().numpy().view(np.uint32), state.view(np.uint32))
+            back = torch.empty(n * xrec, dtype=torch.float32, device="cuda")
+            assert hip.hipMemcpy(C.c_void_p(back.data_ptr()), C.c_void_p(pX.value), C.c_size_t(n * xrec * 4), 3) == 0
+            x = back.cpu().numpy().reshape(n, 2, 2, 38, 64)[:, :, :, :32]
+            left_out = np.isnan(x[..., 48:]).all(axis=(1, 2, 3, 4))
+            written = ~np.isnan(x[..., 48:]).any(axis=(1, 2, 3, 4))
+            assert (left_out | written).all()                  # a frame stores all of its upper bands or none
+            assert not np.isnan(x[..., :48]).any()
+            skipped += int(left_out.sum()); full += int(written.sum())
+        assert skipped > n and full > n // 4, (skipped, full)
+    finally:
+        small.close()
