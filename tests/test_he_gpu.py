@@ -490,17 +490,22 @@ def test_simd_float_to_int16_configuration(pkg, oracle, dev, cfgname):
 def test_unstored_x_bands_are_never_read(pkg, oracle, dev):
     """The fused HF + PS kernel leaves out the X bands it has proved to be +0 (k_psf.h: x_bands) and k_synth takes them
     from a page of zeros.  With the hand-over workspace poisoned by NaN beforehand, PCM and state still equal the
-    oracle's bit for bit, some frames do leave bands unwritten (the NaN is still there afterwards: the mechanism is
-    exercised), and others -- where both mixing factors of a channel can be negative -- write all of them."""
+    oracle's bit for bit, over headers whose SBR range ends at band 45, 41, 38 (48 bands stored) and 27, 23 (32 bands);
+    some frames do leave bands unwritten (the NaN is still there afterwards: the mechanism is exercised), and others --
+    where both mixing factors of a channel can be negative -- write all of them."""
     import ctypes as C
     import torch
     synth = _synth()
     cfg = pkg.CFG_HEV2
-    n = 192
-    hdr = synth.default_headers(pkg)                       # kx + m = 45: bands 48..63 are candidates
+    n = 224
+    hdr = synth.default_headers(pkg, extra=True)
+    hc = np.arange(n) % len(hdr)
+    top16 = ((hdr["kx"].astype(int) + hdr["m"].astype(int) + 15) & ~15)[hc]
+    assert set(top16.tolist()) == {32, 48}
     rng = np.random.default_rng(2024)
-    frames = list(synth.he_stream(rng, cfg, n, 3, hdr))
+    frames = list(synth.he_stream(rng, cfg, n, 3, hdr, hdr_choice=hc))
     small = pkg.Device(n)
+    hip = C.CDLL("libamdhip64.so")
     try:
         pW, pX, chunk = C.c_void_p(), C.c_void_p(), C.c_size_t()
         assert pkg.lib().heaac_debug_workspace(small._h, C.byref(pW), C.byref(pX), C.byref(chunk)) == 0
@@ -509,12 +514,12 @@ def test_unstored_x_bands_are_never_read(pkg, oracle, dev):
         state = np.zeros((n, pkg.STATE_WORDS[cfg]), np.float32)
         d_state = torch.from_numpy(state).cuda()
         d_hdr = pkg.to_device(hdr)
-        skipped = full = 0
+        skipped = {32: 0, 48: 0}
+        full = 0
         for fr in frames:
             # poison X of every frame of the chunk (device to device: kind 3)
             poison = torch.full((n * xrec,), float("nan"), dtype=torch.float32, device="cuda")
             torch.cuda.synchronize()
-            hip = C.CDLL("libamdhip64.so")
             assert hip.hipMemcpy(C.c_void_p(pX.value), C.c_void_p(poison.data_ptr()), C.c_size_t(n * xrec * 4), 3) == 0
             ref_pcm, state = oracle.he_decode_batch(cfg, fr["coeffs"], fr["ics"], fr["sbr"], hdr, fr["ps"], state)
             pcm, d_state = small.he_decode(cfg, torch.from_numpy(fr["coeffs"]).cuda(), pkg.to_device(fr["ics"]),
@@ -525,11 +530,15 @@ def test_unstored_x_bands_are_never_read(pkg, oracle, dev):
             back = torch.empty(n * xrec, dtype=torch.float32, device="cuda")
             assert hip.hipMemcpy(C.c_void_p(back.data_ptr()), C.c_void_p(pX.value), C.c_size_t(n * xrec * 4), 3) == 0
             x = back.cpu().numpy().reshape(n, 2, 2, 38, 64)[:, :, :, :32]
-            left_out = np.isnan(x[..., 48:]).all(axis=(1, 2, 3, 4))
-            written = ~np.isnan(x[..., 48:]).any(axis=(1, 2, 3, 4))
-            assert (left_out | written).all()                  # a frame stores all of its upper bands or none
-            assert not np.isnan(x[..., :48]).any()
-            skipped += int(left_out.sum()); full += int(written.sum())
-        assert skipped > n and full > n // 4, (skipped, full)
+            for f in range(n):
+                t = int(top16[f])
+                upper = np.isnan(x[f, ..., t:])
+                assert upper.all() or not upper.any(), f              # a frame stores all of its upper bands or none
+                assert not np.isnan(x[f, ..., :t]).any(), f
+                if upper.all():
+                    skipped[t] += 1
+                else:
+                    full += 1
+        assert skipped[48] > n // 2 and skipped[32] > n // 8 and full > n // 4, (skipped, full)
     finally:
         small.close()
