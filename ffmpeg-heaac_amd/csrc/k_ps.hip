@@ -4,7 +4,7 @@
 //
 //   k_hfps         HF adjustment (k_hf.h) fused with baseline PS: the HE-AACv2 hot path
 //   k_ps<false,8>  baseline PS alone (20 bands, no IPD/OPD) -- the unfused A/B path
-//   k_ps<true,4>   every other layout: 34 bands, IPD/OPD, 20 <-> 34 switches, PS off
+//   k_ps<true,5>   every other layout: 34 bands, IPD/OPD, 20 <-> 34 switches, PS off
 //
 // Lane = frequency band.  Every recursion of the reference (transient smoother, all-pass chain,
 // H-matrix interpolation) runs over time inside one lane, so the reference's operation order is
@@ -27,15 +27,17 @@ void k_ps(const float *__restrict__ g_tab, const HeaacPsFrame *__restrict__ g_ps
     __shared__ HeaacPsFrame s_p[WAVES];
     __shared__ float s_inb[WAVES][WT::NLOW][44][2];
     __shared__ float s_scr[WAVES][WT::SCR];          // |s|^2, later subL / subR
-    __shared__ float s_sub[WAVES][WT::NSUB][SUB_STRIDE];
+    __shared__ float s_sub[WAVES][WT::SUBROWS][SUB_STRIDE];
     __shared__ float s_pw[WAVES][WT::NPAR][33];
     __shared__ float s_Hs[WAVES][6][WT::NH][WT::NPAR];
     // IPD/OPD index rows exist only in the general variant (the baseline one never touches them)
     __shared__ signed char s_idx[WAVES][GENERAL ? 4 : 2][5][WT::NPAR];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
+    // mixed sub-subband outputs: baseline = two blocks in the scratch; general = left in place over the sub-subband
+    // rows, right in the scratch
     WT W = { s_p[wave], s_inb[wave], s_scr[wave], s_sub[wave],
-             reinterpret_cast<float (*)[SUB_STRIDE]>(s_scr[wave]),
-             reinterpret_cast<float (*)[SUB_STRIDE]>(s_scr[wave] + (WT::NSUB + 1) * SUB_STRIDE),
+             GENERAL ? s_sub[wave] : reinterpret_cast<float (*)[SUB_STRIDE]>(s_scr[wave]),
+             reinterpret_cast<float (*)[SUB_STRIDE]>(s_scr[wave] + (GENERAL ? 0 : (WT::NSUB + 1) * SUB_STRIDE)),
              s_pw[wave], s_Hs[wave], s_idx[wave][0], s_idx[wave][1],
              s_idx[wave][GENERAL ? 2 : 0], s_idx[wave][GENERAL ? 3 : 0],
              g_tab + TB_F20_0_8, g_tab + TB_G1_Q2 };
@@ -183,7 +185,7 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
 }
 
 #define PS_WAVES_20 8
-#define PS_WAVES_GEN 4
+#define PS_WAVES_GEN 5
 
 // variants: bit 0 = baseline kernel, bit 1 = general kernel
 extern "C" int heaac_launch_ps(const float *d_tab, const HeaacPsFrame *d_ps, const HeaacSbrFrame *d_sbr,

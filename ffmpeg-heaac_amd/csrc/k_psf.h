@@ -34,6 +34,7 @@ struct BandMembers {
     unsigned char order[92];      // hybrid bands sorted by (parameter band, k)
     unsigned char first[36];      // first[i] .. first[i+1]: members of band i
     int split;                    // bands [0,split) and [split,nr_par) hold about half the members each
+    int quarter[5];               // the same in four parts: bands [quarter[j], quarter[j + 1])
 };
 constexpr BandMembers make_members(const KtoI &t, int nr_bands, int nr_par)
 {
@@ -49,6 +50,13 @@ constexpr BandMembers make_members(const KtoI &t, int nr_bands, int nr_par)
     m.split = nr_par;
     for (int i = 0; i <= nr_par; i++)
         if (2 * m.first[i] >= pos) { m.split = i; break; }
+    m.quarter[0] = 0;
+    m.quarter[4] = nr_par;
+    for (int j = 1; j < 4; j++) {
+        m.quarter[j] = nr_par;
+        for (int i = m.quarter[j - 1]; i <= nr_par; i++)
+            if (4 * m.first[i] >= j * pos) { m.quarter[j] = i; break; }
+    }
     return m;
 }
 __device__ constexpr BandMembers kMem20 = make_members(k_to_i_20_c, 71, 20);
@@ -66,9 +74,15 @@ struct PsWaveT {
     static constexpr bool IS_GENERAL = GENERAL;
     static constexpr int NH = GENERAL ? 8 : 4;      // H rows kept: re+im, or re only (IPD/OPD off)
     static constexpr int PNS = NB + 1;              // |s|^2 row stride (72 / 92 floats)
+    // The general layout saves LDS for a fifth wave per CU (round 3): the left mix of a sub-subband overwrites the
+    // sub-subband signal it was made from (one more row: the scratch row of the lanes that are not sub-subbands), and
+    // |s|^2 is formed for sixteen slots at a time.
+    static constexpr int SUBROWS = GENERAL ? NSUB + 1 : NSUB;
+    static constexpr int PN_SLOTS = GENERAL ? 16 : 32;
+    static constexpr int MIXROWS = GENERAL ? (NSUB + 1) : 2 * (NSUB + 1);     // rows of mixed output kept in the scratch
     // scratch shared by |s|^2 (until the band powers are formed) and the mixed
     // sub-subband outputs (written afterwards): max of the two, in floats
-    static constexpr int SCR = (32 * PNS > 2 * (NSUB + 1) * SUB_STRIDE) ? 32 * PNS : 2 * (NSUB + 1) * SUB_STRIDE;
+    static constexpr int SCR = (PN_SLOTS * PNS > MIXROWS * SUB_STRIDE) ? PN_SLOTS * PNS : MIXROWS * SUB_STRIDE;
     // Views of separate __shared__ arrays (distinct objects for the alias analysis).
     HeaacPsFrame &p;
     float (*inb)[44][2];               // [NLOW] hybrid analysis input: 6 history + 38 current slots
@@ -296,6 +310,7 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
     v2f hA = zero, hB = zero, hA_step = zero, hB_step = zero;        // (h11r, h12r), (h21r, h22r)
     v2f hAi = zero, hBi = zero, hAi_step = zero, hBi_step = zero;    // imaginary parts (IPD/OPD)
     int e = -1, stop = -1;
+    v2f sub_back[2] = { zero, zero };
 
     // Fully unrolled over the 32 slots: ring positions and column indices are static.
 #pragma unroll
@@ -333,8 +348,16 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
             // unconditional: as select operands the compiler would put each one under an
             // exec-mask branch of its own.
             v2f subv = srow[n];
-            v2f sub2 = srow[n >= 2 ? n - 2 : 0];                  // sub-subbands are all-pass bands: D = 2
-            asm volatile("" : "+v"(subv), "+v"(sub2));
+            v2f sub2;                                             // sub-subbands are all-pass bands: D = 2
+            if constexpr (W::IS_GENERAL) {
+                // (the row is being overwritten by the left mix: the two samples back are kept in registers)
+                sub2 = sub_back[n & 1];
+                sub_back[n & 1] = subv;
+                asm volatile("" : "+v"(subv));
+            } else {
+                sub2 = srow[n >= 2 ? n - 2 : 0];
+                asm volatile("" : "+v"(subv), "+v"(sub2));
+            }
             sv = is_sub ? subv : col[n];
             // state tail for the first slots (static register index per category)
             const v2f ap_d = n >= 2 ? (is_sub ? sub2 : col[n >= 2 ? n - 2 : 0]) : hst[12 + (n < 2 ? n : 0)];
@@ -383,6 +406,10 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
         if (HEAVY) {
             *reinterpret_cast<v2f *>(lrow + 2 * n) = lv;
             *reinterpret_cast<v2f *>(rrow + 2 * n) = rr;
+            if constexpr (W::IS_GENERAL) {
+                // new delay-line tail = s[k][18..31], stored as the slots pass (the sub-subband rows do not survive the loop)
+                if (n >= 18) SO.stb2(sv, opaque(kh * 8), HEAAC_PS_DELAY + (n - 18) * dl_stride);
+            }
         }
         if constexpr (DUAL) {
             // second role (aacps.c:738-752 with the one-slot delay, then :940-969)
@@ -408,6 +435,7 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
         if ((n & (PS_SCHED_GROUP - 1)) == PS_SCHED_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
     }
     // new delay-line tail = s[k][18..31]
+    if constexpr (!(HEAVY && W::IS_GENERAL))
 #pragma unroll
     for (int j = 0; j < 14; j++) {
         v2f v = col[18 + j];
@@ -455,6 +483,15 @@ __device__ __forceinline__ void band_power_range(const float *row, float *pw_col
         band_power_one<IS34, I0>(row, pw_col);
         band_power_range<IS34, I0 + 1, I1>(row, pw_col);
     }
+}
+template <bool IS34>
+__device__ __forceinline__ void band_power4(const float *row, float *pw_col, int quarter)
+{
+    constexpr BandMembers M = IS34 ? kMem34 : kMem20;
+    if (quarter == 0)      band_power_range<IS34, M.quarter[0], M.quarter[1]>(row, pw_col);
+    else if (quarter == 1) band_power_range<IS34, M.quarter[1], M.quarter[2]>(row, pw_col);
+    else if (quarter == 2) band_power_range<IS34, M.quarter[2], M.quarter[3]>(row, pw_col);
+    else                   band_power_range<IS34, M.quarter[3], M.quarter[4]>(row, pw_col);
 }
 template <bool IS34>
 __device__ __forceinline__ void band_power(const float *row, float *pw_col, int half)
@@ -548,8 +585,10 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
         // hybrid index of the lane's column (unless it is one of the nlow hybrid-filter inputs)
         const int kh_own = GENERAL ? (lane >= nsub ? lane : 64 + lane) : lane + 7;
         if (GENERAL ? (lane >= nsub || lane < P2) : lane >= 3) {
+            if constexpr (!GENERAL) {
 #pragma unroll
-            for (int n = 0; n < 32; n++) w.pn[n * WT::PNS + kh_own] = col[n].x * col[n].x + col[n].y * col[n].y;
+                for (int n = 0; n < 32; n++) w.pn[n * WT::PNS + kh_own] = col[n].x * col[n].x + col[n].y * col[n].y;
+            }
         } else {
             // hybrid analysis input (aacps.c:362-367): in[i][j+6] = L[.][j][i]
 #pragma unroll
@@ -646,7 +685,7 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     auto hybrid_put = [&](int ks, int n, float re, float im) {
         w.sub[ks][2 * n] = re;
         w.sub[ks][2 * n + 1] = im;
-        w.pn[n * WT::PNS + ks] = re * re + im * im;
+        if constexpr (!GENERAL) w.pn[n * WT::PNS + ks] = re * re + im * im;
     };
     if (!is34) {
         // 20-band layout: 10 sub-subbands x 32 slots = five passes of the wave; pass `it` forms the
@@ -706,16 +745,40 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     // ---- band power (aacps.c:673-678): members of each parameter band in ascending
     // hybrid-band order.  The member lists are compile-time constants, so the sums
     // unroll into straight-line LDS reads; two half-waves split the parameter bands.
-    {
+    if constexpr (GENERAL) {
+        // sixteen slots at a time: |s|^2 of the lane's column and (lanes below nsub) of its sub-subband row, then the
+        // sums with four lanes per slot, each a quarter of the parameter bands
+        const int kh_own = lane >= nsub ? lane : 64 + lane;
+        const bool has_col = lane >= nsub || lane < P2;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            if (has_col) {
+#pragma unroll
+                for (int n = 0; n < 16; n++) {
+                    const v2f c = col[16 * r + n];
+                    w.pn[n * WT::PNS + kh_own] = c.x * c.x + c.y * c.y;
+                }
+            }
+            if (lane < nsub) {
+#pragma unroll
+                for (int n = 0; n < 16; n++) {
+                    const float re = w.sub[lane][2 * (16 * r + n)], im = w.sub[lane][2 * (16 * r + n) + 1];
+                    w.pn[n * WT::PNS + lane] = re * re + im * im;
+                }
+            }
+            wave_sync();
+            const int n = lane & 15, quarter = lane >> 4;
+            const float *row = w.pn + n * WT::PNS;
+            if (is34) band_power4<true>(row, &w.pw[0][16 * r + n], quarter);
+            else      band_power4<false>(row, &w.pw[0][16 * r + n], quarter);
+            wave_sync();
+        }
+    } else {
         const int n = lane & 31, half = lane >> 5;
         const float *row = w.pn + n * WT::PNS;
-        if (is34) {
-            if constexpr (GENERAL) band_power<true>(row, &w.pw[0][n], half);
-        } else {
-            band_power<false>(row, &w.pw[0][n], half);
-        }
+        band_power<false>(row, &w.pw[0][n], half);
+        wave_sync();
     }
-    wave_sync();
     STAMP(3);
     lane = opaque(lane);
     // ---- transient detection (:681-692), one lane per parameter band ----
