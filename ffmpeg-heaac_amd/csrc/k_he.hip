@@ -178,14 +178,20 @@ void k_core_ana(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_
             const int k = lane;
             const float w0 = s_qmf_ds[k], w1 = s_qmf_ds[k + 64], w2 = s_qmf_ds[k + 128],
                         w3 = s_qmf_ds[k + 192], w4 = s_qmf_ds[k + 256];
-            // two slots per packed multiply / add
+            // Two slots per packed multiply / add.  Tap t of slot i is x[32 i + 319 - k - 64 t]: the sample that is tap 0
+            // of the slot pair (i, i + 1) is tap t of the pair (i + 2 t, i + 2 t + 1), so each pair reads ONE new sample pair
+            // from LDS and takes the other four from the pairs before it (10 -> 2 reads per pair: the fold was a quarter
+            // of this kernel's time, profiles/r03_experiments.md E28).
+            const float *xk = x + 319 - k;
+            v2f a1 = v2f{xk[-64], xk[-32]}, a2 = v2f{xk[-128], xk[-96]}, a3 = v2f{xk[-192], xk[-160]},
+                a4 = v2f{xk[-256], xk[-224]};
+#pragma unroll
             for (int i = 0; i < 32; i += 2) {
-                const float *xa = x + 32 * i + 319 - k, *xb = xa + 32;
-                const v2f f = bc(w0) * v2f{xa[0], xb[0]} + bc(w1) * v2f{xa[-64], xb[-64]} +
-                              bc(w2) * v2f{xa[-128], xb[-128]} + bc(w3) * v2f{xa[-192], xb[-192]} +
-                              bc(w4) * v2f{xa[-256], xb[-256]};
+                const v2f a0 = v2f{xk[32 * i], xk[32 * i + 32]};
+                const v2f f = bc(w0) * a0 + bc(w1) * a1 + bc(w2) * a2 + bc(w3) * a3 + bc(w4) * a4;
                 uu[i * 65 + k] = f.x;
                 uu[(i + 1) * 65 + k] = f.y;
+                a4 = a3; a3 = a2; a2 = a1; a1 = a0;
             }
         }
         wave_sync();
@@ -216,8 +222,13 @@ void k_core_ana(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_
             if (c == 1 && !have1) break;
             const float *uu = c ? w.x0u1 : w.tu;
             float *Wo = g_W + (c ? u1 : u0) * 2048;
-            for (int t = lane; t < 2048; t += WAVE) {
-                Wo[t] = uu[(t >> 6) * 65 + (t & 63)];
+            // four rows per pass, sixteen bytes per lane: 8 stores of 1 KiB instead of 32 of 256 bytes (the LDS rows have
+            // an odd stride, so their four floats are read one by one: two lanes per bank, the minimum for a wave)
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const int r = 4 * it + (lane >> 4), q = 4 * (lane & 15);
+                const float *sr = uu + r * 65 + q;
+                *reinterpret_cast<float4 *>(Wo + r * 64 + q) = make_float4(sr[0], sr[1], sr[2], sr[3]);
             }
         }
         wave_sync();
