@@ -257,54 +257,64 @@ __device__ __forceinline__ void hf_channel(const HfWave &w, const float *g_noise
     if (start) {
         HSTAMP(2);
         // ---- sbr_hf_inverse_filter (:1261-1313) + autocorrelate (:1232-1255) ----
-        if (lane < h.k0 && lane < 32) {
-            // the whole row first (all LDS reads in flight), then the five running sums
-            float x[80];
-            const float *xs = w.xlow + lane * XL_STRIDE;
+        // Three lanes per band, one lag each: every one of the reference's five running sums is
+        //   s0 += a c + b d,   s1 += a d - b c      with (a, b) = x[i], (c, d) = x[i + lag]
+        // for lag 0 (real_sum0; its s1 is a b - b a = +0), lag 1 (real_sum1, imag_sum1) and lag 2 (real_sum2, imag_sum2),
+        // each sum in the reference's own order; the boundary terms (:1244-1253) have the same form with i = 0 and
+        // i = 38.  21 bands per pass of the wave (one pass up to k0 = 21); the lag-0 lane of a band collects the eight
+        // values and solves for the two coefficients as before.
+        {
+            const int band_in_pass = (lane * 171) >> 9;                  // lane / 3 for lane < 128
+            const int lag = lane - 3 * band_in_pass;
+            const int k0 = h.k0 < 32 ? h.k0 : 32;
+            for (int first = 0; first < k0; first += 21) {
+                const int band = first + band_in_pass;
+                const bool active = lane < 63 && band < k0;
+                const float *xs = w.xlow + (active ? band : 0) * XL_STRIDE;
+                const float *xl = xs + 2 * lag;
+                float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 80; i++) x[i] = xs[i];
-            float r0 = 0.0f, r1 = 0.0f, i1 = 0.0f, r2 = 0.0f, i2 = 0.0f;
-#pragma unroll
-            for (int i = 1; i < 38; i++) {
-                const float a = x[2 * i], b = x[2 * i + 1];
-                r0 += a * a + b * b;
-                r1 += a * x[2 * i + 2] + b * x[2 * i + 3];
-                i1 += a * x[2 * i + 3] - b * x[2 * i + 2];
-                r2 += a * x[2 * i + 4] + b * x[2 * i + 5];
-                i2 += a * x[2 * i + 5] - b * x[2 * i + 4];
+                for (int i = 1; i < 38; i++) {
+                    const float a = xs[2 * i], b = xs[2 * i + 1], c = xl[2 * i], d = xl[2 * i + 1];
+                    s0 += a * c + b * d;
+                    s1 += a * d - b * c;
+                }
+                // sums with the i = 0 term (phi[.][1][.] of the reference) and with the i = 38 term (phi[.][0][.])
+                const float lo0 = s0 + xs[0] * xl[0] + xs[1] * xl[1];
+                const float lo1 = s1 + xs[0] * xl[1] - xs[1] * xl[0];
+                const float hi0 = s0 + xs[76] * xl[76] + xs[77] * xl[77];
+                const float hi1 = s1 + xs[76] * xl[77] - xs[77] * xl[76];
+                // lag 0: (p210, -, p100, -)   lag 1: (p110, p111, p000, p001)   lag 2: (p010, p011, -, -)
+                const int l1 = lane + 1 < 64 ? lane + 1 : 63, l2 = lane + 2 < 64 ? lane + 2 : 63;
+                const float p110 = __shfl(lo0, l1), p111 = __shfl(lo1, l1), p000 = __shfl(hi0, l1), p001 = __shfl(hi1, l1);
+                const float p010 = __shfl(lo0, l2), p011 = __shfl(lo1, l2);
+                if (active && lag == 0) {
+                    const float p210 = lo0, p100 = hi0;
+                    const float dk = p210 * p100 - (p110 * p110 + p111 * p111) / 1.000001f;
+                    float a1r, a1i, a0r, a0i;
+                    if (!dk) {
+                        a1r = 0; a1i = 0;
+                    } else {
+                        const float tr = p000 * p110 - p001 * p111 - p010 * p100;
+                        const float ti = p000 * p111 + p001 * p110 - p011 * p100;
+                        a1r = tr / dk;
+                        a1i = ti / dk;
+                    }
+                    if (!p100) {
+                        a0r = 0; a0i = 0;
+                    } else {
+                        const float tr = p000 + a1r * p110 + a1i * p111;
+                        const float ti = p001 + a1i * p110 - a1r * p111;
+                        a0r = -tr / p100;
+                        a0i = -ti / p100;
+                    }
+                    if (a1r * a1r + a1i * a1i >= 16.0f || a0r * a0r + a0i * a0i >= 16.0f) {
+                        a1r = 0; a1i = 0; a0r = 0; a0i = 0;
+                    }
+                    w.alpha0[band][0] = a0r; w.alpha0[band][1] = a0i;
+                    w.alpha1[band][0] = a1r; w.alpha1[band][1] = a1i;
+                }
             }
-            const float p210 = r0 + x[0] * x[0] + x[1] * x[1];
-            const float p100 = r0 + x[76] * x[76] + x[77] * x[77];
-            const float p110 = r1 + x[0] * x[2] + x[1] * x[3];
-            const float p111 = i1 + x[0] * x[3] - x[1] * x[2];
-            const float p000 = r1 + x[76] * x[78] + x[77] * x[79];
-            const float p001 = i1 + x[76] * x[79] - x[77] * x[78];
-            const float p010 = r2 + x[0] * x[4] + x[1] * x[5];
-            const float p011 = i2 + x[0] * x[5] - x[1] * x[4];
-
-            const float dk = p210 * p100 - (p110 * p110 + p111 * p111) / 1.000001f;
-            float a1r, a1i, a0r, a0i;
-            if (!dk) {
-                a1r = 0; a1i = 0;
-            } else {
-                const float tr = p000 * p110 - p001 * p111 - p010 * p100;
-                const float ti = p000 * p111 + p001 * p110 - p011 * p100;
-                a1r = tr / dk;
-                a1i = ti / dk;
-            }
-            if (!p100) {
-                a0r = 0; a0i = 0;
-            } else {
-                const float tr = p000 + a1r * p110 + a1i * p111;
-                const float ti = p001 + a1i * p110 - a1r * p111;
-                a0r = -tr / p100;
-                a0i = -ti / p100;
-            }
-            if (a1r * a1r + a1i * a1i >= 16.0f || a0r * a0r + a0i * a0i >= 16.0f) {
-                a1r = 0; a1i = 0; a0r = 0; a0i = 0;
-            }
-            w.alpha0[lane][0] = a0r; w.alpha0[lane][1] = a0i;
-            w.alpha1[lane][0] = a1r; w.alpha1[lane][1] = a1i;
         }
         HSTAMP(3);
         // ---- sbr_chirp (:1316-1334) ----
