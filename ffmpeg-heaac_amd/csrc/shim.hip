@@ -385,6 +385,10 @@ static int dec_init_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p)
         if (p->m4ac.object_type != HEAAC_AOT_AAC_LC && p->m4ac.object_type != HEAAC_AOT_AAC_MAIN) return -1;
         // one SCE or one CPE: the single-element path (with Parametric Stereo and coupling elements); else the layout path
         p->have_layout = p->m4ac.chan_config != 1 && p->m4ac.chan_config != 2;
+        // A program-config layout with explicitly signalled SBR leaves ps = -1 (no channel count to rule it out,
+        // mpeg4audio.c:137-139), which decode_audio_specific_config turns into ps = 1 (:476-477): the reference then gives
+        // every SCE of the layout a second, Parametric Stereo output channel (che_configure, :203-206).  Not decoded here.
+        if (p->have_layout && p->m4ac.sbr == 1 && p->m4ac.ps == -1) return -1;
         p->have_m4ac = 1;
     }
     const size_t words = HEAAC_STATE_WORDS_HEV2 > HEAAC_STATE_WORDS_HEV1 ? HEAAC_STATE_WORDS_HEV2 : HEAAC_STATE_WORDS_HEV1;

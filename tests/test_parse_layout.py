@@ -350,3 +350,24 @@ def test_audio_specific_config_with_and_without_a_program_config_element(pkg):
     bw = W.BitWriter()
     bw.put(2, 5); bw.put(3, 4); bw.put(6, 4); bw.put(1, 1); bw.put(0, 2)
     assert pkg.asc_layout(bw.bytes())[0] == -3
+
+
+def test_codec_refuses_the_layout_the_reference_would_decode_with_ps_channels(pkg):
+    """Explicit SBR with channel configuration 0 leaves ps = -1 in the configuration (mpeg4audio.c:137-139: no channel
+    count to rule it out), which the reference turns into ps = 1 (aacdec.c:476-477) and then gives every SCE of the
+    program-config layout a second output channel (:203-206).  The codec surface refuses such a stream at open, before it
+    touches a device."""
+    import ctypes as C
+    from test_shim_gpu import HeaacCodecContext
+    rng = np.random.default_rng(35)
+    bw = W.BitWriter()
+    bw.put(5, 5); bw.put(6, 4); bw.put(0, 4); bw.put(3, 4); bw.put(2, 5); bw.put(0, 3); bw.put(0, 4)
+    write_pce_body(bw, rng, [(0, 0), (1, 0)], [], [(1, 1)], [0])
+    asc = bw.bytes()
+    r, c, l = pkg.asc_layout(asc)
+    assert r == 0 and c.sbr == 1 and c.ps == -1 and int(l[0]["channels"]) == 6
+    lib = pkg.lib()
+    ctx = HeaacCodecContext(cfg=-1, extradata=asc, extradata_size=len(asc))
+    codec = C.c_void_p.in_dll(lib, "heaac_aac_decoder")
+    assert lib.heaac_codec_open(C.byref(ctx), C.c_void_p(C.addressof(codec))) == -1
+    assert not ctx.priv_data and not ctx.codec
