@@ -47,6 +47,22 @@ __device__ __forceinline__ void core2_lds_init(Core2Lds &L, const float *g_tab, 
     }
 }
 
+// The tables of the transform + windowing code as pointers: a kernel decides per table whether it reads its LDS copy or the
+// blob in global memory (k_core_ana keeps the 16 KB of long windows and N = 2048 rotation tables out of LDS for a
+// seventh wave per CU; every pointer that one expression selects between must be in ONE address space).
+struct CoreTabs {
+    const float *cos;                 // ff_cos_16 .. ff_cos_512 at their blob offsets
+    const float *rot2048, *rot256;    // tcos[n/4] then tsin[n/4]
+    const float *kbd_long, *sine_long, *kbd_short, *sine_short;
+    const float2 *rotA512, *rotA64;   // pre-rotation twiddles in layout-A order
+    const uint16_t *kA512, *kA64;     // the k behind every layout-A slot
+};
+__device__ __forceinline__ CoreTabs core2_tabs(const Core2Lds &L)
+{
+    return CoreTabs{ L.tab, L.tab + TB_ROT2048, L.tab + TB_ROT256, L.tab + TB_KBD_LONG, L.tab + TB_SINE_LONG,
+                     L.tab + TB_KBD_SHORT, L.tab + TB_SINE_SHORT, L.rotA512, L.rotA64, L.kA512, L.kA64 };
+}
+
 // bit c of the result: a block of size 1 << bits starts at offset c << bits
 constexpr unsigned sr_block_mask(const SrSchedule &s, int bits)
 {
@@ -87,7 +103,22 @@ __device__ __forceinline__ void sr_transform_sel(cpx &a0, cpx &a1, cpx &a2, cpx 
 //         buf[1024] (the reference's buf[], floats) in its first 4 KiB
 //   hl  : lane within the half-wave (0..31)
 // Both half-waves of a wave call this together (each with its own in / T / eight).
-__device__ __forceinline__ void imdct_half_regs(const Core2Lds &L, const float *in, cpx *T, bool eight, int hl)
+// Twiddles of the long transform that depend on the lane only -- the pre-rotation pairs of layout A and the post-rotation
+// pairs (tsin[e], tcos[e]), e = hl + 32 j: a kernel whose tables sit in global memory loads them once and keeps them in
+// registers across its units (LongTw, TW = true); TW = false reads the tables at every unit.
+struct LongTw { float2 pre[16], post[16]; };
+__device__ __forceinline__ void core2_load_long_twiddles(const CoreTabs &L, int hl, LongTw &t)
+{
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        t.pre[i] = L.rotA512[hl + 32 * i];
+        t.post[i] = make_float2(L.rot2048[512 + hl + 32 * i], L.rot2048[hl + 32 * i]);
+    }
+}
+
+template <bool TW>
+__device__ __forceinline__ void imdct_half_regs_tw(const CoreTabs &L, const float *in, cpx *T, bool eight, int hl,
+                                                   const LongTw &tw)
 {
     cpx z[16];
     const int c = hl >> 2, r = hl & 3;       // layout B: 64-chunk (= window when eight) and residue
@@ -101,14 +132,21 @@ __device__ __forceinline__ void imdct_half_regs(const Core2Lds &L, const float *
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const int k = kt[i * kstride];
-            const float2 w = rt[i * kstride];
+            float2 w;
+            if constexpr (TW) {
+                // (the short transform's pairs are read only by the half-waves that need them)
+                w = tw.pre[i];
+                if (eight) w = rt[i * kstride];
+            } else {
+                w = rt[i * kstride];
+            }
             cmul(z[i].re, z[i].im, x[last - 2 * k], x[2 * k], w.x, w.y);
         }
     }
     wave_sync();                              // all reads of `in` precede the writes of T below
     // ---- layout A: fft4 / fft8 leaves and pass16 ----
     {
-        const float *c16 = L.tab + TB_COS16;
+        const float *c16 = L.cos + TB_COS16;
         const float sqrthalf = c16[2];
         const bool is16 = ((eight ? kMask16_64 >> (hl & 3) : kMask16_512 >> hl) & 1) != 0;
         sr_fft4(z[0], z[1], z[2], z[3]);
@@ -133,7 +171,7 @@ __device__ __forceinline__ void imdct_half_regs(const Core2Lds &L, const float *
     wave_sync();
     // ---- layout B: pass32 on the first half, then pass64 or pass32 on the second half ----
     {
-        const float *c32 = L.tab + TB_COS32, *c64 = L.tab + TB_COS64;
+        const float *c32 = L.cos + TB_COS32, *c64 = L.cos + TB_COS64;
         const bool is64 = eight || ((kMask64_512 >> c) & 1) != 0;
         const float w32[2][2] = { { c32[r], c32[8 - r] }, { c32[r + 4], c32[4 - r] } };
 #pragma unroll
@@ -157,7 +195,7 @@ __device__ __forceinline__ void imdct_half_regs(const Core2Lds &L, const float *
     float *buf = reinterpret_cast<float *>(T);
     if (eight) {
         // ---- post-rotation of window c from layout B (mdct.c:145-158), N = 256 ----
-        const float *tcos = L.tab + TB_ROT256, *tsin = tcos + 64;
+        const float *tcos = L.rot256, *tsin = tcos + 64;
         cpx o[16];
 #pragma unroll
         for (int m = 0; m < 16; m++) {
@@ -180,7 +218,7 @@ __device__ __forceinline__ void imdct_half_regs(const Core2Lds &L, const float *
         for (int j = 0; j < 16; j++) z[j] = T[hl + 32 * j + 4 * (j >> 1)];
         wave_sync();
         // ---- layout C: pass128 at 0, 256, 384; pass256; pass512 ----
-        const float *c128 = L.tab + TB_COS128, *c256 = L.tab + TB_COS256, *c512 = L.tab + TB_COS512;
+        const float *c128 = L.cos + TB_COS128, *c256 = L.cos + TB_COS256, *c512 = L.cos + TB_COS512;
         {
             const float wre = c128[hl], wim = c128[32 - hl];
             sr_transform_sel(z[0], z[1], z[2], z[3], wre, wim, hl == 0);
@@ -198,12 +236,13 @@ __device__ __forceinline__ void imdct_half_regs(const Core2Lds &L, const float *
             sr_transform_sel(z[kap], z[kap + 4], z[kap + 8], z[kap + 12], c512[k], c512[128 - k], kap == 0 && hl == 0);
         }
         // ---- post-rotation (mdct.c:145-158): z[e] -> buf[2e] (re), buf[1023 - 2e] (im) ----
-        const float *tcos = L.tab + TB_ROT2048, *tsin = tcos + 512;
+        const float *tcos = L.rot2048, *tsin = tcos + 512;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const int e = hl + 32 * j;
             float re, im;
-            cmul(re, im, z[j].im, z[j].re, tsin[e], tcos[e]);
+            if constexpr (TW) cmul(re, im, z[j].im, z[j].re, tw.post[j].x, tw.post[j].y);
+            else              cmul(re, im, z[j].im, z[j].re, tsin[e], tcos[e]);
             buf[2 * e] = re;
             buf[1023 - 2 * e] = im;
         }
@@ -211,19 +250,25 @@ __device__ __forceinline__ void imdct_half_regs(const Core2Lds &L, const float *
     wave_sync();
 }
 
+__device__ __forceinline__ void imdct_half_regs(const CoreTabs &L, const float *in, cpx *T, bool eight, int hl)
+{
+    const LongTw none = {};
+    imdct_half_regs_tw<false>(L, in, T, eight, hl, none);
+}
+
 // Windowing, overlap-add and the new overlap (aacdec.c:1763-1805) for one channel, whole
 // wave.  buf: the channel's buf[1024] in LDS; saved in / out in HBM (may alias).
 // emit(q, v) receives out[q]; within one call every lane's q is distinct and a group of
 // 64 consecutive positions (ascending or descending with the lane).
 template <class Emit>
-__device__ __forceinline__ void core2_window(const Core2Lds &L, HeaacIcs ics, float bias, const float *buf,
+__device__ __forceinline__ void core2_window(const CoreTabs &L, HeaacIcs ics, float bias, const float *buf,
                                              const float *g_saved_in, float *g_saved_out, int lane, Emit emit)
 {
     const int ws0 = ics.window_sequence[0], ws1 = ics.window_sequence[1];
     const bool eight = ws0 == HEAAC_EIGHT_SHORT_SEQUENCE;
-    const float *swindow      = L.tab + (ics.use_kb_window[0] ? TB_KBD_SHORT : TB_SINE_SHORT);
-    const float *lwindow_prev = L.tab + (ics.use_kb_window[1] ? TB_KBD_LONG  : TB_SINE_LONG);
-    const float *swindow_prev = L.tab + (ics.use_kb_window[1] ? TB_KBD_SHORT : TB_SINE_SHORT);
+    const float *swindow      = ics.use_kb_window[0] ? L.kbd_short : L.sine_short;
+    const float *lwindow_prev = ics.use_kb_window[1] ? L.kbd_long  : L.sine_long;
+    const float *swindow_prev = ics.use_kb_window[1] ? L.kbd_short : L.sine_short;
     const bool long_long =
         (ws1 == HEAAC_ONLY_LONG_SEQUENCE || ws1 == HEAAC_LONG_STOP_SEQUENCE) &&
         (ws0 == HEAAC_ONLY_LONG_SEQUENCE || ws0 == HEAAC_LONG_START_SEQUENCE);

@@ -84,7 +84,7 @@ __device__ __forceinline__ void qmf_analysis_wave(const float *qmf_ds, const flo
 // two consecutive mono frames).  Core IMDCT in registers (k_core2.h), then the analysis
 // filterbank with one 128-point IMDCT per lane: 2 x 32 slots fill the wave.
 // ---------------------------------------------------------------------------
-#define CA_WAVES 6
+#define CA_WAVES 7               // (6 with all transform tables in LDS: profiles/r03_experiments.md E31)
 #define CA_U     2080             // fold rows u[32][65] of one channel
 
 struct CaWave {
@@ -103,19 +103,42 @@ void k_core_ana(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_
                 int ncore, int off_saved0, int off_sbr0,
                 float *__restrict__ g_W, float scale, unsigned long long n_units)
 {
-    __shared__ Core2Lds L;
+    // Tables: the small ones in LDS; the long windows (8 KB), the N = 2048 post-rotation table (4 KB) and the pre-rotation
+    // twiddles (4.5 KB) are read from the table blob in global memory (cache resident, coalesced, loaded well ahead of
+    // their use) -- the LDS they would take is what a seventh wave per CU needs.
+    __shared__ float s_cos[TB_ROT2048];          // ff_cos_16 .. ff_cos_512
+    __shared__ float s_rot256[128];
+    __shared__ float s_wshort[256];              // KBD then sine, 128 each
+    __shared__ uint16_t s_kA512[512], s_kA64[64];
     __shared__ float s_qmf_ds[320];
     __shared__ float s_rot[64];                  // SBR analysis MDCT: tcos[32], tsin[32]
     __shared__ CaWave S[CA_WAVES];
-    core2_lds_init(L, g_tab, g_rev);
+    static_assert(TB_SINE_SHORT == TB_KBD_SHORT + 128, "the two short windows are copied as one run");
+    for (int i = threadIdx.x; i < TB_ROT2048; i += blockDim.x) s_cos[i] = g_tab[i];
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) s_rot256[i] = g_tab[TB_ROT256 + i];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_wshort[i] = g_tab[TB_KBD_SHORT + i];
+    for (int k = threadIdx.x; k < 512; k += blockDim.x) {
+        const int e = g_rev[RV_512 + k];
+        s_kA512[(e & 15) * 32 + (e >> 4)] = (uint16_t)k;
+    }
+    for (int k = threadIdx.x; k < 64; k += blockDim.x) {
+        const int e = g_rev[RV_64 + k];
+        s_kA64[(e & 15) * 4 + (e >> 4)] = (uint16_t)k;
+    }
     for (int i = threadIdx.x; i < 320; i += blockDim.x) s_qmf_ds[i] = g_tab[TB_QMF_DS + i];
     for (int i = threadIdx.x; i < 64; i += blockDim.x)  s_rot[i] = g_tab[TB_ROT128A + i];
     __syncthreads();
+    const CoreTabs L = { s_cos, g_tab + TB_ROT2048, s_rot256, g_tab + TB_KBD_LONG, g_tab + TB_SINE_LONG,
+                         s_wshort, s_wshort + 128,
+                         reinterpret_cast<const float2 *>(g_tab + TB_ROTA512), reinterpret_cast<const float2 *>(g_tab + TB_ROTA64),
+                         s_kA512, s_kA64 };
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane0 = threadIdx.x % WAVE;
     CaWave &w = S[wave];
     cpx *T0 = reinterpret_cast<cpx *>(w.tu), *T1 = T0 + C2_TSTRIDE;
-    const float *c16 = L.tab + TB_COS16, *c32 = L.tab + TB_COS32;
+    const float *c16 = s_cos + TB_COS16, *c32 = s_cos + TB_COS32;
     const unsigned long long pairs = (n_units + 1) / 2;
+    LongTw tw;
+    core2_load_long_twiddles(L, lane0 & 31, tw);
     for (unsigned long long pr = (unsigned long long)blockIdx.x * CA_WAVES + wave; pr < pairs;
          pr += (unsigned long long)gridDim.x * CA_WAVES) {
         const unsigned long long u0 = 2 * pr;
@@ -130,7 +153,7 @@ void k_core_ana(const float *__restrict__ g_tab, const uint16_t *__restrict__ g_
             const int half = lane >> 5, hl = lane & 31;
             const bool eight = (half ? ics1.window_sequence[0] : ics0.window_sequence[0]) == HEAAC_EIGHT_SHORT_SEQUENCE;
             cpx *T = half ? T1 : T0;
-            imdct_half_regs(L, reinterpret_cast<const float *>(T), T, eight, hl);
+            imdct_half_regs_tw<true>(L, reinterpret_cast<const float *>(T), T, eight, hl, tw);
         }
         // windowing (bias 0) -> x = [history 288 | out * scale] per channel (vector_fmul_scalar,
         // aacsbr.c:1142), x history in / out

@@ -46,6 +46,7 @@ void k_lc_decode(const float *__restrict__ g_tab, const uint16_t *__restrict__ g
     __shared__ Core2Lds L;
     __shared__ Lc2Wave W[LC2_WAVES];
     core2_lds_init(L, g_tab, g_rev);
+    const CoreTabs LT = core2_tabs(L);
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
@@ -65,7 +66,7 @@ void k_lc_decode(const float *__restrict__ g_tab, const uint16_t *__restrict__ g
         {
             const int half = lane >> 5, hl = lane & 31;
             const bool eight = (half ? ics1.window_sequence[0] : ics0.window_sequence[0]) == HEAAC_EIGHT_SHORT_SEQUENCE;
-            imdct_half_regs(L, reinterpret_cast<const float *>(w.T[half]), w.T[half], eight, hl);
+            imdct_half_regs(LT, reinterpret_cast<const float *>(w.T[half]), w.T[half], eight, hl);
         }
         // add_bias: 385 for the C conversion, 0 for the SIMD configuration (aacdec.c:573-581)
         constexpr float LC_BIAS = FMT == HEAAC_PCM_S16_INTERLEAVED_SSE2 ? 0.0f : HEAAC_ADD_BIAS;
@@ -79,19 +80,19 @@ void k_lc_decode(const float *__restrict__ g_tab, const uint16_t *__restrict__ g
             float *sout = g_state_out + u * 512;
             if (FMT == HEAAC_PCM_F32_PLANAR) {
                 float *o = reinterpret_cast<float *>(g_pcm) + u * 1024;
-                core2_window(L, ics, LC_BIAS, buf, sin_, sout, lane, [&](int q, float v) { LC_ST(o + q, v); });
+                core2_window(LT, ics, LC_BIAS, buf, sin_, sout, lane, [&](int q, float v) { LC_ST(o + q, v); });
             } else if (CH == 1) {
                 int16_t *o = reinterpret_cast<int16_t *>(g_pcm) + u * 1024;
-                core2_window(L, ics, LC_BIAS, buf, sin_, sout, lane,
+                core2_window(LT, ics, LC_BIAS, buf, sin_, sout, lane,
                              [&](int q, float v) { LC_ST(o + q, (int16_t)pcm_int16<FMT>(v)); });
             } else if (c == 0) {
-                core2_window(L, ics, LC_BIAS, buf, sin_, sout, lane,
+                core2_window(LT, ics, LC_BIAS, buf, sin_, sout, lane,
                              [&](int q, float v) { w.pcm0[q] = (uint16_t)pcm_int16<FMT>(v); });
                 wave_sync();
             } else {
                 // float_to_int16_interleave (dsputil.c:3989-4001): L from LDS, R fresh
                 uint32_t *o = reinterpret_cast<uint32_t *>(g_pcm) + (u0 / 2) * 1024;
-                core2_window(L, ics, LC_BIAS, buf, sin_, sout, lane, [&](int q, float v) {
+                core2_window(LT, ics, LC_BIAS, buf, sin_, sout, lane, [&](int q, float v) {
                     LC_ST(o + q, (uint32_t)w.pcm0[q] | ((uint32_t)(pcm_int16<FMT>(v) & 0xffff) << 16));
                 });
             }

@@ -258,6 +258,16 @@ void heaac_build_tables(HeaacHostTables *t)
     fill_hybrid(f + TB_F34_2_4,  g2_Q4,   4);
     fill_allpass(f + TB_QFRACT, f + TB_PHIFRACT);
     memcpy(f + TB_G1_Q2, g1_Q2, sizeof(g1_Q2));
+    for (int k = 0; k < 512; k++) {
+        const int e = t->rev[RV_512 + k], slot = (e & 15) * 32 + (e >> 4);
+        f[TB_ROTA512 + 2 * slot]     = f[TB_ROT2048 + k];
+        f[TB_ROTA512 + 2 * slot + 1] = f[TB_ROT2048 + 512 + k];
+    }
+    for (int k = 0; k < 64; k++) {
+        const int e = t->rev[RV_64 + k], slot = (e & 15) * 4 + (e >> 4);
+        f[TB_ROTA64 + 2 * slot]     = f[TB_ROT256 + k];
+        f[TB_ROTA64 + 2 * slot + 1] = f[TB_ROT256 + 64 + k];
+    }
 }
 
 int heaac_get_table(const char *name, float *dst, int max)

@@ -47,7 +47,11 @@ extern "C" {
 #define TB_QFRACT     10260    /* 2*50*3*2 = 600 */
 #define TB_PHIFRACT   10860    /* 2*50*2 = 200 */
 #define TB_G1_Q2      11060    /* 7 -> 8 */
-#define TB_TOTAL      11068
+/* The MDCT pre-rotation twiddles in the order the register FFT's first layout takes them (k_core2.h, layout A):
+ * entry (revtab[k] & 15) * S + (revtab[k] >> 4) = (tcos[k], tsin[k]), S = 32 for N = 2048, 4 for N = 256. */
+#define TB_ROTA512    11068    /* 512 (re,im) pairs */
+#define TB_ROTA64     12092    /*  64 pairs */
+#define TB_TOTAL      12220
 
 /* Split-radix input permutations revtab (fft.c:121-122), as uint16. */
 #define RV_512        0
