@@ -50,7 +50,7 @@ __device__ __forceinline__ float exp2_half(int twice)
 // and per envelope (mapped scalefactors, estimated envelope, gains) lives in that
 // lane's registers; the only cross-lane steps are the limiter-band sums of
 // sbr_gain_calc, which go through small LDS arrays in the reference's order.
-#define HF_WAVES 10
+#define HF_WAVES 11               // (10 before alpha0 / alpha1 were laid over the second limiter-sum array)
 #define XL_STRIDE 81              // X_low row: 40 slots * (re,im) + 1 pad (bank spread)
 #define MAXM 48                   // e_origmapped[7][48] etc. in the reference (sbr.h:165-177)
 #define MAXE 5
@@ -58,7 +58,7 @@ __device__ __forceinline__ float exp2_half(int twice)
 // Per-wave LDS of the HF stage, as three blocks so that a fused kernel can lay them over
 // arrays of a later stage; HfWave is the view hf_channel works through.
 #define HF_XLOW_WORDS (32 * XL_STRIDE)                                   // X_low[k][i][re,im]
-#define HF_AUX_WORDS  (2 * 64 + 8 + 2 * MAXE * MAXM + MAXE * 32)         // alpha0/1, bw, sumA/B, bandv
+#define HF_AUX_WORDS  (8 + 2 * MAXE * MAXM + MAXE * 32)                  // bw, sumA, sumB (under it: alpha0/1), bandv
 #define HF_REC_WORDS  ((int)((sizeof(HeaacSbrHeader) + 2 * sizeof(HeaacSbrChannel)) / 4))
 struct HfWave {
     float *xlow;
@@ -71,11 +71,15 @@ struct HfWave {
 };
 __device__ __forceinline__ HfWave hf_wave_view(float *xlow, float *aux, float *rec)
 {
+    // alpha0 / alpha1 (inverse filter -> the per-band constants of hf_gen, and the non-interpolating envelope estimate,
+    // which broadcasts through sumA) are dead before sbr_gain_calc writes sumB: they share its first 128 words
+    static_assert(MAXE * MAXM >= 128, "alpha0 / alpha1 fit under sumB");
     return HfWave{ xlow,
-                   reinterpret_cast<float (*)[2]>(aux), reinterpret_cast<float (*)[2]>(aux + 64), aux + 128,
-                   reinterpret_cast<float (*)[MAXM]>(aux + 136),
-                   reinterpret_cast<float (*)[MAXM]>(aux + 136 + MAXE * MAXM),
-                   reinterpret_cast<float (*)[32]>(aux + 136 + 2 * MAXE * MAXM),
+                   reinterpret_cast<float (*)[2]>(aux + 8 + MAXE * MAXM), reinterpret_cast<float (*)[2]>(aux + 8 + MAXE * MAXM + 64),
+                   aux,
+                   reinterpret_cast<float (*)[MAXM]>(aux + 8),
+                   reinterpret_cast<float (*)[MAXM]>(aux + 8 + MAXE * MAXM),
+                   reinterpret_cast<float (*)[32]>(aux + 8 + 2 * MAXE * MAXM),
                    *reinterpret_cast<HeaacSbrHeader *>(rec),
                    reinterpret_cast<HeaacSbrChannel *>(rec + sizeof(HeaacSbrHeader) / 4) };
 }

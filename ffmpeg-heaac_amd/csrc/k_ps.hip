@@ -85,9 +85,9 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
 {
     using WT = PsWaveT<false>;
     static_assert(WT::SCR <= HF_XLOW_WORDS, "|s|^2 / subL / subR lie over X_low");
-    static_assert(WT::NSUB * SUB_STRIDE <= HF_AUX_WORDS, "sub-subband rows lie over the limiter sums");
+    constexpr int B_WORDS = WT::NSUB * SUB_STRIDE > HF_AUX_WORDS ? WT::NSUB * SUB_STRIDE : HF_AUX_WORDS;
     __shared__ float s_a[HFPS_WAVES][HF_XLOW_WORDS];      // HF: X_low           | PS: |s|^2, subL / subR
-    __shared__ float s_b[HFPS_WAVES][HF_AUX_WORDS];       // HF: alpha, sums     | PS: sub-subband rows
+    __shared__ float s_b[HFPS_WAVES][B_WORDS];            // HF: sums (alpha)    | PS: sub-subband rows
     __shared__ float s_c[HFPS_WAVES][HFPS_C_WORDS];       // HF: header, channel | PS: band power / transient gain
     __shared__ HeaacPsFrame s_p[HFPS_WAVES];
     __shared__ float s_inb[HFPS_WAVES][WT::NLOW][44][2];
