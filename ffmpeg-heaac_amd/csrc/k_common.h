@@ -35,6 +35,11 @@ __device__ __forceinline__ void wave_sync()
 // ---------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// One channel of the X hand-over workspace between the HF / PS kernels and the synthesis kernels: [38 slots][64 bands]
+// [re, im] floats (slots 32..37: the hybrid filters' look-ahead).  A frame's record is two of them (left / mono, right).
+// (Re and im side by side: a lane's value leaves as ONE 8-byte store, a row of 48 bands is exactly three 128-byte lines.)
+#define HE_X_CHANNEL (38 * 64 * 2)
+
 template <int ST_AUX>
 struct GBufT {
     __amdgpu_buffer_rsrc_t r;

@@ -282,13 +282,12 @@ void k_hfadj(const float *__restrict__ g_tab,
         const unsigned long long f = u / ncore;
         const int ch = (int)(u - f * ncore);
         const int off = off_sbr0 + ch * HEAAC_ST_SBR;
-        float *X0 = g_X + (f * 2 + ch) * (2 * 38 * 64), *X1 = X0 + 38 * 64;
+        v2f *Xc = reinterpret_cast<v2f *>(g_X + (f * 2 + ch) * HE_X_CHANNEL);
         hf_channel(S, s_noise, &g_sbr[f], g_hdr, n_hdr, ch, g_W + u * 2048,
                    g_state_in + f * state_words + off, g_state_out + f * state_words + off, lane,
                    [&](int i, float re, float im) {
                        // written once, read by k_synth a whole batch later: non-temporal (-7 % kernel time)
-                       __builtin_nontemporal_store(re, X0 + i * 64 + lane);
-                       __builtin_nontemporal_store(im, X1 + i * 64 + lane);
+                       __builtin_nontemporal_store(v2f{re, im}, Xc + i * 64 + lane);
                    });
       }
         feed.advance();
@@ -351,30 +350,46 @@ __device__ __forceinline__ f32x4 syn_ld4(const f32x4 *p) { return *p; }
 __device__ __forceinline__ float syn_ld1(const float *p) { return *p; }
 template <class T>
 __device__ __forceinline__ void syn_st(T *p, T v) { __builtin_nontemporal_store(v, p); }
+// PLANES = true: X0 / X1 are the re / im planes [32][64] of the stage-level entry point (heaac_qmf_synthesis_batch).
+// PLANES = false: X0 is a channel of the decoders' hand-over workspace, [slot][band][re, im] (X1 unused): load q holds
+// the bands 2 (lane & 31), + 1 of slot 2 q + (lane >> 5) as (re, im, re, im).
+template <bool PLANES>
 __device__ __forceinline__ void syn_load(const float *X0, const float *X1, const float *v_in, int lane, SynIn &d)
 {
     const f32x4 *p0 = reinterpret_cast<const f32x4 *>(X0), *p1 = reinterpret_cast<const f32x4 *>(X1);
 #pragma unroll
     for (int q = 0; q < 16; q++) {
-        const f32x4 t = syn_ld4(q < 8 ? p0 + q * 64 + lane : p1 + (q - 8) * 64 + lane);
+        const f32x4 t = PLANES ? syn_ld4(q < 8 ? p0 + q * 64 + lane : p1 + (q - 8) * 64 + lane)
+                               : syn_ld4(p0 + q * 64 + lane);
         d.x[4 * q] = t.x; d.x[4 * q + 1] = t.y; d.x[4 * q + 2] = t.z; d.x[4 * q + 3] = t.w;
     }
 #pragma unroll
     for (int r = 0; r < 18; r++) d.h[r] = syn_ld1(v_in + lane + 64 * r);
 }
 
-template <class SL>
+template <bool PLANES, class SL>
 __device__ __forceinline__ void syn_rows(const SL &S, SynWave &w, const SynIn &d, int lane)
 {
-    // staged image: row (plane, slot) at (plane * 32 + slot) * SYN_STAGE_STRIDE; piece q of the loads holds
-    // floats 4 (lane & 15) .. of row 4 (q & 7) + (lane >> 4) of plane q >> 3
+    // staged image: row (plane, slot) at (plane * 32 + slot) * SYN_STAGE_STRIDE.  PLANES: piece q of the loads holds
+    // floats 4 (lane & 15) .. of row 4 (q & 7) + (lane >> 4) of plane q >> 3; else (re, im) of two bands of one slot: the
+    // two re go to the slot's plane-0 row, the two im to its plane-1 row
     float x[64];
     {
         float4 *st = reinterpret_cast<float4 *>(w.vb);
+        if constexpr (PLANES) {
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int row = (q >> 3) * 32 + 4 * (q & 7) + (lane >> 4);
-            st[(row * SYN_STAGE_STRIDE >> 2) + (lane & 15)] = make_float4(d.x[4 * q], d.x[4 * q + 1], d.x[4 * q + 2], d.x[4 * q + 3]);
+            for (int q = 0; q < 16; q++) {
+                const int row = (q >> 3) * 32 + 4 * (q & 7) + (lane >> 4);
+                st[(row * SYN_STAGE_STRIDE >> 2) + (lane & 15)] = make_float4(d.x[4 * q], d.x[4 * q + 1], d.x[4 * q + 2], d.x[4 * q + 3]);
+            }
+        } else {
+            float2 *st2 = reinterpret_cast<float2 *>(w.vb);
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int slot = 2 * q + (lane >> 5), pi = lane & 31;
+                st2[(slot * SYN_STAGE_STRIDE >> 1) + pi] = make_float2(d.x[4 * q], d.x[4 * q + 2]);
+                st2[((32 + slot) * SYN_STAGE_STRIDE >> 1) + pi] = make_float2(d.x[4 * q + 1], d.x[4 * q + 3]);
+            }
         }
         wave_sync();
         const int mine = (lane & 1) * 32 + (lane >> 1);
@@ -459,8 +474,8 @@ __device__ __forceinline__ void synth_channel(const SL &S, SynWave &w, const flo
 {
     SSTAMP(0);
     SynIn d;
-    syn_load(X0, X1, v_in, lane, d);
-    syn_rows(S, w, d, lane);
+    syn_load<true>(X0, X1, v_in, lane, d);
+    syn_rows<true>(S, w, d, lane);
     wave_sync();
     syn_poly<UNROLL>(S, w, scale, bias, lane, emit);
     syn_hist_out(w, v_out, lane);
@@ -492,8 +507,8 @@ void k_synth(const float *__restrict__ g_tab, const float *g_X,
     // lanes that would load them aim at that page instead (an address select, no branch around the loads).
     auto load_unit = [&](unsigned long long f, int ch, SynIn &d) {
         const int xt = __builtin_amdgcn_readfirstlane((int)g_xtop[f]);
-        const float *X0 = (lane & 15) * 4 < xt ? g_X + (f * 2 + ch) * (2 * 38 * 64) : g_zero;
-        syn_load(X0, X0 + 38 * 64, g_state_in + f * state_words + off_syn0 + ch * HEAAC_ST_SYNTH, lane, d);
+        const float *X0 = (lane & 31) * 2 < xt ? g_X + (f * 2 + ch) * HE_X_CHANNEL : g_zero;
+        syn_load<false>(X0, nullptr, g_state_in + f * state_words + off_syn0 + ch * HEAAC_ST_SYNTH, lane, d);
     };
     // the frame in work and the next one are known (FrameFeed, k_common.h: two frames per ticket)
     FrameFeed<2> feed;
@@ -507,7 +522,7 @@ void k_synth(const float *__restrict__ g_tab, const float *g_X,
         // one channel: rows from `cur`, then the next unit's loads, then the polyphase sum
         auto channel = [&](int ch, auto emit) {
             SSTAMP(0);
-            syn_rows(S, w, cur, lane);
+            syn_rows<false>(S, w, cur, lane);
             wave_sync();
             if (ch + 1 < nout) load_unit(f, ch + 1, cur);
             else if (f1 < n_frames) load_unit(f1, 0, cur);
@@ -610,7 +625,8 @@ __device__ __forceinline__ void syn_ds_lds_init(SynDsLds &S, const float *g_tab)
 
 // One channel of the downsampled bank.  X0 / X1: re / im planes, row stride 64 (bands 0..31 used);
 // v_in / v_out: 576 floats; emit(i, n, value) receives out[32 i + n].
-template <class Emit>
+// PLANES = false: X0 is a channel of the hand-over workspace, [slot][band][re, im] (X1 unused).
+template <bool PLANES, class Emit>
 __device__ __forceinline__ void synth_ds_channel(const SynDsLds &S, float *vb, const float *X0, const float *X1,
                                                  const float *v_in, float *v_out, float scale, float bias,
                                                  int lane, Emit emit)
@@ -619,10 +635,11 @@ __device__ __forceinline__ void synth_ds_channel(const SynDsLds &S, float *vb, c
     for (int t = lane; t < 576; t += WAVE) vb[(32 + (t >> 6)) * DS_STRIDE + (t & 63)] = v_in[t];
     if (lane < 32) {
         const int i = lane;
-        const float *r0 = X0 + i * 64, *r1 = X1 + i * 64;
+        const float *r0 = PLANES ? X0 + i * 64 : X0 + i * 128, *r1 = PLANES ? X1 + i * 64 : X0 + i * 128 + 1;
+        constexpr int step = PLANES ? 1 : 2;
         float o[64];
         // X[0][i][n] = -X[0][i][n]; X[0][i][32+n] = X[1][i][31-n]
-        imdct128_reg([&](int j) -> float { return j < 32 ? -r0[j] : r1[63 - j]; }, o, S.rot, S.c16, S.c32);
+        imdct128_reg([&](int j) -> float { return j < 32 ? -r0[step * j] : r1[step * (63 - j)]; }, o, S.rot, S.c16, S.c32);
         float *v = vb + (31 - i) * DS_STRIDE;
 #pragma unroll
         for (int k = 0; k < 32; k++) {
@@ -661,7 +678,7 @@ void k_qmf_synthesis_ds(const float *__restrict__ g_tab, const float *__restrict
     for (unsigned long long u = (unsigned long long)blockIdx.x * SYN_WAVES + wave; u < n;
          u += (unsigned long long)gridDim.x * SYN_WAVES) {
         float *o = g_out + u * 1024;
-        synth_ds_channel(S, S.vb[wave], g_X + u * 4096, g_X + u * 4096 + 2048, g_v_in + u * 576, g_v_out + u * 576,
+        synth_ds_channel<true>(S, S.vb[wave], g_X + u * 4096, g_X + u * 4096 + 2048, g_v_in + u * 576, g_v_out + u * 576,
                          scale, bias, lane, [&](int i, int nn, float v) { o[32 * i + nn] = v; });
     }
 }
@@ -681,18 +698,18 @@ void k_synth_ds(const float *__restrict__ g_tab, const float *g_X,
     for (unsigned long long f = (unsigned long long)blockIdx.x * SYN_WAVES + wave; f < n_frames;
          f += (unsigned long long)gridDim.x * SYN_WAVES) {
         for (int ch = 0; ch < nout; ch++) {
-            const float *X0 = g_X + (f * 2 + ch) * (2 * 38 * 64), *X1 = X0 + 38 * 64;
+            const float *X0 = g_X + (f * 2 + ch) * HE_X_CHANNEL, *X1 = nullptr;
             const float *v_in = g_state_in + f * state_words + off_syn0 + ch * HEAAC_ST_SYNTH;
             float *v_out = g_state_out + f * state_words + off_syn0 + ch * HEAAC_ST_SYNTH;
             if (v_out != v_in)
                 for (int t = 576 + lane; t < HEAAC_ST_SYNTH; t += WAVE) v_out[t] = v_in[t];
             if (FMT == HEAAC_PCM_F32_PLANAR) {
                 float *o = reinterpret_cast<float *>(g_pcm) + (f * nout + ch) * 1024;
-                synth_ds_channel(S, S.vb[wave], X0, X1, v_in, v_out, scale, bias, lane,
+                synth_ds_channel<false>(S, S.vb[wave], X0, X1, v_in, v_out, scale, bias, lane,
                                  [&](int i, int nn, float v) { o[32 * i + nn] = v; });
             } else {
                 int16_t *o = reinterpret_cast<int16_t *>(g_pcm) + f * 1024 * nout + ch;
-                synth_ds_channel(S, S.vb[wave], X0, X1, v_in, v_out, scale, bias, lane,
+                synth_ds_channel<false>(S, S.vb[wave], X0, X1, v_in, v_out, scale, bias, lane,
                                  [&](int i, int nn, float v) { o[(32 * i + nn) * nout] = (int16_t)pcm_int16<FMT>(v); });
             }
         }

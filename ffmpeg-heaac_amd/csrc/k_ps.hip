@@ -57,7 +57,7 @@ void k_ps(const float *__restrict__ g_tab, const HeaacPsFrame *__restrict__ g_ps
             const unsigned hi = g_sbr[f].hdr;
             const HeaacSbrHeader &h = g_hdr[hi < n_hdr ? hi : n_hdr - 1];
             const int top = h.kx + h.m;             // ff_ps_apply(..., sbr->kx[1] + sbr->m[1])
-            float *XL = g_X + (f * 2) * (2 * 38 * 64);
+            float *XL = g_X + (f * 2) * HE_X_CHANNEL;
             ps_frame<GENERAL>(W, g_tab, &g_ps[f], top, g_state_in + f * state_words + off_ps,
                               g_state_out + f * state_words + off_ps, XL, lane, wave, no_cols);
         }
@@ -128,7 +128,8 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
             }
         };
         const bool base = __builtin_amdgcn_readfirstlane(!ps_frame_is_general(&g_ps[f]));
-        float *Xf = g_X + (f * 2) * (2 * 38 * 64);
+        float *Xf = g_X + (f * 2) * HE_X_CHANNEL;
+        v2f *Xf2 = reinterpret_cast<v2f *>(Xf);
         const float *st_in = g_state_in + f * state_words;
         float *st_out = g_state_out + f * state_words;
         v2f col[32];
@@ -154,8 +155,7 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
                            // look-ahead slots of the hybrid analysis (aacps.c:362-367)
                            if (lane < WT::NLOW) { inb[lane][6 + i][0] = re; inb[lane][6 + i][1] = im; }
                        } else {
-                           Xf[i * 64 + lane] = re;
-                           Xf[38 * 64 + i * 64 + lane] = im;
+                           Xf2[i * 64 + lane] = v2f{re, im};
                        }
                    },
                    [&]() {
@@ -167,7 +167,7 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
                    });
         if (!base) {
 #pragma unroll
-            for (int i = 0; i < 32; i++) { Xf[i * 64 + lane] = col[i].x; Xf[38 * 64 + i * 64 + lane] = col[i].y; }
+            for (int i = 0; i < 32; i++) Xf2[i * 64 + lane] = col[i];
         } else {
             // ff_ps_apply(..., sbr->kx[1] + sbr->m[1]): the header is still in the HF stage's LDS
             const int top = __builtin_amdgcn_readfirstlane(H.h.kx + H.h.m);

@@ -235,7 +235,7 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
 {
     static_assert(!DUAL || HEAVY, "the second role rides on the heavy pass");
     constexpr int dl_stride = 91 * 2, ap_stride = 50 * 2;
-    constexpr int XP = 38 * 64;                       // X record: [L, R][re, im][38][64]
+    constexpr int XC = HE_X_CHANNEL;                  // X record: [L, R][38][64][re, im]
     const int nr_allpass = is34 ? 50 : 30, short_delay = is34 ? 62 : 42;
     const int b = kti[kh];
     const int enable_ipdopd = W::IS_GENERAL ? w.p.enable_ipdopd : 0;
@@ -304,7 +304,7 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
     const v2f *srow = reinterpret_cast<const v2f *>(w.sub[is_sub ? kh : 0]);
     float *lrow = w.subL[is_sub ? kh : W::NSUB], *rrow = w.subR[is_sub ? kh : W::NSUB];   // row NSUB = scratch
     // column 0 of every row is rewritten by the hybrid synthesis at the end of the frame
-    const int qs4 = q * 4;
+    const int qs8 = q * 8;
 
     // H11/H12 and H21/H22 share a pair each, so one packed add steps two of them
     v2f hA = zero, hB = zero, hA_step = zero, hB_step = zero;        // (h11r, h12r), (h21r, h22r)
@@ -426,9 +426,9 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
         // restored around every slot (+4 % kernel time); aiming the lanes past the buffer's range instead (the bounds
         // check drops the store) saves a quarter of what masking them saves.
         if (X_BANDS == 64 || q < X_BANDS) {
-            const int qb = opaque(qs4);
-            X.stb(lv.x, qb, n * 64);          X.stb(lv.y, qb, XP + n * 64);
-            X.stb(rr.x, qb, 2 * XP + n * 64); X.stb(rr.y, qb, 3 * XP + n * 64);
+            const int qb = opaque(qs8);
+            X.stb2(lv, qb, n * 128);
+            X.stb2(rr, qb, XC + n * 128);
         }
         // bound the scheduler's look-ahead: without it the 32 unrolled slots are
         // interleaved until the register file overflows
@@ -520,7 +520,7 @@ template <bool GENERAL, bool FUSED = false, class Hook = NoHook>
 __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__restrict__ g_tab,
                                          const HeaacPsFrame *g_p, int top_qmf,
                                          const float *st_in, float *st_out,
-                                         float *Xrec /* [2][2][38][64]: in: mono in [0], out: left, right */,
+                                         float *Xrec /* [2][38][64][re, im]: in: mono in [0], out: left, right */,
                                          int lane_in, int wave, const v2f (&hfcol)[32], Hook hook = Hook(),
                                          unsigned char *x_bands_out = nullptr, bool x_zero_above_top = false)
 {
@@ -530,7 +530,7 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     // into registers that end up spilled.
     int lane = opaque(lane_in);
     using WT = PsWaveT<GENERAL>;
-    constexpr int XP = 38 * 64;
+    constexpr int XC = HE_X_CHANNEL;
     const GBuf SI(st_in), X(Xrec);
     const GBufXR XR(Xrec);
     const GBufSO SO(st_out);
@@ -545,7 +545,7 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
 
     if (!p.start) {
         // memcpy(sbr->X[1], sbr->X[0]) (aacsbr.c:1755); PS state untouched
-        for (int t = lane; t < 2 * XP; t += WAVE) X.st(X.ld(t), t, 2 * XP);
+        for (int t = lane; t < XC; t += WAVE) X.st(X.ld(t), t, XC);
         if (st_out != st_in)
             for (int t = lane; t < HEAAC_ST_PS; t += WAVE) SO.st(SI.ld(t), t);
         wave_sync();
@@ -577,8 +577,8 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     } else {
 #pragma unroll
         for (int n = 0; n < 32; n++) {
-            const int qb = opaque(q_own * 4);
-            col[n] = v2f{X.ldb(qb, n * 64), X.ldb(qb, XP + n * 64)};
+            const int qb = opaque(q_own * 8);
+            col[n] = X.ldb2(qb, n * 128);
         }
     }
     {
@@ -601,8 +601,8 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
         w.inb[i][j][0] = SI.ld(t * 2, HEAAC_PS_INBUF);
         w.inb[i][j][1] = SI.ld(t * 2, HEAAC_PS_INBUF + 1);
         // lookahead slots 32..37
-        w.inb[i][38 + j][0] = X.ld((32 + j) * 64 + i);
-        w.inb[i][38 + j][1] = X.ld((32 + j) * 64 + i, XP);
+        w.inb[i][38 + j][0] = X.ld(((32 + j) * 64 + i) * 2);
+        w.inb[i][38 + j][1] = X.ld(((32 + j) * 64 + i) * 2 + 1);
     }
     wave_sync();
     STAMP(1);
@@ -612,7 +612,7 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
         const int i = t / 6, j = t % 6;
         float re = 0.0f, im = 0.0f;
         if (i < nlow) { re = w.inb[i][32 + j][0]; im = w.inb[i][32 + j][1]; }
-        else if (!FUSED) { re = X.ld((26 + j) * 64 + i); im = X.ld((26 + j) * 64 + i, XP); }
+        else if (!FUSED) { re = X.ld(((26 + j) * 64 + i) * 2); im = X.ld(((26 + j) * 64 + i) * 2 + 1); }
         if (i < nlow || !FUSED) {
             SO.st(re, t * 2, HEAAC_PS_INBUF);
             SO.st(im, t * 2, HEAAC_PS_INBUF + 1);
@@ -1009,7 +1009,7 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     {
         const int n = lane & 31, side = lane >> 5;
         const float *rows = side ? &w.subR[0][0] : &w.subL[0][0];
-        const int o0 = side * 2 * XP + n * 64, o1 = o0 + XP;
+        const int o0 = side * XC + n * 128, o1 = o0 + 1;       // (re, im) of band qq at o0 + 2 qq, o1 + 2 qq
 #define SUBV(i, c) rows[(i) * SUB_STRIDE + 2 * n + (c)]
         if (is34) {
             const int first[5] = { 0, 12, 20, 24, 28 }, cnt[5] = { 12, 8, 4, 4, 4 };
@@ -1017,16 +1017,16 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
             for (int qq = 0; qq < 5; qq++) {
                 float re = 0.0f, im = 0.0f;
                 for (int i = 0; i < cnt[qq]; i++) { re += SUBV(first[qq] + i, 0); im += SUBV(first[qq] + i, 1); }
-                X.st(re, o0, qq);
-                X.st(im, o1, qq);
+                X.st(re, o0, 2 * qq);
+                X.st(im, o1, 2 * qq);
             }
         } else {
             X.st(SUBV(0, 0) + SUBV(1, 0) + SUBV(2, 0) + SUBV(3, 0) + SUBV(4, 0) + SUBV(5, 0), o0, 0);
             X.st(SUBV(0, 1) + SUBV(1, 1) + SUBV(2, 1) + SUBV(3, 1) + SUBV(4, 1) + SUBV(5, 1), o1, 0);
-            X.st(SUBV(6, 0) + SUBV(7, 0), o0, 1);
-            X.st(SUBV(6, 1) + SUBV(7, 1), o1, 1);
-            X.st(SUBV(8, 0) + SUBV(9, 0), o0, 2);
-            X.st(SUBV(8, 1) + SUBV(9, 1), o1, 2);
+            X.st(SUBV(6, 0) + SUBV(7, 0), o0, 2);
+            X.st(SUBV(6, 1) + SUBV(7, 1), o1, 2);
+            X.st(SUBV(8, 0) + SUBV(9, 0), o0, 4);
+            X.st(SUBV(8, 1) + SUBV(9, 1), o1, 4);
         }
 #undef SUBV
     }

@@ -529,12 +529,12 @@ def test_unstored_x_bands_are_never_read(pkg, oracle, dev):
             assert np.array_equal(d_state.cpu().numpy().view(np.uint32), state.view(np.uint32))
             back = torch.empty(n * xrec, dtype=torch.float32, device="cuda")
             assert hip.hipMemcpy(C.c_void_p(back.data_ptr()), C.c_void_p(pX.value), C.c_size_t(n * xrec * 4), 3) == 0
-            x = back.cpu().numpy().reshape(n, 2, 2, 38, 64)[:, :, :, :32]
+            x = back.cpu().numpy().reshape(n, 2, 38, 64, 2)[:, :, :32]       # [frame][channel][slot][band][re, im]
             for f in range(n):
                 t = int(top16[f])
-                upper = np.isnan(x[f, ..., t:])
+                upper = np.isnan(x[f, :, :, t:])
                 assert upper.all() or not upper.any(), f              # a frame stores all of its upper bands or none
-                assert not np.isnan(x[f, ..., :t]).any(), f
+                assert not np.isnan(x[f, :, :, :t]).any(), f
                 if upper.all():
                     skipped[t] += 1
                 else:

@@ -30,16 +30,16 @@ for step, fr in enumerate(synth.he_stream(rng, cfg, n, steps, hdr, ps_mode=ps_mo
     for s in bad[:2]:
         d = O.he_decode_debug(cfg, fr["coeffs"][s], fr["ics"][s], fr["sbr"][s:s+1], hdr[hc[s]:hc[s]+1] if False else hdr, fr["ps"][s:s+1] if fr["ps"] is not None else None, st_in[s])
         # workspace copies
-        Wg = np.empty((n, ncore, 32, 32, 2), np.float32); Xg = np.empty((n, 2, 2, 38, 64), np.float32)
+        Wg = np.empty((n, ncore, 32, 32, 2), np.float32); Xg = np.empty((n, 2, 38, 64, 2), np.float32)
         torch.cuda.synchronize()
         import ctypes
         tW = torch.empty(Wg.size, device="cuda"); tX = torch.empty(Xg.size, device="cuda")
         hip = C.CDLL("libamdhip64.so")
         hip.hipMemcpy(C.c_void_p(tW.data_ptr()), pW, C.c_size_t(Wg.size * 4), 3)
         Wg = tW.cpu().numpy().reshape(Wg.shape)
-        # X layout in workspace: [frame][2][2][38][64] but W layout is [unit = frame*ncore+ch]
+        # X layout in workspace: [frame][channel][38][64][re, im] (k_common.h, HE_X_CHANNEL); W is [unit = frame*ncore+ch]
         hip.hipMemcpy(C.c_void_p(tX.data_ptr()), pX, C.c_size_t(Xg.size * 4), 3)
-        Xg = tX.cpu().numpy().reshape(Xg.shape)
+        Xg = np.ascontiguousarray(np.moveaxis(tX.cpu().numpy().reshape(Xg.shape), 4, 2))     # -> [frame][channel][re/im][38][64]
         h = hdr[hc[s]]
         print(" stream", s, "hdr", hc[s], "kx", h["kx"], "m", h["m"], "n_q", h["n_q"], "interpol", h["bs_interpol_freq"], "smooth", h["bs_smoothing_mode"])
         c0 = fr["sbr"][s]["ch"][0]
