@@ -18,8 +18,8 @@ struct HeaacDevice {
     uint16_t *d_rev;
     void *d_work;
     unsigned *d_queue;      // frame-queue heads of the kernels that draw frames dynamically (one set per lane)
-    // X hand-over side data: a page of zeros, then per workspace set one byte per frame = the number of QMF bands of
-    // the frame's X rows the HF / PS stage has stored (the bands above are +0 and are not written; the synthesis
+    // X hand-over side data: a page of zeros, then per workspace set one byte per frame and channel = the number of QMF
+    // bands of the X rows the HF / PS stage has stored (the bands above are +0 and are not written; the synthesis
     // kernel reads them from the zero page instead)
     unsigned char *d_aux;
     size_t work_bytes;
@@ -156,7 +156,7 @@ extern "C" int heaac_device_create(HeaacDevice **out, size_t max_frames)
     if (hipMalloc((void **)&d->d_tab, sizeof(t->f)) != hipSuccess ||
         hipMalloc((void **)&d->d_rev, sizeof(t->rev)) != hipSuccess ||
         hipMalloc((void **)&d->d_queue, 64 * HE_MAX_LANES) != hipSuccess ||
-        hipMalloc((void **)&d->d_aux, HE_ZERO_BYTES + (size_t)(d->sets > 0 ? d->sets : 1) * (d->chunk ? d->chunk : 1)) != hipSuccess ||
+        hipMalloc((void **)&d->d_aux, HE_ZERO_BYTES + 2 * (size_t)(d->sets > 0 ? d->sets : 1) * (d->chunk ? d->chunk : 1)) != hipSuccess ||
         (d->work_bytes && hipMalloc(&d->d_work, d->work_bytes) != hipSuccess))
         rc = HEAAC_ERR_NOMEM;
     if (rc == HEAAC_OK &&
@@ -330,7 +330,7 @@ extern "C" int heaac_he_decode_batch_ex(HeaacDevice *dev, int cfg, int flags,
                              d_state_in + f0 * words, d_state_out + f0 * words,
                              (char *)d_pcm + f0 * pcm_bytes, pcm_format,
                              ws_W, ws_X, dev->d_queue + 16 * k,
-                             dev->d_aux + HE_ZERO_BYTES + (size_t)k * dev->chunk, (const float *)dev->d_aux,
+                             dev->d_aux + HE_ZERO_BYTES + 2 * (size_t)k * dev->chunk, (const float *)dev->d_aux,
                              nc, 0, flags, lanes ? dev->lane[k] : s);
     }
     if (lanes) {

@@ -262,7 +262,8 @@ __global__ __launch_bounds__(HF_WAVES * WAVE)
 void k_hfadj(const float *__restrict__ g_tab,
              const HeaacSbrFrame *__restrict__ g_sbr, const HeaacSbrHeader *__restrict__ g_hdr, unsigned n_hdr,
              const float *g_W, const float *g_state_in, float *g_state_out, int state_words,
-             int ncore, int off_sbr0, float *g_X, unsigned long long n_units, unsigned *g_queue)
+             int ncore, int off_sbr0, float *g_X, unsigned long long n_units, unsigned *g_queue,
+             unsigned char *__restrict__ g_xtop)
 {
     __shared__ float s_xlow[HF_WAVES][HF_XLOW_WORDS], s_aux[HF_WAVES][HF_AUX_WORDS], s_rec[HF_WAVES][HF_REC_WORDS];
     __shared__ float s_noise[1024];              // sbr_noise_table, staged once per workgroup
@@ -283,11 +284,24 @@ void k_hfadj(const float *__restrict__ g_tab,
         const int ch = (int)(u - f * ncore);
         const int off = off_sbr0 + ch * HEAAC_ST_SBR;
         v2f *Xc = reinterpret_cast<v2f *>(g_X + (f * 2 + ch) * HE_X_CHANNEL);
+        int xb = 64;
         hf_channel(S, s_noise, &g_sbr[f], g_hdr, n_hdr, ch, g_W + u * 2048,
                    g_state_in + f * state_words + off, g_state_out + f * state_words + off, lane,
                    [&](int i, float re, float im) {
+                       if (i == 0 && g_xtop) {            // (g_xtop == nullptr: a PS stage follows and reads every band)
+                           // sbr_x_gen writes the literal +0 above kx + m (aacsbr.c:1433-1444) -- in its first i_Temp slots
+                           // above the PREVIOUS frame's range (:1419-1432): if there are no such slots or that range ends
+                           // inside this one, the bands from kx + m (rounded up to a 128-byte line) on are +0 in every
+                           // slot.  They are not stored; the unit's byte says how many bands are, and k_synth reads the
+                           // rest from its page of zeros.
+                           const int top16 = (S.h.kx + S.h.m + 15) & ~15;
+                           const int t_old = S.c[ch].t_env_num_env_old;
+                           const bool zero = 2 * t_old - 32 <= 0 || (int)g_sbr[f].kx_old + (int)g_sbr[f].m_old <= top16;
+                           xb = __builtin_amdgcn_readfirstlane(zero && top16 < 64 ? top16 : 64);
+                           if (lane == 0 && xb != 64) g_xtop[f * 2 + ch] = (unsigned char)xb;
+                       }
                        // written once, read by k_synth a whole batch later: non-temporal (-7 % kernel time)
-                       __builtin_nontemporal_store(v2f{re, im}, Xc + i * 64 + lane);
+                       if (lane < xb) __builtin_nontemporal_store(v2f{re, im}, Xc + i * 64 + lane);
                    });
       }
         feed.advance();
@@ -506,7 +520,7 @@ void k_synth(const float *__restrict__ g_tab, const float *g_X,
     // Bands the HF / PS stage did not store (they are +0: g_xtop, one byte per frame) come from a page of zeros: the
     // lanes that would load them aim at that page instead (an address select, no branch around the loads).
     auto load_unit = [&](unsigned long long f, int ch, SynIn &d) {
-        const int xt = __builtin_amdgcn_readfirstlane((int)g_xtop[f]);
+        const int xt = __builtin_amdgcn_readfirstlane((int)g_xtop[f * 2 + ch]);
         const float *X0 = (lane & 31) * 2 < xt ? g_X + (f * 2 + ch) * HE_X_CHANNEL : g_zero;
         syn_load<false>(X0, nullptr, g_state_in + f * state_words + off_syn0 + ch * HEAAC_ST_SYNTH, lane, d);
     };
@@ -769,7 +783,7 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
     // stride stays where it measured faster (k_core_ana, k_hfadj: neighbouring waves share lines)
     if (hipMemsetAsync(d_queue, 0, 64, s) != hipSuccess) return HEAAC_ERR_HIP;
     // every frame's X rows are whole (64 bands) unless the fused HF + PS kernel says otherwise
-    if (hipMemsetAsync(d_xtop, 64, n, s) != hipSuccess) return HEAAC_ERR_HIP;
+    if (hipMemsetAsync(d_xtop, 64, 2 * n, s) != hipSuccess) return HEAAC_ERR_HIP;
     hipLaunchKernelGGL(k_core_ana, dim3(he_grid((units + 1) / 2, CA_WAVES)), dim3(CA_WAVES * WAVE), 0, s,
                        d_tab, d_rev, d_coeffs, d_ics, d_state_in, d_state_out, words, ncore,
                        off_saved0, off_sbr0, d_ws_W, 1 / (-1024 * sf_scale), units);
@@ -785,7 +799,7 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
     } else {
         hipLaunchKernelGGL(k_hfadj, dim3(he_grid((units + 1) / 2, HF_WAVES)), dim3(HF_WAVES * WAVE), 0, s,
                            d_tab, d_sbr, d_hdr, n_hdr, d_ws_W, d_state_in, d_state_out, words, ncore, off_sbr0,
-                           d_ws_X, units, d_queue + 1);
+                           d_ws_X, units, d_queue + 1, cfg == HEAAC_CFG_HEV2 ? nullptr : d_xtop);
         if (cfg == HEAAC_CFG_HEV2) {
             int rc = heaac_launch_ps(d_tab, d_ps, d_sbr, d_hdr, n_hdr, d_state_in, d_state_out, words,
                                      off_syn0 + 2 * HEAAC_ST_SYNTH, d_ws_X, n, 3, s);

@@ -177,7 +177,7 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
             const bool x_zero_above = __builtin_amdgcn_readfirstlane(
                 2 * t_old - 32 <= 0 || (int)g_sbr[f].kx_old + (int)g_sbr[f].m_old <= ((top + 15) & ~15));
             ps_frame<false, true>(W, g_tab, &g_ps[f], top, st_in + off_ps, st_out + off_ps, Xf, lane, wave, col,
-                                  prefetch_next, g_xtop + f, x_zero_above);
+                                  prefetch_next, g_xtop + 2 * f, x_zero_above);
         }
         feed.advance();
     }

@@ -936,7 +936,7 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
             const bool bad = lane < nr_par && lane >= kMem20.kti[top16 + 7] && !h_ok;
             if (__builtin_amdgcn_readfirstlane(__ballot(bad) == 0ull)) x_bands = top16;
         }
-        if (x_bands_out && x_bands != 64 && lane == 0) *x_bands_out = (unsigned char)x_bands;
+        if (x_bands_out && x_bands != 64 && lane == 0) { x_bands_out[0] = (unsigned char)x_bands; x_bands_out[1] = (unsigned char)x_bands; }
     }
     // ---- pass 1: hybrid bands 0..63 = all sub-subbands + the first QMF bands ----
     {

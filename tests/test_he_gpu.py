@@ -542,3 +542,52 @@ def test_unstored_x_bands_are_never_read(pkg, oracle, dev):
         assert skipped[48] > n // 2 and skipped[32] > n // 8 and full > n // 4, (skipped, full)
     finally:
         small.close()
+
+
+def test_unstored_x_bands_are_never_read_hev1(pkg, oracle, dev):
+    """The same for HE-AACv1, where the HF kernel itself leaves out the bands above kx + m (sbr_x_gen's literal +0) and
+    says so per channel: workspace poisoned, PCM and state bit-exact, and the bands above the range (rounded up to a
+    128-byte line) are still NaN afterwards in every frame whose first slots do not follow an older, wider range."""
+    import ctypes as C
+    import torch
+    synth = _synth()
+    cfg = pkg.CFG_HEV1
+    n = 112
+    hdr = synth.default_headers(pkg, extra=True)
+    hc = np.arange(n) % len(hdr)
+    top16 = ((hdr["kx"].astype(int) + hdr["m"].astype(int) + 15) & ~15)[hc]
+    rng = np.random.default_rng(2025)
+    frames = list(synth.he_stream(rng, cfg, n, 4, hdr, hdr_choice=hc, events=dict(p_switch=0.15)))
+    small = pkg.Device(n)
+    hip = C.CDLL("libamdhip64.so")
+    try:
+        pW, pX, chunk = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        assert pkg.lib().heaac_debug_workspace(small._h, C.byref(pW), C.byref(pX), C.byref(chunk)) == 0
+        xrec = 2 * 38 * 64 * 2
+        state = np.zeros((n, pkg.STATE_WORDS[cfg]), np.float32)
+        d_state = torch.from_numpy(state).cuda()
+        d_hdr = pkg.to_device(hdr)
+        skipped = full = 0
+        for fr in frames:
+            poison = torch.full((n * xrec,), float("nan"), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            assert hip.hipMemcpy(C.c_void_p(pX.value), C.c_void_p(poison.data_ptr()), C.c_size_t(n * xrec * 4), 3) == 0
+            ref_pcm, state = oracle.he_decode_batch(cfg, fr["coeffs"], fr["ics"], fr["sbr"], hdr, None, state)
+            pcm, d_state = small.he_decode(cfg, torch.from_numpy(fr["coeffs"]).cuda(), pkg.to_device(fr["ics"]),
+                                           pkg.to_device(fr["sbr"]), d_hdr, None, d_state)
+            torch.cuda.synchronize()
+            assert np.array_equal(pcm.cpu().numpy().view(np.uint32), ref_pcm.view(np.uint32))
+            assert np.array_equal(d_state.cpu().numpy().view(np.uint32), state.view(np.uint32))
+            back = torch.empty(n * xrec, dtype=torch.float32, device="cuda")
+            assert hip.hipMemcpy(C.c_void_p(back.data_ptr()), C.c_void_p(pX.value), C.c_size_t(n * xrec * 4), 3) == 0
+            x = back.cpu().numpy().reshape(n, 2, 38, 64, 2)
+            for f in range(n):
+                t = int(((int(hdr[int(fr["sbr"][f]["hdr"])]["kx"]) + int(hdr[int(fr["sbr"][f]["hdr"])]["m"]) + 15) & ~15))
+                for c in range(2):
+                    upper = np.isnan(x[f, c, :, t:]) if t < 64 else np.zeros(1, bool)
+                    assert upper.all() or not upper.any(), (f, c)
+                    assert not np.isnan(x[f, c, :, :t]).any(), (f, c)
+                    skipped += int(t < 64 and upper.all()); full += int(not upper.all())
+        assert skipped > 4 * n and full > 0, (skipped, full)
+    finally:
+        small.close()
