@@ -926,7 +926,7 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     // BOTH factors are negative (or not finite), and likewise h12 / h22 for the right channel.  If, for every
     // parameter band that covers such a band and every envelope, one factor of each pair stays above 1e-3 at both ends
     // of its interpolation (and all four inside +-16, so that 32 rounded steps cannot carry it below zero: h_ok, formed
-    // with the matrices above), every X value of the bands from top (rounded up to 64 bytes of a row) on is exactly
+    // with the matrices above), every X value of the bands from top (rounded up to a 128-byte line of a row: 16 bands) on is exactly
     // +0: they are not stored, the frame's byte in x_bands_out says so, and k_synth reads them from a page of zeros.
     int x_bands = 64;
     if constexpr (FUSED) {
