@@ -225,7 +225,8 @@ __device__ __forceinline__ void hybrid_fir(const float *in, const float *filt, f
 // fused kernel touches the next frame's records into L2 from it: early enough to be back before
 // they are needed, late enough to survive in L2 until then.
 typedef GBufT<2> GBufSO;          // the state record out (aux 2 = non-temporal): written once per frame, read by the next launch
-typedef GBufT<0> GBufXR;          // the X rows of the slot loop (nt measured +1.5 %: the hybrid synthesis completes these lines later)
+typedef GBufT<2> GBufXR;          // the X rows of the slot loop: non-temporal too since they leave as whole (re, im) rows (-0.8 %; with the
+                                  // plane layout of rounds 1-2, whose lines the hybrid synthesis completed later, it was +1.5 %)
 template <bool HEAVY, bool ALIGNED8, bool DUAL, int X_BANDS = 64, class W, class Hook = NoHook>
 __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, const signed char *kti,
                                         int is34, int kh, bool clear_state,
