@@ -99,7 +99,7 @@ CC_BEFORE_TNS, CC_BETWEEN_TNS_AND_IMDCT, CC_AFTER_IMDCT = 0, 1, 3
 TOOLS_PRE, TOOLS_POST, TOOLS_ALL = 1, 2, 3
 CCE_LINK_DT = np.dtype([("target_ch", "u1"), ("pad", "u1", (3,)), ("gain", "<f4", (120,))])
 CCE_FRAME_DT = np.dtype([("present", "u1"), ("elem_id", "u1"), ("coupling_point", "u1"), ("n_links", "u1"),
-                         ("behind_target", "u1"), ("seq", "u1"), ("pad", "u1", (2,)), ("ics", TOOLS_ICS_DT), ("band_type", "u1", (128,)),
+                         ("behind_target", "u1"), ("seq", "u1"), ("outputs_before", "u1"), ("pad", "u1"), ("ics", TOOLS_ICS_DT), ("band_type", "u1", (128,)),
                          ("link", CCE_LINK_DT, (MAX_CCE_LINKS,))])
 assert CCE_LINK_DT.itemsize == 484 and CCE_FRAME_DT.itemsize == 2216
 assert SBR_HDR_DT.itemsize == 532 and SBR_CH_DT.itemsize == 336
@@ -123,7 +123,7 @@ EXPORTED = [
     # heaac_codec.h
     "heaac_aac_decoder", "heaac_codec_open", "heaac_codec_decode", "heaac_codec_close",
     # heaac_parse.h
-    "heaac_asc_parse", "heaac_ga_specific_config", "heaac_aac_parse_frame_ex", "heaac_pcm_interleave_batch", "heaac_aac_layout_default", "heaac_aac_layout_from_pce", "heaac_asc_layout", "heaac_aac_parse_frame_layout", "heaac_spectral_tools_batch_ex", "heaac_codec_get_context_defaults", "heaac_adts_parse_header", "heaac_adts_probe", "heaac_adts_split",
+    "heaac_asc_parse", "heaac_ga_specific_config", "heaac_aac_parse_frame_ex", "heaac_pcm_interleave_batch", "heaac_aac_layout_default", "heaac_aac_layout_from_pce", "heaac_asc_layout", "heaac_aac_parse_frame_layout", "heaac_aac_parse_frame_layout_ex", "heaac_spectral_tools_batch_ex", "heaac_codec_get_context_defaults", "heaac_adts_parse_header", "heaac_adts_probe", "heaac_adts_split",
     "heaac_heaac_parse_frame_ex", "heaac_pipeline_create", "heaac_pipeline_destroy", "heaac_pipeline_submit",
     "heaac_pipeline_collect", "heaac_pipeline_timing",
     "heaac_multi_shard", "heaac_multi_create", "heaac_multi_destroy", "heaac_multi_devices", "heaac_multi_device",
@@ -600,20 +600,27 @@ def asc_layout(buf):
     return lib().heaac_asc_layout(C.byref(c), l.ctypes.data_as(C.c_void_p), buf, len(buf)), c, l
 
 
-def aac_parse_frame_layout(cfg, layout, streams, au):
-    """heaac_aac_parse_frame_layout on one access unit.  layout: one AAC_LAYOUT_DT record (its tag map is updated),
-    streams: AAC_STREAM_DT [n_elements] (updated).  Returns (status, dict(coeffs [ne][2][1024], ics [ne][2], tools [ne],
-    elem [ne], info))."""
+def aac_parse_frame_layout(cfg, layout, streams, au, with_cce=False):
+    """heaac_aac_parse_frame_layout (with_cce: heaac_aac_parse_frame_layout_ex) on one access unit.  layout: one
+    AAC_LAYOUT_DT record (its tag map is updated), streams: AAC_STREAM_DT [n_elements] (updated).  Returns (status,
+    dict(coeffs [ne][2][1024], ics [ne][2], tools [ne], elem [ne], info; with_cce: cce [ne][MAX_CCE], cce_coeffs
+    [MAX_CCE][1024], cce_ics [MAX_CCE], cce_tools [MAX_CCE]))."""
     au = bytes(au)
     ne = int(layout[0]["n_elements"])
     assert streams.dtype == AAC_STREAM_DT and streams.shape[0] >= ne
     out = dict(coeffs=np.zeros((ne, 2, 1024), np.float32), ics=np.zeros((ne, 2), ICS_DT), tools=np.zeros(ne, TOOLS_FRAME_DT),
                elem=np.zeros(ne, AAC_ELEM_INFO_DT), info=np.zeros(1, AAC_INFO_DT))
-    r = lib().heaac_aac_parse_frame_layout(C.byref(cfg), layout.ctypes.data_as(C.c_void_p), streams.ctypes.data_as(C.c_void_p),
-                                           au, len(au), out["coeffs"].ctypes.data_as(C.c_void_p),
-                                           out["ics"].ctypes.data_as(C.c_void_p), out["tools"].ctypes.data_as(C.c_void_p),
-                                           out["elem"].ctypes.data_as(C.c_void_p), out["info"].ctypes.data_as(C.c_void_p))
-    return r, out
+    args = (C.byref(cfg), layout.ctypes.data_as(C.c_void_p), streams.ctypes.data_as(C.c_void_p),
+            au, len(au), out["coeffs"].ctypes.data_as(C.c_void_p),
+            out["ics"].ctypes.data_as(C.c_void_p), out["tools"].ctypes.data_as(C.c_void_p),
+            out["elem"].ctypes.data_as(C.c_void_p))
+    if not with_cce:
+        return lib().heaac_aac_parse_frame_layout(*args, out["info"].ctypes.data_as(C.c_void_p)), out
+    out.update(cce=np.zeros((ne, MAX_CCE), CCE_FRAME_DT), cce_coeffs=np.zeros((MAX_CCE, 1024), np.float32),
+               cce_ics=np.zeros(MAX_CCE, ICS_DT), cce_tools=np.zeros(MAX_CCE, TOOLS_FRAME_DT))
+    co = _CceOut(out["cce"].ctypes.data, out["cce_coeffs"].ctypes.data, out["cce_ics"].ctypes.data,
+                 out["cce_tools"].ctypes.data)
+    return lib().heaac_aac_parse_frame_layout_ex(*args, C.byref(co), out["info"].ctypes.data_as(C.c_void_p)), out
 
 
 def aac_parse_batch(cfg, streams, aus, threads=0):

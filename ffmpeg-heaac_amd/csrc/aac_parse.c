@@ -533,23 +533,26 @@ static int skip_pce(Bits *b)
     return HEAAC_PARSE_OK;
 }
 
-/* coupling_channel_element (decode_cce, aacdec.c:1503-1570).  The element's target list is resolved against the
- * ONE output element of this slice the way apply_channel_coupling walks it (:1870-1898): every entry consumes
- * one gain list, or two for a pair coupled with separate gains (ch_select 3), whether or not it names our
- * element; an entry that does name it contributes links (target channel, list index). */
+/* coupling_channel_element (decode_cce, aacdec.c:1503-1570) */
 typedef struct { int type, id, ch_select; } CceTarget;
-
-static int read_cce(const HeaacAacConfig *cfg, Bits *b, int elem_id, int target_type, int target_id, int behind,
-                    HeaacCceFrame *out, HeaacToolsChannel *ch, WinInfo *w, float coef[1024])
-{
+/* A coupling element as transmitted: its target list and its gain lists in transmission order (:1538-1567).  Which
+ * of the lists land on an output element is cce_resolve's. */
+typedef struct {
+    int num_coupled;
     CceTarget tg[8];
+    float gl[16][120];
+} CceLists;
+
+static int read_cce(const HeaacAacConfig *cfg, Bits *b, int elem_id, HeaacCceFrame *out, CceLists *ls,
+                    HeaacToolsChannel *ch, WinInfo *w, float coef[1024])
+{
+    CceTarget *tg = ls->tg;
     int num_gain = 0;
     memset(out, 0, sizeof(*out));
     out->present = 1;
     out->elem_id = (uint8_t)elem_id;
-    out->behind_target = (uint8_t)behind;
     int point = 2 * (int)bit1(b);                      /* ind_sw_cce_flag */
-    const int num_coupled = (int)bits(b, 3);
+    const int num_coupled = ls->num_coupled = (int)bits(b, 3);
     for (int c = 0; c <= num_coupled; c++) {
         num_gain++;
         tg[c].type = bit1(b) ? TYPE_CPE : TYPE_SCE;
@@ -570,8 +573,8 @@ static int read_cce(const HeaacAacConfig *cfg, Bits *b, int elem_id, int target_
     memcpy(out->band_type, ch->band_type, sizeof(out->band_type));
 
     /* the gain lists, in transmission order (:1538-1567) */
-    float gl[16][120];
-    memset(gl, 0, sizeof(gl));
+    float (*gl)[120] = ls->gl;
+    memset(ls->gl, 0, sizeof(ls->gl));
     for (int c = 0; c < num_gain; c++) {
         int idx = 0, cge = 1, gain = 0;
         float gain_cache = 1.0f;
@@ -606,24 +609,32 @@ static int read_cce(const HeaacAacConfig *cfg, Bits *b, int elem_id, int target_
                 gl[c][idx] = gain_cache;
             }
     }
-    /* which lists land on the output element, and on which of its channels */
+    return HEAAC_PARSE_OK;
+}
+
+/* Which lists land on the output element (target_type, target_id), and on which of its channels: the index walk of
+ * apply_channel_coupling (:1870-1898) -- every entry of the target list consumes one gain list, or two for a pair
+ * coupled with separate gains (ch_select 3), whether or not it names this element. */
+static int cce_resolve(const CceLists *ls, int target_type, int target_id, HeaacCceFrame *out)
+{
     int index = 0, n_links = 0;
-    for (int c = 0; c <= num_coupled; c++) {
-        if (tg[c].type == target_type && tg[c].id == target_id) {
+    for (int c = 0; c <= ls->num_coupled; c++) {
+        const CceTarget *tg = &ls->tg[c];
+        if (tg->type == target_type && tg->id == target_id) {
             int use[2], nuse = 0, chn[2];
-            if (tg[c].ch_select != 1) {
+            if (tg->ch_select != 1) {
                 use[nuse] = index; chn[nuse++] = 0;
-                if (tg[c].ch_select != 0) index++;
+                if (tg->ch_select != 0) index++;
             }
-            if (tg[c].ch_select != 2) { use[nuse] = index++; chn[nuse++] = 1; }
+            if (tg->ch_select != 2) { use[nuse] = index++; chn[nuse++] = 1; }
             for (int k = 0; k < nuse; k++) {
                 if (n_links >= HEAAC_MAX_CCE_LINKS) return HEAAC_PARSE_ERR_UNSUPPORTED;
                 out->link[n_links].target_ch = (uint8_t)chn[k];
-                memcpy(out->link[n_links].gain, gl[use[k]], sizeof(out->link[n_links].gain));
+                memcpy(out->link[n_links].gain, ls->gl[use[k]], sizeof(out->link[n_links].gain));
                 n_links++;
             }
         } else {
-            index += 1 + (tg[c].ch_select == 3);
+            index += 1 + (tg->ch_select == 3);
         }
     }
     out->n_links = (uint8_t)n_links;
@@ -715,9 +726,12 @@ int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
             wc[slot].use_kb_window[0] = st->cce_use_kb_window[slot];
             wc[slot].window_sequence[1] = wc[slot].use_kb_window[1] = 0;
             memset(&cce->tools[slot], 0, sizeof(HeaacToolsFrame));
-            r = read_cce(cfg, &b, elem_id, target_type, 0, fi.channels != 0, &cce->cce[slot], &cce->tools[slot].ch[0],
-                         &wc[slot], cce->coeffs + slot * 1024);
+            CceLists ls;
+            r = read_cce(cfg, &b, elem_id, &cce->cce[slot], &ls, &cce->tools[slot].ch[0], &wc[slot],
+                         cce->coeffs + slot * 1024);
             if (r < 0) return r;
+            if ((r = cce_resolve(&ls, target_type, 0, &cce->cce[slot])) < 0) return r;
+            cce->cce[slot].behind_target = cce->cce[slot].outputs_before = (uint8_t)(fi.channels != 0);
             cce->cce[slot].seq = (uint8_t)(n_cce - 1);
             break;
         }
@@ -850,7 +864,10 @@ int heaac_aac_layout_from_pce(HeaacAacLayout *l, const uint8_t *buf, int size, i
         }
     for (int i = 0; i < num_lfe; i++) have[TYPE_LFE][bits(&b, 4)] = 1;
     skip(&b, 4 * num_assoc);
-    skip(&b, 5 * num_cc);                              /* coupling elements: not part of the output order */
+    for (int i = 0; i < num_cc; i++) {
+        bit1(&b);                                      /* cc_element_is_ind_sw: the element says so itself */
+        have[TYPE_CCE][bits(&b, 4)] = 1;
+    }
     b.pos = (b.pos + 7) & ~7;
     const int comment = 8 * (int)bits(&b, 8);
     if (b.over || bits_left(&b) < comment) return HEAAC_PARSE_ERR_OVERREAD;
@@ -862,6 +879,10 @@ int heaac_aac_layout_from_pce(HeaacAacLayout *l, const uint8_t *buf, int size, i
         for (int t = 0; t < 3; t++)
             if (have[order[t]][id] && layout_add(l, order[t], id) < 0) return HEAAC_PARSE_ERR_UNSUPPORTED;
     }
+    /* the coupling elements the program names (che_configure allocates no others, :198-212): not output elements;
+     * their slots, in ascending tag order, are the order apply_channel_coupling walks them in (:1876) */
+    for (int id = 0, k = 0; id < 16; id++)
+        if (have[TYPE_CCE][id]) l->slot_of[TYPE_CCE][id] = (int8_t)++k;
     memcpy(l->tag_map, l->slot_of, sizeof(l->tag_map));      /* tag_che_map = che: elements are found by their tag */
     l->tags_mapped = 4 * 16;
     if (bits_used) *bits_used = b.pos - bit_offset;
@@ -913,9 +934,18 @@ int heaac_aac_parse_frame_layout(const HeaacAacConfig *cfg, HeaacAacLayout *layo
                                  float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
                                  HeaacAacElementInfo *elem, HeaacAacFrameInfo *info)
 {
+    return heaac_aac_parse_frame_layout_ex(cfg, layout, st, au, size, coeffs, ics, tools, elem, NULL, info);
+}
+
+int heaac_aac_parse_frame_layout_ex(const HeaacAacConfig *cfg, HeaacAacLayout *layout, HeaacAacStream *st,
+                                    const uint8_t *au, int size,
+                                    float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
+                                    HeaacAacElementInfo *elem, const HeaacCceOut *cce, HeaacAacFrameInfo *info)
+{
     if (!cfg || !layout || !st || !au || size <= 0 || !coeffs || !ics || !tools || !elem ||
         cfg->sampling_index < 0 || cfg->sampling_index > 12 ||
-        layout->n_elements < 1 || layout->n_elements > HEAAC_MAX_ELEMENTS)
+        layout->n_elements < 1 || layout->n_elements > HEAAC_MAX_ELEMENTS ||
+        (cce && (!cce->cce || !cce->coeffs || !cce->ics || !cce->tools)))
         return HEAAC_PARSE_ERR_ARG;
     pthread_once(&g_once, tables_init);
     if (g_tables_bad) return HEAAC_PARSE_ERR_ARG;
@@ -942,6 +972,13 @@ int heaac_aac_parse_frame_layout(const HeaacAacConfig *cfg, HeaacAacLayout *layo
     uint8_t seen[4][16];
     memset(seen, 0, sizeof(seen));
     int n_seen = 0, prev_slot = -1, prev_is_output = 0, type, r;
+    /* coupling elements: slot k of the layout's list; lists[k] until the output elements are all known */
+    WinInfo wc[HEAAC_MAX_CCE];
+    HeaacCceFrame cbase[HEAAC_MAX_CCE];
+    CceLists lists[HEAAC_MAX_CCE];
+    int n_cce = 0;
+    memset(cbase, 0, sizeof(cbase));
+    if (cce) memset(cce->cce, 0, (size_t)ne * HEAAC_MAX_CCE * sizeof(HeaacCceFrame));
     while ((type = (int)bits(&b, 3)) != TYPE_END) {
         int tag = (int)bits(&b, 4);
         int slot = -1;
@@ -966,8 +1003,24 @@ int heaac_aac_parse_frame_layout(const HeaacAacConfig *cfg, HeaacAacLayout *layo
             elem[slot].seq = (uint8_t)n_seen++;
             break;
         }
-        case TYPE_CCE:
-            return HEAAC_PARSE_ERR_UNSUPPORTED;
+        case TYPE_CCE: {
+            /* get_che: a tag met twice moves up; only what a program config element named is allocated */
+            while (tag < 16 && seen[TYPE_CCE][tag]) tag++;
+            if (tag == 16) return HEAAC_PARSE_ERR_DATA;
+            seen[TYPE_CCE][tag] = 1;
+            const int k = layout->tag_map[TYPE_CCE][tag] - 1;
+            if (k < 0) return HEAAC_PARSE_ERR_DATA;   /* "channel element 2.%d is not allocated" */
+            if (!cce || k >= HEAAC_MAX_CCE) return HEAAC_PARSE_ERR_UNSUPPORTED;
+            wc[k].window_sequence[0] = st[0].cce_window_sequence[k];
+            wc[k].use_kb_window[0] = st[0].cce_use_kb_window[k];
+            wc[k].window_sequence[1] = wc[k].use_kb_window[1] = 0;
+            memset(&cce->tools[k], 0, sizeof(HeaacToolsFrame));
+            r = read_cce(cfg, &b, tag, &cbase[k], &lists[k], &cce->tools[k].ch[0], &wc[k], cce->coeffs + k * 1024);
+            if (r < 0) return r;
+            cbase[k].outputs_before = (uint8_t)n_seen;
+            cbase[k].seq = (uint8_t)n_cce++;
+            break;
+        }
         case TYPE_DSE:
             if ((r = skip_dse(&b)) < 0) return r;
             break;
@@ -1003,6 +1056,26 @@ int heaac_aac_parse_frame_layout(const HeaacAacConfig *cfg, HeaacAacLayout *layo
         if (bits_left(&b) < 3) return HEAAC_PARSE_ERR_OVERREAD;
     }
     if (!n_seen) return HEAAC_PARSE_ERR_DATA;
+    /* every coupling element against every output element: apply_channel_coupling compares the target list with the
+     * element's place in ac->che[type][] (:1903-1933 hands it `i`), which a program config element makes its tag */
+    for (int k = 0; k < HEAAC_MAX_CCE; k++) {
+        if (!cbase[k].present) continue;
+        for (int e = 0; e < ne; e++) {
+            HeaacCceFrame *o = &cce->cce[e * HEAAC_MAX_CCE + k];
+            *o = cbase[k];
+            o->behind_target = (uint8_t)(elem[e].present && cbase[k].outputs_before > elem[e].seq);
+            if ((r = cce_resolve(&lists[k], layout->elem[e].type, layout->elem[e].id, o)) < 0) return r;
+        }
+    }
+    for (int k = 0; k < HEAAC_MAX_CCE; k++) {
+        if (!cbase[k].present) continue;
+        cce->ics[k].window_sequence[0] = wc[k].window_sequence[0];
+        cce->ics[k].window_sequence[1] = wc[k].window_sequence[1];
+        cce->ics[k].use_kb_window[0] = wc[k].use_kb_window[0];
+        cce->ics[k].use_kb_window[1] = wc[k].use_kb_window[1];
+        st[0].cce_window_sequence[k] = wc[k].window_sequence[0];
+        st[0].cce_use_kb_window[k] = wc[k].use_kb_window[0];
+    }
     for (int e = 0; e < ne; e++) {
         if (!elem[e].present) continue;
         for (int c = 0; c < layout->elem[e].channels; c++) {
@@ -1020,6 +1093,7 @@ int heaac_aac_parse_frame_layout(const HeaacAacConfig *cfg, HeaacAacLayout *layo
         info->channels = layout->channels;
         info->bits_consumed = b.pos;
         info->sbr_payload_bit = -1;
+        info->n_cce = n_cce;
     }
     return HEAAC_PARSE_OK;
 }

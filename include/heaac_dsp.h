@@ -528,7 +528,10 @@ typedef struct HeaacCceFrame {
                                          noise generator across elements) */
     uint8_t seq;                      /* position among the access unit's coupling elements in BITSTREAM order (the
                                          slots are in tag order) */
-    uint8_t pad[2];
+    uint8_t outputs_before;           /* output elements (SCE / CPE / LFE) in front of it in the access unit: with
+                                         HeaacAacElementInfo.seq and `seq` the order of ALL elements, which is the
+                                         order the noise generator runs through them */
+    uint8_t pad;
     HeaacToolsIcs ics;                /* the coupling channel's own grouping and band offsets */
     uint8_t band_type[128];           /* its band types: ZERO_BT (0) bands couple nothing (:1828) */
     HeaacCceLink link[HEAAC_MAX_CCE_LINKS];

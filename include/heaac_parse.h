@@ -126,7 +126,7 @@ typedef struct HeaacAacFrameInfo {
     int sbr_payload_bytes;        /* its length in bytes (the `cnt` of decode_extension_payload) */
     int sbr_crc;
     int elem_id;                  /* instance tag of the output element */
-    int n_cce;                    /* coupling elements found (heaac_aac_parse_frame_ex) */
+    int n_cce;                    /* coupling elements found (heaac_aac_parse_frame_ex, heaac_aac_parse_frame_layout_ex) */
 } HeaacAacFrameInfo;
 
 /* What heaac_aac_parse_frame_ex adds for access units that carry coupling channel elements: per slot (ascending
@@ -152,12 +152,16 @@ int heaac_aac_parse_frame(const HeaacAacConfig *cfg, HeaacAacStream *st,
                           float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
                           HeaacAacFrameInfo *info);
 
-/* The same for everything aac_decode_frame accepts with one SCE or one CPE as the output element: data stream and
- * fill elements anywhere, program config elements (read past: decode_pce :303-357; the channel layout stays the one
- * of the configuration), and up to HEAAC_MAX_CCE coupling channel elements into `cce` (NULL: an access unit with a
- * coupling element is HEAAC_PARSE_ERR_UNSUPPORTED, as in heaac_aac_parse_frame).  A second SCE / CPE / LFE, a
- * third coupling element, or more than HEAAC_MAX_CCE_LINKS gain lists of one element landing on the target are
- * HEAAC_PARSE_ERR_UNSUPPORTED.
+/* The same for an access unit with one SCE or one CPE as the output element: data stream and fill elements
+ * anywhere, program config elements (read past: decode_pce :303-357; the channel layout stays the one of the
+ * configuration), and up to HEAAC_MAX_CCE coupling channel elements into `cce` (NULL: an access unit with a
+ * coupling element is HEAAC_PARSE_ERR_UNSUPPORTED, as in heaac_aac_parse_frame), their gain lists resolved against
+ * the output element as (type of the configuration, tag 0).  A second SCE / CPE / LFE, a third coupling element, or
+ * more than HEAAC_MAX_CCE_LINKS gain lists of one element landing on the target are HEAAC_PARSE_ERR_UNSUPPORTED.
+ * This is the record-level entry (it feeds heaac_spectral_tools_batch_ex and the coupling tests).  aac_decode_frame
+ * itself only knows the coupling elements a program config element has named (che_configure :198-212; get_che
+ * :132-177 finds no other, "channel element 2.%d is not allocated"): through the codec surface such access units
+ * decode in a channel-configuration-0 stream, by heaac_aac_parse_frame_layout_ex below, and fail in any other.
  * coeff_channels: 1 or 2 -- the channel stride of `coeffs`, `ics`: 2 = [2][1024] / [2] as above, 1 = [1][1024] /
  * [1] packed for mono streams (a CPE then fails with HEAAC_PARSE_ERR_ARG). */
 int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
@@ -173,9 +177,9 @@ int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
  * (che_configure: `output_data[channels++]`), plus what get_che needs to find an element of the bitstream in it:
  * for the channel configurations 1..7 the elements are taken BY POSITION -- the n-th output element of a stream must
  * be of the type the configuration has there, whatever its instance tag, and keeps that tag from then on -- for a
- * program config element by (type, tag).  Coupling channel elements are not part of a layout here
- * (HEAAC_PARSE_ERR_UNSUPPORTED in heaac_aac_parse_frame_layout; heaac_aac_parse_frame_ex has them for one- and
- * two-channel streams). */
+ * program config element by (type, tag).  Coupling channel elements are no output elements: a program config
+ * element's are kept in slot_of / tag_map[HEAAC_ELEM_CCE][tag] as 1 + their place in ascending tag order (the order
+ * apply_channel_coupling walks them in, :1876); a channel configuration 1..7 has none. */
 enum { HEAAC_ELEM_SCE = 0, HEAAC_ELEM_CPE = 1, HEAAC_ELEM_CCE = 2, HEAAC_ELEM_LFE = 3 };
 #define HEAAC_MAX_ELEMENTS 16     /* output elements of one layout (channel configuration 7 has five) */
 #define HEAAC_MAX_LAYOUT_CHANNELS 16
@@ -236,14 +240,31 @@ typedef struct HeaacAacElementInfo {
  * The layout's tag map is updated as get_che updates tag_che_map.  An in-band program config element is read
  * past (the reference ignores it too once the layout is settled, :2041-2043).  info->channels = the layout's.
  * Returns HEAAC_PARSE_OK; HEAAC_PARSE_ERR_DATA for an element the layout has no place for ("channel element is
- * not allocated", :2006-2010); HEAAC_PARSE_ERR_UNSUPPORTED for a coupling channel element and for an SBR payload
- * that does not directly follow its element (the reference hands such a payload to its SBR reader with the type of
+ * not allocated", :2006-2010) -- a coupling channel element the layout does not name included;
+ * HEAAC_PARSE_ERR_UNSUPPORTED for a coupling channel element it does name (heaac_aac_parse_frame_layout_ex takes
+ * those) and for an SBR payload that does not directly follow its element (the reference hands such a payload to its SBR reader with the type of
  * the data / fill element in between, which switches that element's SBR off); other errors as heaac_aac_parse_frame.  On error the stream states are left as they were (the tag map keeps what it learned, as
  * the reference's does). */
 int heaac_aac_parse_frame_layout(const HeaacAacConfig *cfg, HeaacAacLayout *layout, HeaacAacStream *st,
                                  const uint8_t *au, int size,
                                  float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
                                  HeaacAacElementInfo *elem, HeaacAacFrameInfo *info);
+
+/* The same with the coupling channel elements of the layout (aac_decode_frame :2025-2027 decode_cce):
+ *   cce->cce    [n_elements][HEAAC_MAX_CCE]  per OUTPUT slot the coupling elements with the gain lists that land on
+ *                                            that element (apply_channel_coupling compares the target list with the
+ *                                            element's type and its place in ac->che[type][], :1880-1881 -- for a
+ *                                            program-config layout its tag); the index is the coupling element's
+ *                                            place in the layout (ascending tag), `present` = 0 where the access
+ *                                            unit left it out
+ *   cce->coeffs [HEAAC_MAX_CCE][1024], cce->ics [HEAAC_MAX_CCE], cce->tools [HEAAC_MAX_CCE] (channel 0)
+ * The coupling channels' window history is st[0].cce_window_sequence / cce_use_kb_window.  info->n_cce = coupling
+ * elements found.  A coupling element beyond the layout's first HEAAC_MAX_CCE, or with more than
+ * HEAAC_MAX_CCE_LINKS gain lists on one output element: HEAAC_PARSE_ERR_UNSUPPORTED. */
+int heaac_aac_parse_frame_layout_ex(const HeaacAacConfig *cfg, HeaacAacLayout *layout, HeaacAacStream *st,
+                                    const uint8_t *au, int size,
+                                    float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
+                                    HeaacAacElementInfo *elem, const HeaacCceOut *cce, HeaacAacFrameInfo *info);
 
 /* n independent streams, one access unit each, on `threads` host threads (<= 0: one per online CPU).
  *   au[n], size[n]         access units

@@ -228,14 +228,15 @@ def test_what_a_layout_has_no_place_for_is_refused(pkg):
     assert parse(6, [(SCE, 0), (CPE, 0), (LFE, 0)]) == -1  # the LFE before the back pair
     assert parse(2, [(SCE, 0)]) == -1
     assert parse(5, [(SCE, 0), (CPE, 0)]) == 0             # an access unit may leave elements out
-    # a coupling element: outside this entry
+    # a coupling element in a channel-configuration stream: get_che has no place for it (:132-177), whoever asks
     bw = W.BitWriter()
     write_elem(bw, rng, si, aot, SCE, 0)
     import test_parse_wide as TW
     TW.write_cce(bw, rng, si, aot, 0, [(0, 0, 2)], 0)
     bw.put(7, 3)
-    r, l = pkg.aac_layout_default(3)
-    assert pkg.aac_parse_frame_layout(TP._cfg(pkg, aot, si, 3), l, st.copy(), bw.bytes())[0] == -3
+    for with_cce in (False, True):
+        r, l = pkg.aac_layout_default(3)
+        assert pkg.aac_parse_frame_layout(TP._cfg(pkg, aot, si, 3), l, st.copy(), bw.bytes(), with_cce=with_cce)[0] == -1
     # an SBR payload in front of every element, and one behind a data stream element
     bw = W.BitWriter()
     write_fill(bw, rng, 0xd, 5); write_elem(bw, rng, si, aot, SCE, 0); bw.put(7, 3)
@@ -329,6 +330,100 @@ def test_a_program_config_element_gives_the_layout(pkg):
         assert pkg.aac_parse_frame_layout(TP._cfg(pkg, aot, si, 0), l, st, au)[0] == -1
     # truncated
     assert pkg.aac_layout_from_pce(bw.bytes()[:3], lead)[0] == -2
+
+
+def test_coupling_elements_of_a_program_config_layout(pkg):
+    """decode_pce names the coupling elements (:343-344), decode_cce reads them (:1503-1570), apply_channel_coupling
+    (:1870-1898) finds the gain lists of every output element by (type, place in che[type][] = tag): the record of a
+    coupling element comes back once per output slot with the lists that land there."""
+    import test_parse_wide as TW
+    rng = np.random.default_rng(36)
+    si, aot = 3, 2
+    elems = [(SCE, 4), (CPE, 1), (CPE, 6), (LFE, 2)]
+    cc_tags = [3, 9, 12]                                   # the third is beyond HEAAC_MAX_CCE
+    bw = W.BitWriter()
+    write_pce_body(bw, rng, [(0, 4), (1, 1)], [], [(1, 6)], [2], cc=[(1, 9), (0, 12), (0, 3)])
+    r, l0, _ = pkg.aac_layout_from_pce(bw.bytes(), 0)
+    assert r == 0 and slots(l0) == [(CPE, 1), (LFE, 2), (SCE, 4), (CPE, 6)]
+    assert [int(l0[0]["tag_map"][CCE][t]) for t in cc_tags] == [1, 2, 3] and int(l0[0]["tag_map"][CCE].astype(bool).sum()) == 3
+    want = slots(l0)
+    cfg = TP._cfg(pkg, aot, si, 0)
+    st = np.zeros(pkg.MAX_ELEMENTS, pkg.AAC_STREAM_DT)
+    prev = {}
+    points_seen, linked = set(), 0
+    for frame in range(30):
+        l = l0.copy()
+        present = [t for t in cc_tags[:2] if rng.random() < 0.8]
+        rng.shuffle(present)
+        order = list(range(len(elems)))
+        rng.shuffle(order)
+        # where the coupling elements stand among the output elements
+        at = sorted(int(x) for x in rng.integers(0, len(elems) + 1, len(present)))
+        bw = W.BitWriter()
+        exp_e, exp_c = [], {}
+        k = 0
+        for pos in range(len(elems) + 1):
+            while k < len(present) and at[k] == pos:
+                targets = []
+                for _ in range(int(rng.integers(1, 4))):
+                    t, tag = elems[int(rng.integers(0, 3))] if rng.random() < 0.8 else (int(rng.integers(0, 2)), 15)
+                    targets.append((t, tag, int(rng.integers(0, 4)) if t == CPE else 2))
+                point = int(rng.choice([0, 1, 3]))
+                exp_c[present[k]] = TW.write_cce(bw, rng, si, aot, present[k], targets, point) + (targets, point, pos, k)
+                k += 1
+            if pos < len(elems):
+                typ, tag = elems[order[pos]]
+                ch, sf, cw = write_elem(bw, rng, si, aot, typ, tag)
+                exp_e.append(dict(type=typ, tag=tag, ch=ch, sf=sf, cw=cw, sbr_bit=-1, sbr_bytes=0, sbr_crc=0))
+        bw.put(7, 3)
+        au = bw.bytes()
+        r, got = pkg.aac_parse_frame_layout(cfg, l, st, au, with_cce=True)
+        if r == -3:         # more than MAX_CCE_LINKS lists of one element on one target
+            assert any(len(TW.expected_links(c[4], t == CPE, tag, c[2])) > pkg.MAX_CCE_LINKS for c in exp_c.values() for t, tag in want)
+            continue
+        assert r == 0 and int(got["info"][0]["n_cce"]) == len(present)
+        for seq, (i, e) in enumerate(zip(order, exp_e)):
+            check_slot(got, want.index(elems[i]), e, si, seq)
+        for k, tag in enumerate(cc_tags[:2]):
+            if tag not in exp_c:
+                assert not got["cce"][:, k]["present"].any()
+                continue
+            d, exp_sf, lists, num_gain, targets, point, pos, seq = exp_c[tag]
+            points_seen.add(point)
+            cw = dict(tools=got["cce_tools"][k:k + 1], ics=got["cce_ics"][k:k + 1][None].repeat(2, 1),
+                      coeffs=np.stack([got["cce_coeffs"][k], np.zeros(1024, np.float32)])[None])
+            TP._check_channel(cw, 0, 0, d, exp_sf, si)
+            if tag in prev:
+                assert int(got["cce_ics"][k]["window_sequence"][1]) == prev[tag]["window_sequence"]
+                assert int(got["cce_ics"][k]["use_kb_window"][1]) == prev[tag]["window_shape"]
+            prev[tag] = d
+            for slot, (t, etag) in enumerate(want):
+                rec = got["cce"][slot, k]
+                eseq = order.index(elems.index((t, etag)))
+                assert (rec["present"], rec["elem_id"], rec["coupling_point"], rec["seq"], rec["outputs_before"]) == (1, tag, point, seq, pos)
+                assert int(rec["behind_target"]) == int(pos > eseq)
+                links = TW.expected_links(targets, t == CPE, etag, lists) if t != LFE else []
+                assert int(rec["n_links"]) == len(links)
+                linked += len(links)
+                for n, (tch, gl) in enumerate(links):
+                    assert int(rec["link"][n]["target_ch"]) == tch
+                    assert np.array_equal(rec["link"][n]["gain"].view(np.uint32), gl.view(np.uint32))
+    assert points_seen == {0, 1, 3} and linked > 20
+    # without the coupling records the element is outside the entry; the third coupling element of the layout too;
+    # one the program did not name is not allocated
+    def one(tag, with_cce):
+        bw = W.BitWriter()
+        write_elem(bw, rng, si, aot, SCE, 4)
+        TW.write_cce(bw, rng, si, aot, tag, [(0, 4, 2)], 0)
+        bw.put(7, 3)
+        return pkg.aac_parse_frame_layout(cfg, l0.copy(), st.copy(), bw.bytes(), with_cce=with_cce)[0]
+    assert one(3, True) == 0 and one(3, False) == -3 and one(12, True) == -3 and one(5, True) == -1 and one(5, False) == -1
+    # the same coupling element twice: the second moves up to the next tag (get_che :121-127), which nobody named
+    bw = W.BitWriter()
+    write_elem(bw, rng, si, aot, SCE, 4)
+    TW.write_cce(bw, rng, si, aot, 3, [(0, 4, 2)], 0); TW.write_cce(bw, rng, si, aot, 3, [(0, 4, 2)], 0)
+    bw.put(7, 3)
+    assert pkg.aac_parse_frame_layout(cfg, l0.copy(), st.copy(), bw.bytes(), with_cce=True)[0] == -1
 
 
 def test_audio_specific_config_with_and_without_a_program_config_element(pkg):
