@@ -8,7 +8,13 @@
 //     SBR (explicitly, or implicitly by a payload in the FIRST access unit, :1666-1675) every element goes through
 //     ff_sbr_apply, with a start = 0 record ("pure upsampling") where it has no payload -- an LFE never has one;
 //   * an access unit that leaves an element of the layout out is refused: the reference transforms whatever that
-//     element's buffers still hold from an earlier frame, which no record of this path carries.
+//     element's buffers still hold from an earlier frame, which no record of this path carries;
+//   * coupling channel elements (AAC-LC / Main streams without SBR): those the program config element names
+//     (che_configure allocates no others).  They are individual channel streams of their own -- tools, and an
+//     IMDCT when they couple AFTER_IMDCT -- processed before their targets (spectral_to_sample walks the element
+//     types downwards, :1907); dependent coupling sits around a target's TNS, independent coupling behind its
+//     IMDCT (:1911-1930), coupling elements in ascending tag order (apply_channel_coupling :1876).  One that an
+//     earlier access unit carried and this one leaves out is refused for the same reason as an output element.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
@@ -29,6 +35,23 @@ struct LayElem {
     float *d_f32;                 // [2][2048]
 };
 
+// Host and device side of the coupling elements of one access unit
+struct LayCoupled {
+    HeaacCceFrame h_cce[HEAAC_MAX_ELEMENTS][HEAAC_MAX_CCE];          // per output slot: the gain lists that land there
+    float h_coeffs[HEAAC_MAX_CCE][1024];
+    HeaacIcs h_ics[HEAAC_MAX_CCE];
+    HeaacToolsFrame h_tools[HEAAC_MAX_CCE];
+    HeaacCceFrame *d_cce;         // [n_elements][MAX_CCE]
+    float *d_coeffs;              // [MAX_CCE][1024]
+    HeaacIcs *d_ics;
+    HeaacToolsFrame *d_tools;
+    float *d_state;               // [MAX_CCE][512] overlap of the coupling channels (AFTER_IMDCT elements)
+    HeaacPredictorState *d_pred;  // [MAX_CCE][672]
+    float *d_ret;                 // [MAX_CCE][1024] the coupling channels' own output
+    HeaacCoupling *d_gain;
+    int seen[HEAAC_MAX_CCE];      // an earlier access unit carried this coupling element
+};
+
 struct HeaacLayoutDec {
     HeaacDevice *dev;
     HeaacAacConfig m4ac;
@@ -47,7 +70,43 @@ struct HeaacLayoutDec {
     HeaacIcs h_ics[HEAAC_MAX_ELEMENTS][2];
     HeaacToolsFrame *h_tools;     // [n]
     HeaacAacElementInfo h_elem[HEAAC_MAX_ELEMENTS];
+    LayCoupled *cpl;              // layouts whose program config element names coupling elements
 };
+
+static void coupled_free(LayCoupled *c)
+{
+    if (!c) return;
+    if (c->d_cce) (void)hipFree(c->d_cce);
+    if (c->d_coeffs) (void)hipFree(c->d_coeffs);
+    if (c->d_ics) (void)hipFree(c->d_ics);
+    if (c->d_tools) (void)hipFree(c->d_tools);
+    if (c->d_state) (void)hipFree(c->d_state);
+    if (c->d_pred) (void)hipFree(c->d_pred);
+    if (c->d_ret) (void)hipFree(c->d_ret);
+    if (c->d_gain) (void)hipFree(c->d_gain);
+    free(c);
+}
+
+static LayCoupled *coupled_alloc(const HeaacPredictorState *ps_reset)
+{
+    LayCoupled *c = (LayCoupled *)calloc(1, sizeof(*c));
+    if (!c) return NULL;
+    bool ok =
+        hipMalloc((void **)&c->d_cce, sizeof(c->h_cce)) == hipSuccess &&
+        hipMalloc((void **)&c->d_coeffs, sizeof(c->h_coeffs)) == hipSuccess &&
+        hipMalloc((void **)&c->d_ics, sizeof(c->h_ics)) == hipSuccess &&
+        hipMalloc((void **)&c->d_tools, sizeof(c->h_tools)) == hipSuccess &&
+        hipMalloc((void **)&c->d_state, HEAAC_MAX_CCE * 512 * 4) == hipSuccess &&
+        hipMalloc((void **)&c->d_pred, HEAAC_MAX_CCE * HEAAC_MAX_PREDICTORS * sizeof(*ps_reset)) == hipSuccess &&
+        hipMalloc((void **)&c->d_ret, HEAAC_MAX_CCE * 1024 * 4) == hipSuccess &&
+        hipMalloc((void **)&c->d_gain, sizeof(HeaacCoupling)) == hipSuccess &&
+        hipMemset(c->d_state, 0, HEAAC_MAX_CCE * 512 * 4) == hipSuccess;
+    for (int k = 0; ok && k < HEAAC_MAX_CCE; k++)
+        ok = hipMemcpy(c->d_pred + k * HEAAC_MAX_PREDICTORS, ps_reset, HEAAC_MAX_PREDICTORS * sizeof(*ps_reset),
+                       hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { coupled_free(c); return NULL; }
+    return c;
+}
 
 void heaac_layout_dec_destroy(HeaacLayoutDec *d)
 {
@@ -65,6 +124,7 @@ void heaac_layout_dec_destroy(HeaacLayoutDec *d)
     if (d->d_hdr) (void)hipFree(d->d_hdr);
     if (d->d_rng) (void)hipFree(d->d_rng);
     if (d->d_pcm) (void)hipFree(d->d_pcm);
+    coupled_free(d->cpl);
     heaac_sbr_table_destroy(d->tab);
     free(d->h_coeffs);
     free(d->h_tools);
@@ -104,6 +164,8 @@ HeaacLayoutDec *heaac_layout_dec_create(HeaacDevice *dev, const HeaacAacConfig *
              hipMemset(e.d_state, 0, HEAAC_STATE_WORDS_HEV1 * 4) == hipSuccess &&
              hipMemcpy(e.d_pred, ps, 2 * HEAAC_MAX_PREDICTORS * sizeof(*ps), hipMemcpyHostToDevice) == hipSuccess;
     }
+    for (int id = 0; ok && id < 16; id++)
+        if (layout->slot_of[HEAAC_ELEM_CCE][id] && !d->cpl) ok = (d->cpl = coupled_alloc(ps)) != NULL;
     free(ps);
     const int32_t seed = 0x1f2e3d4c;                                   // ac->random_state, aacdec.c:558
     for (int i = 0; i < LAY_MAX_HDRS; i++) d->hdr[i].kx = 32;          // kx' = 32, m = 0 (aacsbr.c:130)
@@ -124,12 +186,32 @@ int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void
     // the parser works on copies of the window histories until the whole unit has parsed
     HeaacAacStream st[HEAAC_MAX_ELEMENTS];
     for (int i = 0; i < d->n; i++) st[i] = d->e[i].ast;
-    if (heaac_aac_parse_frame_layout(&d->m4ac, &d->layout, st, buf, size, d->h_coeffs, &d->h_ics[0][0], d->h_tools,
-                                     d->h_elem, &fi) != HEAAC_PARSE_OK)
+    LayCoupled *c = d->cpl;
+    HeaacCceOut co = { NULL, NULL, NULL, NULL };
+    if (c) { co.cce = &c->h_cce[0][0]; co.coeffs = &c->h_coeffs[0][0]; co.ics = c->h_ics; co.tools = c->h_tools; }
+    if (heaac_aac_parse_frame_layout_ex(&d->m4ac, &d->layout, st, buf, size, d->h_coeffs, &d->h_ics[0][0], d->h_tools,
+                                        d->h_elem, c ? &co : NULL, &fi) != HEAAC_PARSE_OK)
         return -1;
     for (int i = 0; i < d->n; i++)
         if (!d->h_elem[i].present) return -1;
+    // the coupling elements of this access unit: slot k of the layout's list, the same in every output slot's row
+    int cce_here[HEAAC_MAX_CCE] = { 0 }, n_cce = 0;
+    for (int k = 0; c && k < HEAAC_MAX_CCE; k++) {
+        cce_here[k] = c->h_cce[0][k].present;
+        n_cce += cce_here[k];
+        if (c->seen[k] && !cce_here[k]) return -1;
+    }
+    if (n_cce) {
+        // coupling together with SBR (apply_independent_coupling over 1024 << sbr samples) is outside this path
+        int sbr = d->m4ac.sbr;
+        if (!d->locked && sbr == -1)
+            for (int i = 0; i < d->n; i++)
+                if (d->h_elem[i].sbr_payload_bit >= 0) sbr = 1;
+        if (sbr == 1) return -1;
+    }
     for (int i = 0; i < d->n; i++) d->e[i].ast = st[i];
+    for (int k = 0; k < HEAAC_MAX_CCE; k++)
+        if (cce_here[k]) c->seen[k] = 1;
     if (!d->locked) {
         // implicit SBR counts only when the first access unit carries it (aacdec.c:1666-1675)
         if (d->m4ac.sbr == -1) {
@@ -150,14 +232,52 @@ int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void
             hipMemcpy(e.d_tools, &d->h_tools[i], sizeof(HeaacToolsFrame), hipMemcpyHostToDevice) != hipSuccess)
             return -1;
     }
-    for (int seq = 0; seq < d->n; seq++)
+    if (n_cce &&
+        (hipMemcpy(c->d_cce, c->h_cce, (size_t)d->n * HEAAC_MAX_CCE * sizeof(HeaacCceFrame), hipMemcpyHostToDevice) != hipSuccess ||
+         hipMemcpy(c->d_coeffs, c->h_coeffs, sizeof(c->h_coeffs), hipMemcpyHostToDevice) != hipSuccess ||
+         hipMemcpy(c->d_ics, c->h_ics, sizeof(c->h_ics), hipMemcpyHostToDevice) != hipSuccess ||
+         hipMemcpy(c->d_tools, c->h_tools, sizeof(c->h_tools), hipMemcpyHostToDevice) != hipSuccess))
+        return -1;
+    // A coupling element's tools as a whole at its place in the stream (nothing couples INTO it); an output element's
+    // first half there, its second half -- coupling, TNS, coupling -- once every coupling element is through.
+    auto cce_tools = [&](int outputs_before) -> int {
+        for (int seq = 0; seq < n_cce; seq++)
+            for (int k = 0; k < HEAAC_MAX_CCE; k++) {
+                const HeaacCceFrame &r = c->h_cce[0][k];
+                if (!r.present || r.seq != seq || r.outputs_before != outputs_before) continue;
+                HeaacPredictorState *pr = main_profile ? c->d_pred + k * HEAAC_MAX_PREDICTORS : NULL;
+                if (heaac_spectral_tools_batch_ex(d->dev, 1, HEAAC_TOOLS_ALL, c->d_coeffs + k * 1024, c->d_tools + k,
+                                                  d->d_rng, d->d_rng, pr, pr, NULL, NULL, 0, 1, NULL) != HEAAC_OK)
+                    return -1;
+            }
+        return 0;
+    };
+    for (int seq = 0; seq < d->n; seq++) {
+        if (n_cce && cce_tools(seq)) return -1;
         for (int i = 0; i < d->n; i++) {
             if (d->h_elem[i].seq != seq) continue;
             LayElem &e = d->e[i];
             HeaacPredictorState *pr = main_profile ? e.d_pred : NULL;
-            if (heaac_spectral_tools_batch(d->dev, e.channels, e.d_coeffs, e.d_tools, d->d_rng, d->d_rng, pr, pr, 1, NULL) != HEAAC_OK)
+            if (heaac_spectral_tools_batch_ex(d->dev, e.channels, n_cce ? HEAAC_TOOLS_PRE : HEAAC_TOOLS_ALL, e.d_coeffs, e.d_tools,
+                                              d->d_rng, d->d_rng, pr, pr, NULL, NULL, 0, 1, NULL) != HEAAC_OK)
                 return -1;
         }
+    }
+    if (n_cce) {
+        if (cce_tools(d->n)) return -1;
+        for (int i = 0; i < d->n; i++) {
+            LayElem &e = d->e[i];
+            if (heaac_spectral_tools_batch_ex(d->dev, e.channels, HEAAC_TOOLS_POST, e.d_coeffs, e.d_tools, NULL, NULL, NULL, NULL,
+                                              c->d_cce + (size_t)i * HEAAC_MAX_CCE, c->d_coeffs, HEAAC_MAX_CCE, 1, NULL) != HEAAC_OK)
+                return -1;
+        }
+        // the coupling channels that couple behind the IMDCT: their own IMDCT first (type 2 before types 1 and 0)
+        for (int k = 0; k < HEAAC_MAX_CCE; k++)
+            if (cce_here[k] && c->h_cce[0][k].coupling_point == HEAAC_CC_AFTER_IMDCT &&
+                heaac_lc_decode_batch(d->dev, 1, c->d_coeffs + k * 1024, c->d_ics + k, c->d_state + k * 512, c->d_state + k * 512,
+                                      c->d_ret + k * 1024, HEAAC_PCM_F32_PLANAR, 1, NULL) != HEAAC_OK)
+                return -1;
+    }
     HeaacPlaneRef planes[HEAAC_MAX_PCM_PLANES];
     for (int i = 0; i < d->n; i++) {
         LayElem &e = d->e[i];
@@ -165,6 +285,20 @@ int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void
         if (!he) {
             rc = heaac_lc_decode_batch(d->dev, e.channels, e.d_coeffs, e.d_ics, e.d_state, e.d_state, e.d_f32,
                                        HEAAC_PCM_F32_PLANAR, 1, NULL);
+            // every AFTER_IMDCT element in tag order, every gain list it lands on this element (apply_channel_coupling)
+            for (int k = 0; rc == HEAAC_OK && k < HEAAC_MAX_CCE; k++) {
+                if (!cce_here[k] || c->h_cce[i][k].coupling_point != HEAAC_CC_AFTER_IMDCT) continue;
+                for (int l = 0; l < c->h_cce[i][k].n_links; l++) {
+                    HeaacCoupling g;
+                    memset(&g, 0, sizeof(g));
+                    const int t = c->h_cce[i][k].link[l].target_ch;
+                    g.on[t] = 1;
+                    g.gain[t] = c->h_cce[i][k].link[l].gain[0];
+                    if (hipMemcpy(c->d_gain, &g, sizeof(g), hipMemcpyHostToDevice) != hipSuccess) return -1;
+                    if (heaac_couple_after_imdct_batch(d->dev, e.channels, e.d_f32, c->d_ret + k * 1024, c->d_gain, NULL, 1, NULL) != HEAAC_OK)
+                        return -1;
+                }
+            }
         } else {
             HeaacSbrFrame sbr;
             const HeaacAacElementInfo &ei = d->h_elem[i];

@@ -327,30 +327,11 @@ typedef struct HeaacDecoderPriv {
     HeaacPredictorState *d_pred;
     float *h_coeffs;
     HeaacToolsFrame *h_tools;
-    // access units with coupling channel elements (AAC-LC / Main): allocated by the first one
-    struct HeaacCoupled *cpl;
     // streams with several output elements per access unit (channel configurations 3..7, program config elements)
     int have_layout;
     HeaacAacLayout layout;
     struct HeaacLayoutDec *lay;
 } HeaacDecoderPriv;
-
-// Host and device side of the coupling elements of one access unit (dec_frame_coupled)
-struct HeaacCoupled {
-    HeaacCceFrame h_cce[HEAAC_MAX_CCE];
-    float h_coeffs[HEAAC_MAX_CCE][1024];
-    HeaacIcs h_ics[HEAAC_MAX_CCE];
-    HeaacToolsFrame h_tools[HEAAC_MAX_CCE];
-    HeaacCceFrame *d_cce;
-    float *d_coeffs;              // [MAX_CCE][1024]
-    HeaacIcs *d_ics;
-    HeaacToolsFrame *d_tools;
-    float *d_state;               // [MAX_CCE][512] overlap of the coupling channels (AFTER_IMDCT elements)
-    HeaacPredictorState *d_pred;  // [MAX_CCE][672]
-    float *d_ret;                 // [1024] a coupling channel's own output
-    float *d_f32;                 // [2][1024] the target's float output while coupling is added
-    HeaacCoupling *d_gain;
-};
 
 static void set_cfg(HeaacDecoderPriv *p, int cfg)
 {
@@ -434,9 +415,6 @@ static int dec_init_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p)
     return 0;
 }
 
-static int dec_frame_coupled(HeaacCodecContext *avctx, HeaacDecoderPriv *p, void *data, int *data_size,
-                             const uint8_t *buf, int size);
-
 static int dec_frame_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p, void *data, int *data_size,
                                HeaacPacket *avpkt)
 {
@@ -490,8 +468,10 @@ static int dec_frame_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p, vo
     memset(ics, 0, sizeof(ics));
     const int r = heaac_heaac_parse_frame(&p->m4ac, &p->ast, &p->sst, p->tab, buf, size, p->h_coeffs, ics, p->h_tools,
                                           &sbr, &ps, &fi);
-    if (r == HEAAC_PARSE_ERR_UNSUPPORTED)              // outside the one-element slice: coupling channel elements?
-        return dec_frame_coupled(avctx, p, data, data_size, buf, size);
+    // A coupling channel element lands here too: in a channel configuration 1 / 2 stream get_che has no place for it
+    // ("channel element 2.%d is not allocated", aacdec.c:132-177, :2006-2010) -- only a program config element
+    // allocates coupling elements, and those streams take the layout path above.
+    if (r == HEAAC_PARSE_ERR_UNSUPPORTED) return -1;
     if (r == HEAAC_PARSE_ERR_ARG) return -1;
     if (r < 0 && fi.channels == 0) return -1;          // the core element failed (aacdec.c:2046-2049)
     if (fi.channels != p->m4ac.chan_config) return -1;
@@ -546,141 +526,6 @@ static int dec_frame_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p, vo
     return size > off ? consumed : size;
 }
 
-static void coupled_free(HeaacCoupled *c)
-{
-    if (!c) return;
-    if (c->d_cce) (void)hipFree(c->d_cce);
-    if (c->d_coeffs) (void)hipFree(c->d_coeffs);
-    if (c->d_ics) (void)hipFree(c->d_ics);
-    if (c->d_tools) (void)hipFree(c->d_tools);
-    if (c->d_state) (void)hipFree(c->d_state);
-    if (c->d_pred) (void)hipFree(c->d_pred);
-    if (c->d_ret) (void)hipFree(c->d_ret);
-    if (c->d_f32) (void)hipFree(c->d_f32);
-    if (c->d_gain) (void)hipFree(c->d_gain);
-    free(c);
-}
-
-static HeaacCoupled *coupled_alloc(void)
-{
-    HeaacCoupled *c = (HeaacCoupled *)calloc(1, sizeof(*c));
-    if (!c) return NULL;
-    HeaacPredictorState *ps = (HeaacPredictorState *)calloc(HEAAC_MAX_CCE * HEAAC_MAX_PREDICTORS, sizeof(*ps));
-    bool ok = ps != NULL &&
-        hipMalloc((void **)&c->d_cce, sizeof(c->h_cce)) == hipSuccess &&
-        hipMalloc((void **)&c->d_coeffs, sizeof(c->h_coeffs)) == hipSuccess &&
-        hipMalloc((void **)&c->d_ics, sizeof(c->h_ics)) == hipSuccess &&
-        hipMalloc((void **)&c->d_tools, sizeof(c->h_tools)) == hipSuccess &&
-        hipMalloc((void **)&c->d_state, HEAAC_MAX_CCE * 512 * 4) == hipSuccess &&
-        hipMalloc((void **)&c->d_pred, HEAAC_MAX_CCE * HEAAC_MAX_PREDICTORS * sizeof(*ps)) == hipSuccess &&
-        hipMalloc((void **)&c->d_ret, 1024 * 4) == hipSuccess &&
-        hipMalloc((void **)&c->d_f32, 2 * 1024 * 4) == hipSuccess &&
-        hipMalloc((void **)&c->d_gain, sizeof(HeaacCoupling)) == hipSuccess &&
-        hipMemset(c->d_state, 0, HEAAC_MAX_CCE * 512 * 4) == hipSuccess;
-    if (ok) {
-        for (int i = 0; i < HEAAC_MAX_CCE * HEAAC_MAX_PREDICTORS; i++) ps[i].var0 = ps[i].var1 = 1.0f;
-        ok = hipMemcpy(c->d_pred, ps, HEAAC_MAX_CCE * HEAAC_MAX_PREDICTORS * sizeof(*ps), hipMemcpyHostToDevice) == hipSuccess;
-    }
-    free(ps);
-    if (!ok) { coupled_free(c); return NULL; }
-    return c;
-}
-
-// An AAC-LC / Main access unit that carries coupling channel elements (aac_decode_frame's element loop with
-// TYPE_CCE, then spectral_to_sample, aacdec.c:1903-1933): the coupling channels are individual channel streams of
-// their own (tools, and an IMDCT when they couple AFTER_IMDCT); the noise generator runs over the elements in
-// bitstream order; dependent coupling sits around the target's TNS, independent coupling behind its IMDCT.
-static int dec_frame_coupled(HeaacCodecContext *avctx, HeaacDecoderPriv *p, void *data, int *data_size,
-                             const uint8_t *buf, int size)
-{
-    if (p->configured && p->out_len != 1024) return -1;               // SBR streams: not with coupling in this slice
-    if (!p->cpl && !(p->cpl = coupled_alloc())) return -1;
-    HeaacCoupled *c = p->cpl;
-    HeaacIcs ics[2];
-    HeaacAacFrameInfo fi;
-    memset(ics, 0, sizeof(ics));
-    const HeaacCceOut co = { c->h_cce, &c->h_coeffs[0][0], c->h_ics, c->h_tools };
-    if (heaac_aac_parse_frame_ex(&p->m4ac, &p->ast, buf, size, 2, p->h_coeffs, ics, p->h_tools, &co, &fi) != HEAAC_PARSE_OK)
-        return -1;
-    if (fi.channels != p->m4ac.chan_config) return -1;
-    if (!p->configured) {
-        if (p->m4ac.sbr == -1) p->m4ac.sbr = 0;                        // no SBR payload was looked at: plain AAC
-        if (p->m4ac.sbr == 1) return -1;
-        set_cfg(p, fi.channels == 2 ? HEAAC_CFG_LC_STEREO : HEAAC_CFG_LC_MONO);
-        publish_cfg(avctx, p);
-        p->configured = 1;
-    }
-    const int ch = fi.channels, n_cce = fi.n_cce;
-    uint8_t *d_ics = p->d_side;
-    if (hipMemcpy(p->d_coeffs, p->h_coeffs, (size_t)ch * 4096, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(d_ics, ics, sizeof(ics), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(p->d_tools, p->h_tools, sizeof(HeaacToolsFrame), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(c->d_cce, c->h_cce, sizeof(c->h_cce), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(c->d_coeffs, c->h_coeffs, sizeof(c->h_coeffs), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(c->d_ics, c->h_ics, sizeof(c->h_ics), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(c->d_tools, c->h_tools, sizeof(c->h_tools), hipMemcpyHostToDevice) != hipSuccess)
-        return -1;
-    const int main_profile = p->m4ac.object_type == HEAAC_AOT_AAC_MAIN;
-    // the elements' own tools in bitstream order (one generator state runs through them)
-    auto cce_tools = [&](int behind) -> int {
-        for (int seq = 0; seq < n_cce; seq++)
-            for (int s = 0; s < n_cce; s++) {
-                if (c->h_cce[s].seq != seq || c->h_cce[s].behind_target != behind) continue;
-                HeaacPredictorState *pr = main_profile ? c->d_pred + s * HEAAC_MAX_PREDICTORS : NULL;
-                if (heaac_spectral_tools_batch_ex(p->dev, 1, HEAAC_TOOLS_ALL, c->d_coeffs + s * 1024, c->d_tools + s,
-                                                  p->d_rng, p->d_rng, pr, pr, NULL, NULL, 0, 1, NULL) != HEAAC_OK)
-                    return -1;
-            }
-        return 0;
-    };
-    HeaacPredictorState *pr = main_profile ? p->d_pred : NULL;
-    if (cce_tools(0)) return -1;
-    if (heaac_spectral_tools_batch_ex(p->dev, ch, HEAAC_TOOLS_PRE, p->d_coeffs, p->d_tools, p->d_rng, p->d_rng, pr, pr,
-                                      NULL, NULL, 0, 1, NULL) != HEAAC_OK) return -1;
-    if (cce_tools(1)) return -1;
-    if (heaac_spectral_tools_batch_ex(p->dev, ch, HEAAC_TOOLS_POST, p->d_coeffs, p->d_tools, NULL, NULL, NULL, NULL,
-                                      c->d_cce, c->d_coeffs, HEAAC_MAX_CCE, 1, NULL) != HEAAC_OK) return -1;
-    int after = 0;
-    for (int s = 0; s < n_cce; s++) after += c->h_cce[s].coupling_point == HEAAC_CC_AFTER_IMDCT;
-    if (!after) {
-        if (heaac_lc_decode_batch(p->dev, ch, p->d_coeffs, (const HeaacIcs *)d_ics, p->d_state, p->d_state, p->d_pcm,
-                                  HEAAC_PCM_S16_INTERLEAVED, 1, NULL) != HEAAC_OK) return -1;
-    } else {
-        if (heaac_lc_decode_batch(p->dev, ch, p->d_coeffs, (const HeaacIcs *)d_ics, p->d_state, p->d_state, c->d_f32,
-                                  HEAAC_PCM_F32_PLANAR, 1, NULL) != HEAAC_OK) return -1;
-        // every AFTER_IMDCT element in tag order, every gain list it lands on the target (apply_channel_coupling)
-        int calls = 0, total = 0;
-        for (int s = 0; s < n_cce; s++)
-            if (c->h_cce[s].coupling_point == HEAAC_CC_AFTER_IMDCT) total += c->h_cce[s].n_links ? c->h_cce[s].n_links : 1;
-        for (int s = 0; s < n_cce; s++) {
-            if (c->h_cce[s].coupling_point != HEAAC_CC_AFTER_IMDCT) continue;
-            if (heaac_lc_decode_batch(p->dev, 1, c->d_coeffs + s * 1024, c->d_ics + s, c->d_state + s * 512,
-                                      c->d_state + s * 512, c->d_ret, HEAAC_PCM_F32_PLANAR, 1, NULL) != HEAAC_OK) return -1;
-            const int nl = c->h_cce[s].n_links ? c->h_cce[s].n_links : 1;
-            for (int l = 0; l < nl; l++) {
-                HeaacCoupling g;
-                memset(&g, 0, sizeof(g));
-                if (l < c->h_cce[s].n_links) {
-                    const int t = c->h_cce[s].link[l].target_ch;
-                    g.on[t] = 1;
-                    g.gain[t] = c->h_cce[s].link[l].gain[0];
-                }
-                calls++;
-                if (hipMemcpy(c->d_gain, &g, sizeof(g), hipMemcpyHostToDevice) != hipSuccess) return -1;
-                if (heaac_couple_after_imdct_batch(p->dev, ch, c->d_f32, c->d_ret, c->d_gain,
-                                                   calls == total ? p->d_pcm : NULL, 1, NULL) != HEAAC_OK) return -1;
-            }
-        }
-    }
-    const int bytes = p->out_len * p->nout * 2;
-    if (hipMemcpy(data, p->d_pcm, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    *data_size = bytes;
-    const int consumed = (fi.bits_consumed + 7) >> 3;
-    int off = consumed;
-    while (off < size && !buf[off]) off++;
-    return size > off ? consumed : size;
-}
-
 static int dec_init(HeaacCodecContext *avctx)
 {
     HeaacDecoderPriv *p = (HeaacDecoderPriv *)avctx->priv_data;
@@ -719,7 +564,6 @@ static int dec_close(HeaacCodecContext *avctx)
     if (p->d_rng) (void)hipFree(p->d_rng);
     if (p->d_pred) (void)hipFree(p->d_pred);
     heaac_sbr_table_destroy(p->tab);
-    coupled_free(p->cpl);
     heaac_layout_dec_destroy(p->lay);
     free(p->h_coeffs);
     free(p->h_tools);

@@ -5,7 +5,9 @@
  * of seed access units (u32 kind, u32 length, bytes; kind 0 = AAC-LC CPE 48 kHz, 1 = HE-AACv1 CPE 24 kHz,
  * 2 = HE-AACv2 SCE 24 kHz, 3 = AAC-LC CPE 48 kHz with coupling / program config elements, 4 = the same around an SCE:
  * kinds 3 and 4 go through heaac_aac_parse_frame_ex; 5 = a 5.1 access unit (SCE CPE CPE LFE, some with SBR payloads) through
- * heaac_aac_parse_frame_layout, its bytes also read as a program config element at a random bit offset).  Every 16th iteration instead walks a buffer of seeds behind ADTS
+ * heaac_aac_parse_frame_layout, its bytes also read as a program config element at a random bit offset; 6 = an access
+ * unit of a program-config 5.1 stream with coupling channel elements through heaac_aac_parse_frame_layout_ex, its
+ * layout from the AudioSpecificConfig in the one seed of kind 7).  Every 16th iteration instead walks a buffer of seeds behind ADTS
  * headers, mutated the same ways, through heaac_adts_split and checks that the packets tile it.  Each iteration mutates a seed (bit flips, byte noise, truncation, splice of two
  * seeds, pure noise), parses it on a stream that keeps its state across iterations, and checks what the parser
  * promises: whatever the status, the records it wrote pass validate.h.
@@ -29,15 +31,25 @@ int main(int argc, char **argv)
     if (!f) return 2;
     Seed seed[256];
     int ns = 0;
+    HeaacAacConfig ccfg;
+    HeaacAacLayout clay0, clay;
+    int have_clay = 0;
     while (ns < 256) {
         uint32_t h[2];
         if (fread(h, 4, 2, f) != 2) break;
         seed[ns].kind = h[0]; seed[ns].len = h[1];
         seed[ns].data = malloc(h[1] ? h[1] : 1);
         if (fread(seed[ns].data, 1, h[1], f) != h[1]) return 2;
+        if (h[0] == 7) {                                   /* not an access unit: the coupled stream's configuration */
+            if (heaac_asc_layout(&ccfg, &clay0, seed[ns].data, (int)h[1]) != 0) return 2;
+            have_clay = 1;
+            free(seed[ns].data);
+            continue;
+        }
         ns++;
     }
     fclose(f);
+    clay = clay0;
     if (!ns) return 2;
     const long iters = atol(argv[2]);
     HeaacAacConfig cfg[3];
@@ -75,7 +87,11 @@ int main(int argc, char **argv)
     HeaacIcs lics[HEAAC_MAX_ELEMENTS][2];
     HeaacToolsFrame *ltools = malloc(HEAAC_MAX_ELEMENTS * sizeof(*ltools));
     HeaacAacElementInfo lelem[HEAAC_MAX_ELEMENTS];
-    long layouts_ok = 0, layout_units = 0, layout_bad = 0;
+    long layouts_ok = 0, layout_units = 0, layout_bad = 0, coupled_units = 0, coupled_links = 0;
+    HeaacCceFrame *lcce = malloc(HEAAC_MAX_ELEMENTS * HEAAC_MAX_CCE * sizeof(*lcce));
+    const HeaacCceOut lco = { lcce, cce_coeffs, cce_ics, cce_tools };
+    HeaacAacStream cst[HEAAC_MAX_ELEMENTS];
+    memset(cst, 0, sizeof(cst));
     for (long it = 0; it < iters; it++) {
         const Seed *s = &seed[rnd() % ns];
         const int k = (int)s->kind;
@@ -116,6 +132,37 @@ int main(int argc, char **argv)
             if (np < 0 || (np <= 64 && at != total)) adts_bad++;
             (void)heaac_adts_probe(buf, total);
             free(buf); free(au);
+            continue;
+        }
+        if (k == 6) {
+            if (!have_clay) return 2;
+            memset(&info, 0, sizeof(info));
+            const int r = heaac_aac_parse_frame_layout_ex(&ccfg, &clay, cst, au, (int)len, lcoeffs, &lics[0][0], ltools, lelem,
+                                                          (rnd() & 7) ? &lco : NULL, &info);
+            free(au);
+            if (r >= 0) ok++; else err++;
+            if (r == HEAAC_PARSE_OK && info.n_cce) {
+                coupled_units++;
+                /* every output slot's row holds the same coupling elements, each with its own links */
+                for (int c2 = 0; c2 < HEAAC_MAX_CCE; c2++) {
+                    int v = 0;
+                    for (int e = 0; e < clay.n_elements; e++) {
+                        const HeaacCceFrame *c = &lcce[e * HEAAC_MAX_CCE + c2];
+                        v |= c->present != lcce[c2].present;
+                        if (!c->present) continue;
+                        v |= c->n_links > HEAAC_MAX_CCE_LINKS || (c->coupling_point != 0 && c->coupling_point != 1 && c->coupling_point != 3) ||
+                             c->ics.num_window_groups < 1 || c->ics.num_window_groups > 8 || c->ics.max_sfb > c->ics.num_swb ||
+                             c->ics.num_window_groups * c->ics.max_sfb > 120 || c->seq >= HEAAC_MAX_CCE ||
+                             c->outputs_before > clay.n_elements || c->elem_id > 15 || c->seq != lcce[c2].seq ||
+                             clay.tag_map[HEAAC_ELEM_CCE][c->elem_id] != c2 + 1;
+                        v |= clay.elem[e].type == HEAAC_ELEM_LFE && c->n_links;
+                        for (int l = 0; l < c->n_links && l < HEAAC_MAX_CCE_LINKS; l++) v |= c->link[l].target_ch >= clay.elem[e].channels;
+                        coupled_links += c->n_links;
+                    }
+                    if (v) { layout_bad++; if (layout_bad < 5) printf("iteration %ld: coupling record of a layout out of range\n", it); }
+                }
+            }
+            if (it % 1024 == 1023) { clay = clay0; memset(cst, 0, sizeof(cst)); }
             continue;
         }
         if (k == 5) {
@@ -201,8 +248,9 @@ int main(int argc, char **argv)
            iters, ok, err, started, heaac_sbr_table_count(tab), bad_records);
     printf("coupling elements parsed %ld, ADTS frames delivered %ld, ADTS walks that did not tile %ld\n", coupled, adts_frames, adts_bad);
     printf("5.1 units parsed %ld, program config layouts accepted %ld, out of range %ld\n", layout_units, layouts_ok, layout_bad);
+    printf("coupled layout units parsed %ld, gain lists landed %ld\n", coupled_units, coupled_links);
     if (adts_bad || layout_bad) return 1;
-    free(lcoeffs); free(ltools);
+    free(lcoeffs); free(ltools); free(lcce);
     free(cce); free(cce_coeffs); free(cce_tools);
     heaac_sbr_table_destroy(tab);
     free(sst); free(coeffs); free(tools);

@@ -1,0 +1,129 @@
+"""Checker for streams whose program config element names coupling channel elements (test infrastructure): the
+layout parser's records (pinned by tests/test_parse_layout.py) through the ORACLE the way aac_decode_frame +
+spectral_to_sample order the work (aacdec.c:1999-2075, :1903-1933) -- every element's noise substitution /
+prediction / stereo tools where it stands in the access unit (one noise generator), the coupling elements' TNS and
+IMDCT before their targets', dependent coupling around a target's TNS, independent coupling behind its IMDCT, in
+ascending tag order of the coupling elements, then ff_float_to_int16_interleave_c over the output planes.
+Also writes such streams with the test bit writers."""
+import numpy as np
+
+import aac_bitwriter as W
+import test_parse as TP
+import test_parse_layout as TL
+import test_parse_wide as TW
+
+SCE, CPE, CCE, LFE = 0, 1, 2, 3
+
+
+def pce_args(elems, cc_tags):
+    front = [(int(t == CPE), g) for t, g in elems if t in (SCE, CPE)]
+    return front, [], [], [g for t, g in elems if t == LFE], [(int(k & 1), g) for k, g in enumerate(cc_tags)]
+
+
+def asc(aot, si, elems, cc_tags, rng):
+    """AudioSpecificConfig with channel configuration 0 and the program config element inside."""
+    bw = W.BitWriter()
+    bw.put(aot, 5); bw.put(si, 4); bw.put(0, 4)
+    bw.put(0, 3)                                           # GASpecificConfig: 1024 samples, no core coder, no extension
+    bw.put(0, 4)                                           # element_instance_tag
+    a = pce_args(elems, cc_tags)
+    TL.write_pce_body(bw, rng, *a[:4], cc=a[4])
+    return bw.bytes()
+
+
+def write_unit(rng, si, aot, elems, tags, points, quiet=False):
+    """One access unit: the output elements in a random order, the coupling elements `tags` anywhere between them."""
+    order = list(range(len(elems)))
+    rng.shuffle(order)
+    at = sorted(int(x) for x in rng.integers(0, len(elems) + 1, len(tags)))
+    real = [e for e in elems if e[0] != LFE]
+    bw = W.BitWriter()
+    k = 0
+    for pos in range(len(elems) + 1):
+        while k < len(tags) and at[k] == pos:
+            targets = []
+            for _ in range(int(rng.integers(1, 3))):
+                t, g = real[int(rng.integers(0, len(real)))]
+                targets.append((t, g, int(rng.integers(0, 4)) if t == CPE else 2))
+            if rng.random() < 0.3:
+                targets.insert(int(rng.integers(0, 2)), (int(rng.integers(0, 2)), 14, 3))       # nobody's
+            TW.write_cce(bw, rng, si, aot, tags[k], targets, int(rng.choice(points)), quiet=quiet)
+            k += 1
+        if pos < len(elems):
+            TL.write_elem(bw, rng, si, aot, *elems[order[pos]], quiet=quiet)
+    bw.put(7, 3)
+    return bw.bytes()
+
+
+class Checker:
+    def __init__(self, pkg, oracle, m4, layout, aot):
+        self.pkg, self.oracle, self.m4, self.layout, self.aot = pkg, oracle, m4, layout, aot
+        self.ne, self.nch = int(layout[0]["n_elements"]), int(layout[0]["channels"])
+        self.slot_ch = [int(layout[0]["elem"][e]["channels"]) for e in range(self.ne)]
+        self.st = np.zeros(pkg.MAX_ELEMENTS, pkg.AAC_STREAM_DT)
+        self.state = [np.zeros((1, 512 * c), np.float32) for c in self.slot_ch]
+        fresh = lambda c: np.tile(np.array([0, 0, 1, 1, 0, 0], np.float32), (1, c * pkg.MAX_PREDICTORS, 1)).reshape(1, -1)
+        self.pred = [fresh(c) for c in self.slot_ch]
+        self.cpred = [fresh(1) for _ in range(pkg.MAX_CCE)]
+        self.cstate = [np.zeros((1, 512), np.float32) for _ in range(pkg.MAX_CCE)]
+        self.rng = np.full(1, 0x1f2e3d4c, np.int32)
+        self.dependent = self.independent = 0              # gain lists applied so far
+
+    def parses(self, au):
+        return self.pkg.aac_parse_frame_layout(self.m4, self.layout.copy(), self.st.copy(), au, with_cce=True)[0] == 0
+
+    def frame(self, au):
+        """Returns (int16 [1024][channels], the parsed records)."""
+        pkg, oracle, ne, main = self.pkg, self.oracle, self.ne, self.aot == 1
+        r, g = pkg.aac_parse_frame_layout(self.m4, self.layout, self.st, au, with_cce=True)
+        assert r == 0, r
+        cc = g["cce_coeffs"][None].copy()
+
+        def cce_tools(before):
+            for seq in range(pkg.MAX_CCE):
+                for k in range(pkg.MAX_CCE):
+                    rec = g["cce"][0, k]
+                    if rec["present"] and rec["seq"] == seq and rec["outputs_before"] == before:
+                        c1, self.rng, pr = oracle.spectral_tools_batch_ex(1, oracle.TOOLS_ALL, cc[:, k:k + 1], g["cce_tools"][k:k + 1],
+                                                                          rng=self.rng, pred=self.cpred[k] if main else None)
+                        cc[:, k] = c1[:, 0]
+                        if main:
+                            self.cpred[k] = pr
+        pre = [None] * ne
+        for seq in range(ne):
+            cce_tools(seq)
+            e = [i for i in range(ne) if int(g["elem"][i]["seq"]) == seq][0]
+            c = self.slot_ch[e]
+            pre[e], self.rng, pr = oracle.spectral_tools_batch_ex(c, oracle.TOOLS_PRE, np.ascontiguousarray(g["coeffs"][e:e + 1, :c]),
+                                                                  g["tools"][e:e + 1], rng=self.rng, pred=self.pred[e] if main else None)
+            if main:
+                self.pred[e] = pr
+        cce_tools(ne)
+        rets = {}
+        for k in range(pkg.MAX_CCE):
+            if g["cce"][0, k]["present"] and g["cce"][0, k]["coupling_point"] == 3:
+                rets[k], self.cstate[k] = oracle.lc_decode_batch(1, cc[:, k:k + 1], g["cce_ics"][k:k + 1][None], self.cstate[k],
+                                                                 oracle.PCM_F32)
+        planes = [None] * self.nch
+        for e in range(ne):
+            c = self.slot_ch[e]
+            post, _, _ = oracle.spectral_tools_batch_ex(c, oracle.TOOLS_POST, pre[e], g["tools"][e:e + 1], cce=g["cce"][e][None],
+                                                        cce_coeffs=cc)
+            f32, self.state[e] = oracle.lc_decode_batch(c, post, np.ascontiguousarray(g["ics"][e:e + 1, :c]), self.state[e],
+                                                        oracle.PCM_F32)
+            for k in range(pkg.MAX_CCE):
+                rec = g["cce"][e, k]
+                if not rec["present"]:
+                    continue
+                if rec["coupling_point"] != 3:
+                    self.dependent += int(rec["n_links"])
+                    continue
+                for l in range(int(rec["n_links"])):
+                    cpl = np.zeros(1, pkg.COUPLING_DT)
+                    cpl["on"][0, rec["link"][l]["target_ch"]] = 1
+                    cpl["gain"][0, rec["link"][l]["target_ch"]] = rec["link"][l]["gain"][0]
+                    f32, _ = oracle.couple_after_imdct_batch(c, f32, rets[k].reshape(1, 1024), cpl)
+                    self.independent += 1
+            for j in range(c):
+                planes[int(self.layout[0]["elem"][e]["first_channel"]) + j] = f32[0, j]
+        return oracle.float_to_int16_interleave(planes), g

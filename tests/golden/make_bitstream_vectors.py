@@ -33,6 +33,50 @@ LAYOUT_STREAMS = {
 }
 
 
+# streams whose program config element names coupling channel elements (tests/coupled_ref.py writes and checks them)
+COUPLED_STREAMS = {
+    # name: (object type, sampling index, output elements, coupling element tags, coupling points, frames, seed)
+    "lc_pce_5_1_coupled_48k": (2, 3, [(SCE, 0), (CPE, 0), (CPE, 1), (LFE, 0)], [3, 9], [0, 1, 3], 6, 821),
+    "main_pce_pair_coupled_48k": (1, 3, [(CPE, 2)], [6], [0, 1, 3], 6, 822),
+}
+
+
+def write_coupled_stream(pkg, oracle, name):
+    """Returns (AudioSpecificConfig bytes, access units)."""
+    import coupled_ref as R
+    aot, si, elems, cc_tags, points, frames, seed = COUPLED_STREAMS[name]
+    rng = np.random.default_rng(seed)
+    asc = R.asc(aot, si, elems, cc_tags, rng)
+    r, m4, layout = pkg.asc_layout(asc)
+    assert r == 0
+    chk = R.Checker(pkg, oracle, m4, layout, aot)
+    aus = []
+    while len(aus) < frames:
+        au = R.write_unit(rng, si, aot, elems, cc_tags, points, quiet=True)
+        if chk.parses(au):
+            chk.frame(au)
+            aus.append(au)
+    return asc, aus
+
+
+def decode_coupled_stream(pkg, oracle, name, asc, aus):
+    import coupled_ref as R
+    aot = COUPLED_STREAMS[name][0]
+    r, m4, layout = pkg.asc_layout(asc)
+    assert r == 0
+    chk = R.Checker(pkg, oracle, m4, layout, aot)
+    rec, pcm = [], hashlib.sha256()
+    for au in aus:
+        out, g = chk.frame(au)
+        m = hashlib.sha256(g["tools"].tobytes())
+        for k in ("elem", "cce", "cce_tools", "cce_ics"):
+            m.update(g[k].tobytes())
+        rec.append(m.hexdigest())
+        pcm.update(out.tobytes())
+    assert chk.dependent and chk.independent, name
+    return rec, pcm.hexdigest(), list(out.shape)
+
+
 def write_layout_stream(pkg, name):
     import copy
     import sbr_bitwriter as SW
@@ -193,6 +237,15 @@ def main():
         rec, pcm, shape = decode_layout_stream(pkg, oracle, name, aus)
         out[name] = dict(asc=LAYOUT_STREAMS[name][0].hex(), access_units=[a.hex() for a in aus], records_sha256=rec,
                          pcm_s16_sha256=pcm, frame_shape=shape)
+        print(name, len(aus), "units,", sum(len(a) for a in aus), "bytes, pcm", pcm[:16])
+    for name in COUPLED_STREAMS:
+        if stored and name in stored:
+            asc, aus = bytes.fromhex(stored[name]["asc"]), [bytes.fromhex(a) for a in stored[name]["access_units"]]
+        else:
+            asc, aus = write_coupled_stream(pkg, oracle, name)
+        rec, pcm, shape = decode_coupled_stream(pkg, oracle, name, asc, aus)
+        out[name] = dict(asc=asc.hex(), access_units=[a.hex() for a in aus], records_sha256=rec, pcm_s16_sha256=pcm,
+                         frame_shape=shape)
         print(name, len(aus), "units,", sum(len(a) for a in aus), "bytes, pcm", pcm[:16])
     json.dump(out, open(path, "w"), indent=0)
 

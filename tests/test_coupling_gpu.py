@@ -91,75 +91,88 @@ def test_dependent_coupling_around_tns(pkg, oracle, dev, cpe, behind, two):
     assert np.array_equal(d_rng.cpu().numpy(), r2)
 
 
-@pytest.mark.parametrize("cpe,points", [(True, [0, 1]), (False, [3]), (True, [0, 1, 3])])
-def test_codec_decodes_access_units_with_coupling_elements(pkg, oracle, dev, cpe, points):
-    """heaac_codec_decode on AAC-LC access units that carry a coupling element (dependent or AFTER_IMDCT), state
-    chained over six frames; int16 PCM against the oracle run on the separately parsed records."""
+SCE, CPE, CCE, LFE = 0, 1, 2, 3
+STREAMS = {
+    # name: (object type, output elements in bitstream order, coupling element tags, coupling points drawn from)
+    "pair_dependent": (2, [(CPE, 0)], [5], [0, 1]),
+    "mono_independent": (2, [(SCE, 0)], [5], [3]),
+    "five_one": (2, [(SCE, 0), (CPE, 0), (CPE, 1), (LFE, 0)], [3, 9], [0, 1, 3]),
+    "main_three": (1, [(SCE, 2), (CPE, 4)], [7], [0, 1, 3]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(STREAMS))
+def test_codec_decodes_access_units_with_coupling_elements(pkg, oracle, dev, name):
+    """heaac_codec_decode on AAC-LC / Main streams whose program config element names coupling elements (the only
+    streams whose coupling elements aac_decode_frame knows, che_configure aacdec.c:198-212): dependent coupling around
+    every target's TNS and independent coupling behind its IMDCT, onto one and onto several output elements, the
+    coupling elements anywhere between them; state chained over six frames.  int16 PCM against tests/coupled_ref.py
+    (the oracle's tools, coupling, IMDCTs and interleave on the separately parsed records)."""
+    import coupled_ref as R
     from test_shim_gpu import HeaacCodecContext, HeaacPacket
     lib = pkg.lib()
-    rng = np.random.default_rng(300 + cpe + len(points))
-    si, aot = 3, 2
-    ch = 2 if cpe else 1
+    aot, elems, cc_tags, points = STREAMS[name]
+    rng = np.random.default_rng(sum(map(ord, name)))
+    si = 3
+    asc = R.asc(aot, si, elems, cc_tags, rng)
+    ctx = HeaacCodecContext(cfg=-1, extradata=asc, extradata_size=len(asc))
+    codec = C.c_void_p.in_dll(lib, "heaac_aac_decoder")
+    assert lib.heaac_codec_open(C.byref(ctx), C.c_void_p(C.addressof(codec))) == 0
+    r, m4, layout = pkg.asc_layout(asc)
+    assert r == 0
+    chk = R.Checker(pkg, oracle, m4, layout, aot)
+    assert ctx.channels == chk.nch
+    out = (C.c_int16 * (192000 // 2))()
+    loud = 0
+
+    def unit(tags, check=True):
+        while True:
+            au = R.write_unit(rng, si, aot, elems, tags, points)
+            if not check or chk.parses(au):
+                return au
+
+    def decode(au):
+        b = C.create_string_buffer(au, len(au))
+        pkt = HeaacPacket(C.cast(b, C.c_void_p), len(au))
+        size = C.c_int(192000)
+        return lib.heaac_codec_decode(C.byref(ctx), out, C.byref(size), C.byref(pkt)), size.value
+
+    for t in range(6):
+        au = unit(cc_tags)
+        used, size = decode(au)
+        assert used == len(au) and size == 1024 * chk.nch * 2, (t, used)
+        got = np.frombuffer(out, np.int16, 1024 * chk.nch).reshape(1024, chk.nch).copy()
+        want, _ = chk.frame(au)
+        assert np.array_equal(got, want), ("frame %d" % t, np.argwhere(got != want)[:4])
+        loud = max(loud, int(np.abs(got.astype(int)).max()))
+    assert loud > 50 and (chk.dependent >= 2 or points == [3]) and (chk.independent >= 2 or 3 not in points)
+    # a coupling element the stream has carried so far is left out: refused, as an output element would be (the
+    # reference couples whatever the element's buffers still hold)
+    assert decode(unit([]))[0] < 0
+    # a coupling element the program config element did not name: "channel element 2.%d is not allocated"
+    assert decode(unit(cc_tags[:-1] + [13], check=False))[0] < 0
+    assert lib.heaac_codec_close(C.byref(ctx)) == 0
+
+
+@pytest.mark.parametrize("cpe", [False, True])
+def test_codec_refuses_a_coupling_element_in_a_channel_configuration_stream(pkg, dev, cpe):
+    """Channel configurations 1..7 allocate no coupling element (set_default_channel_config aacdec.c:359-398, get_che
+    :132-177): aac_decode_frame fails such an access unit ("channel element 2.%d is not allocated", :2006-2010), and
+    goes on with the next."""
+    from test_shim_gpu import HeaacCodecContext, HeaacPacket
+    lib = pkg.lib()
+    rng = np.random.default_rng(77 + cpe)
     asc = bytes([0x11, 0x90]) if cpe else bytes([0x11, 0x88])
     ctx = HeaacCodecContext(cfg=-1, extradata=asc, extradata_size=2)
     codec = C.c_void_p.in_dll(lib, "heaac_aac_decoder")
     assert lib.heaac_codec_open(C.byref(ctx), C.c_void_p(C.addressof(codec))) == 0
-    cfg = TP._cfg(pkg, aot, si, ch)
-    st = np.zeros(1, pkg.AAC_STREAM_DT)
-    state = np.zeros((1, 512 * ch), np.float32)
-    cstate = np.zeros((pkg.MAX_CCE, 1, 512), np.float32)
-    r_state = np.full(1, 0x1f2e3d4c, np.int32)
     out = (C.c_int16 * (192000 // 2))()
-    coupled = loud = 0
-    for t in range(6):
-        behind = bool(t & 1)
-        while True:
-            targets = [(1 if cpe else 0, 0, int(rng.integers(0, 4)) if cpe else 2)]
-            au, _ = TW.build_au(rng, si, aot, cpe, [(5, targets, int(rng.choice(points)), behind)])
-            r, g = pkg.aac_parse_frame_ex(cfg, st.copy(), au)
-            if r == 0:
-                break
-        r, g = pkg.aac_parse_frame_ex(cfg, st, au)
+    for behind in (False, True, None):
+        cces = [] if behind is None else [(5, [(1 if cpe else 0, 0, 2)], 0, behind)]
+        au, _ = TW.build_au(rng, 3, 2, cpe, cces)
         b = C.create_string_buffer(au, len(au))
         pkt = HeaacPacket(C.cast(b, C.c_void_p), len(au))
         size = C.c_int(192000)
-        assert lib.heaac_codec_decode(C.byref(ctx), out, C.byref(size), C.byref(pkt)) == len(au), t
-        assert size.value == 1024 * ch * 2 and ctx.channels == ch
-        got = np.frombuffer(out, np.int16, 1024 * ch).reshape(1024, ch).copy()
-        # the oracle: elements' tools in bitstream order, coupling, IMDCTs, independent coupling
-        cce, cc = g["cce"][None], g["cce_coeffs"][None].copy()
-        coeffs = np.ascontiguousarray(g["coeffs"][None, :ch])
-
-        def o_cce(rs):
-            for s in range(pkg.MAX_CCE):
-                if cce[0, s]["present"]:
-                    c1, rs, _ = oracle.spectral_tools_batch_ex(1, oracle.TOOLS_ALL, cc[:, s:s + 1], g["cce_tools"][s:s + 1], rng=rs)
-                    cc[:, s] = c1[:, 0]
-            return rs
-        if not behind:
-            r_state = o_cce(r_state)
-            pre, r_state, _ = oracle.spectral_tools_batch_ex(ch, oracle.TOOLS_PRE, coeffs, g["tools"], rng=r_state)
-        else:
-            pre, r_state, _ = oracle.spectral_tools_batch_ex(ch, oracle.TOOLS_PRE, coeffs, g["tools"], rng=r_state)
-            r_state = o_cce(r_state)
-        post, _, _ = oracle.spectral_tools_batch_ex(ch, oracle.TOOLS_POST, pre, g["tools"], cce=cce, cce_coeffs=cc)
-        ics = np.ascontiguousarray(g["ics"][None, :ch])
-        f32, state = oracle.lc_decode_batch(ch, post, ics, state, oracle.PCM_F32)
-        ref16 = None
-        for s in range(pkg.MAX_CCE):
-            rec = cce[0, s]
-            if rec["present"] and rec["coupling_point"] == 3:
-                ret, cstate[s] = oracle.lc_decode_batch(1, cc[:, s:s + 1], g["cce_ics"][s:s + 1][None], cstate[s], oracle.PCM_F32)
-                for l in range(max(1, int(rec["n_links"]))):
-                    cpl = np.zeros(1, pkg.COUPLING_DT)
-                    if l < rec["n_links"]:
-                        cpl["on"][0, rec["link"][l]["target_ch"]] = 1
-                        cpl["gain"][0, rec["link"][l]["target_ch"]] = rec["link"][l]["gain"][0]
-                    f32, ref16 = oracle.couple_after_imdct_batch(ch, f32, ret.reshape(1, 1024), cpl, s16=True)
-        if ref16 is None:       # nothing couples behind the IMDCT: float_to_int16_interleave of the target alone
-            ref16 = oracle.couple_after_imdct_batch(ch, f32, np.zeros((1, 1024), np.float32), np.zeros(1, pkg.COUPLING_DT), s16=True)[1]
-        assert np.array_equal(got, ref16[0]), "frame %d" % t
-        coupled += int(cce[0, 0]["n_links"]) > 0
-        loud = max(loud, int(np.abs(got.astype(int)).max()))
-    assert coupled >= 3 and loud > 50
+        used = lib.heaac_codec_decode(C.byref(ctx), out, C.byref(size), C.byref(pkt))
+        assert (used == len(au)) if behind is None else (used < 0)
     assert lib.heaac_codec_close(C.byref(ctx)) == 0

@@ -78,8 +78,19 @@ def test_stored_multichannel_bitstreams_parse_and_decode_to_the_stored_hashes(pk
     assert [a.hex() for a in B.write_layout_stream(pkg, name)] == v["access_units"]
 
 
+@pytest.mark.parametrize("name", sorted(B.COUPLED_STREAMS))
+def test_stored_coupled_bitstreams_parse_and_decode_to_the_stored_hashes(pkg, oracle, name):
+    """The same for the stored streams with coupling channel elements (a program config element names them)."""
+    v = json.load(open(BPATH))[name]
+    asc, aus = bytes.fromhex(v["asc"]), [bytes.fromhex(a) for a in v["access_units"]]
+    rec, pcm, shape = B.decode_coupled_stream(pkg, oracle, name, asc, aus)
+    assert rec == v["records_sha256"] and pcm == v["pcm_s16_sha256"] and shape == v["frame_shape"]
+    asc2, aus2 = B.write_coupled_stream(pkg, oracle, name)
+    assert asc2.hex() == v["asc"] and [a.hex() for a in aus2] == v["access_units"]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", sorted(B.STREAMS) + sorted(B.LAYOUT_STREAMS))
+@pytest.mark.parametrize("name", sorted(B.STREAMS) + sorted(B.LAYOUT_STREAMS) + sorted(B.COUPLED_STREAMS))
 def test_codec_decodes_stored_bitstreams_to_the_stored_pcm(pkg, name):
     """heaac_codec_open / _decode on the committed bytes (cfg from the stream): the int16 PCM hashes to the
     stored value.  No oracle in this test."""

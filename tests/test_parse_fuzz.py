@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ffmpeg-heaac_amd", "csrc")
 BUILD = os.path.join(ROOT, "tests", "c", "_build")
 EXE = os.path.join(BUILD, "fuzz_parse")
-KIND = {"lc_stereo_48k": 0, "hev1_stereo_24k": 1, "hev2_mono_24k": 2, "hev2_implicit_24k": 2, "lc_5_1_48k": 5}
+KIND = {"lc_stereo_48k": 0, "hev1_stereo_24k": 1, "hev2_mono_24k": 2, "hev2_implicit_24k": 2, "lc_5_1_48k": 5,
+        "lc_pce_5_1_coupled_48k": 6}
 
 
 def test_parsers_survive_damaged_access_units():
@@ -33,6 +34,9 @@ def test_parsers_survive_damaged_access_units():
             for au in s["access_units"]:
                 b = bytes.fromhex(au)
                 f.write(struct.pack("<II", KIND[name], len(b)) + b)
+            if KIND[name] == 6:                            # the stream's configuration: its program config element
+                b = bytes.fromhex(s["asc"])
+                f.write(struct.pack("<II", 7, len(b)) + b)
         # access units with coupling channel elements and program config elements (the wide parser entry)
         for i in range(40):
             cpe = bool(i & 1)
@@ -57,3 +61,5 @@ def test_parsers_survive_damaged_access_units():
     assert int(m.group(1)) > 5000 and int(m.group(2)) > 10000, m.group(0)
     m = re.search(r"5.1 units parsed (\d+), program config layouts accepted (\d+), out of range (\d+)", p.stdout)
     assert int(m.group(1)) > 3000 and int(m.group(2)) > 1000 and int(m.group(3)) == 0, m.group(0)
+    m = re.search(r"coupled layout units parsed (\d+), gain lists landed (\d+)", p.stdout)
+    assert int(m.group(1)) > 1000 and int(m.group(2)) > 1000, m.group(0)
