@@ -36,8 +36,9 @@ enum {
     HEAAC_PARSE_OK          =  0,
     HEAAC_PARSE_ERR_DATA    = -1,   /* invalid or reserved value in the bitstream (the reference returns -1) */
     HEAAC_PARSE_ERR_OVERREAD = -2,  /* ran past the end of the access unit */
-    HEAAC_PARSE_ERR_UNSUPPORTED = -3, /* valid AAC outside the entry it was handed to: LTP, SSR gain control; a coupling
-                                         element or a second SCE / CPE in heaac_aac_parse_frame, ... */
+    HEAAC_PARSE_ERR_UNSUPPORTED = -3, /* valid AAC outside the entry it was handed to: a coupling element or a second
+                                         SCE / CPE in heaac_aac_parse_frame, ...; and what the reference itself reports as a
+                                         missing feature: LTP (aacdec.c:694), SSR gain control (:1373), 960-sample frames (:409) */
     HEAAC_PARSE_ERR_ARG     = -4,
 };
 
