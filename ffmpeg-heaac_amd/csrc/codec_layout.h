@@ -13,6 +13,10 @@ struct HeaacLayoutOut {
     int64_t channel_layout;
 };
 
+// SBR output mode of a configuration (shim.hip): 0 = 2048 samples at twice the core rate, 1 = "downsampled SBR",
+// 1024 samples at the core rate, -1 = the two rates contradict each other
+int heaac_sbr_output_mode(const HeaacAacConfig *m);
+
 HeaacLayoutDec *heaac_layout_dec_create(HeaacDevice *dev, const HeaacAacConfig *m4ac, const HeaacAacLayout *layout);
 void heaac_layout_dec_destroy(HeaacLayoutDec *d);
 // One access unit -> interleaved int16 in `data` (host).  Returns the bytes consumed (aacdec.c:2102-2107) or -1.

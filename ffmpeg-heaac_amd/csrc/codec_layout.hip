@@ -212,6 +212,12 @@ int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void
     for (int i = 0; i < d->n; i++) d->e[i].ast = st[i];
     for (int k = 0; k < HEAAC_MAX_CCE; k++)
         if (cce_here[k]) c->seen[k] = 1;
+    // "Dependent coupling is not supported together with LTP" (apply_dependent_coupling :1822-1826 returns): an LTP
+    // profile stream (an ADTS header can say so) keeps its coupling elements but nothing couples in the spectrum
+    if (n_cce && d->m4ac.object_type == 4)
+        for (int i = 0; i < d->n; i++)
+            for (int k = 0; k < HEAAC_MAX_CCE; k++)
+                if (c->h_cce[i][k].coupling_point != HEAAC_CC_AFTER_IMDCT) c->h_cce[i][k].n_links = 0;
     if (!d->locked) {
         // implicit SBR counts only when the first access unit carries it (aacdec.c:1666-1675)
         if (d->m4ac.sbr == -1) {
@@ -222,7 +228,9 @@ int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void
         d->locked = 1;
     }
     const int he = d->m4ac.sbr == 1;
-    const int len = he ? 2048 : 1024;
+    const int mode = he ? heaac_sbr_output_mode(&d->m4ac) : 0;        // 1: the output at the core rate (shim.hip)
+    if (mode < 0) return -1;
+    const int len = he && !mode ? 2048 : 1024;
     const int main_profile = d->m4ac.object_type == HEAAC_AOT_AAC_MAIN;
     // uploads, then the spectral tools of the elements in bitstream order (one noise generator)
     for (int i = 0; i < d->n; i++) {
@@ -320,8 +328,8 @@ int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void
             }
             if (heaac_validate_frame(e.cfg_he, &sbr, d->hdr, LAY_MAX_HDRS, NULL)) return -1;
             if (hipMemcpy(e.d_sbr, &sbr, sizeof(sbr), hipMemcpyHostToDevice) != hipSuccess) return -1;
-            rc = heaac_he_decode_batch(d->dev, e.cfg_he, e.d_coeffs, e.d_ics, e.d_sbr, d->d_hdr, LAY_MAX_HDRS, NULL,
-                                       e.d_state, e.d_state, e.d_f32, HEAAC_PCM_F32_PLANAR, 1, NULL);
+            rc = heaac_he_decode_batch_ex(d->dev, e.cfg_he, mode ? HEAAC_HE_DOWNSAMPLED : 0, e.d_coeffs, e.d_ics, e.d_sbr, d->d_hdr,
+                                          LAY_MAX_HDRS, NULL, e.d_state, e.d_state, e.d_f32, HEAAC_PCM_F32_PLANAR, 1, NULL);
         }
         if (rc != HEAAC_OK) return -1;
         for (int c = 0; c < e.channels; c++) {
@@ -338,7 +346,7 @@ int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void
         out->channels = d->layout.channels;
         out->channel_layout = d->layout.channel_layout;
         out->frame_size = len;
-        out->sample_rate = he ? 2 * d->m4ac.sample_rate : d->m4ac.sample_rate;
+        out->sample_rate = he && !mode ? 2 * d->m4ac.sample_rate : d->m4ac.sample_rate;
     }
     // aacdec.c:2102-2107: bytes consumed, or the whole packet when only zero padding follows
     const int consumed = (fi.bits_consumed + 7) >> 3;

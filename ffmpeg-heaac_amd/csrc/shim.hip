@@ -308,6 +308,7 @@ extern "C" void av_fft_end(FFTContext *s) { if (s) { ff_fft_end(s); free(s); } }
 typedef struct HeaacDecoderPriv {
     HeaacDevice *dev;
     int cfg, ncore, nout, out_len;
+    int downsampled;              // SBR with the output at the core rate (bitstream mode; set_rates)
     size_t words;
     float *d_state;               // one record, updated in place
     float *d_coeffs;
@@ -346,14 +347,31 @@ static void set_cfg(HeaacDecoderPriv *p, int cfg)
     }
 }
 
-// what the stream says so far -> the caller-visible fields (aacdec.c:2080-2094: samples = 1024 << multiplier)
-static void publish_cfg(HeaacCodecContext *avctx, const HeaacDecoderPriv *p)
+static int cfg_is_he(int cfg) { return cfg == HEAAC_CFG_HEV1 || cfg == HEAAC_CFG_HEV1_MONO || cfg == HEAAC_CFG_HEV2; }
+
+// The two decisions the reference takes from the configuration's two sample rates: ff_sbr_apply synthesises with the
+// 32-band bank -- 1024 samples per frame -- when ext_sample_rate < sbr->sample_rate = 2 * sample_rate (aacsbr.c:1055,
+// :1719), and aac_decode_frame hands out 1024 << (ext_sample_rate > sample_rate) samples (aacdec.c:2080-2081).  No
+// extension rate (implicit SBR) means twice the core rate (aacsbr.c:1056-1057).  Returns 1 for "downsampled SBR"
+// (both say 1024), 0 for the usual case (both say 2048), -1 where they disagree (an extension rate strictly between:
+// the reference would hand out 2048 samples of which the synthesis wrote 1024).
+int heaac_sbr_output_mode(const HeaacAacConfig *m)
 {
-    const int he = p->out_len == 2048;
+    const int ext = m->ext_sample_rate ? m->ext_sample_rate : 2 * m->sample_rate;
+    const int downsampled = ext < 2 * m->sample_rate, doubled = ext > m->sample_rate;
+    return downsampled == doubled ? -1 : downsampled;
+}
+
+// what the stream says so far -> the caller-visible fields (aacdec.c:2080-2094: samples = 1024 << multiplier)
+static void publish_cfg(HeaacCodecContext *avctx, HeaacDecoderPriv *p)
+{
+    const int he = cfg_is_he(p->cfg);
+    p->downsampled = he && p->bitstream && heaac_sbr_output_mode(&p->m4ac) == 1;
+    if (he) p->out_len = p->downsampled ? 1024 : 2048;
     avctx->channels = p->nout;
     avctx->channel_layout = p->nout == 2 ? HEAAC_CH_LAYOUT_STEREO : HEAAC_CH_LAYOUT_MONO;   // output_configure, aacdec.c:224-301
     avctx->frame_size = p->out_len;
-    avctx->sample_rate = he ? 2 * p->m4ac.sample_rate : p->m4ac.sample_rate;
+    avctx->sample_rate = he && !p->downsampled ? 2 * p->m4ac.sample_rate : p->m4ac.sample_rate;
 }
 
 static int dec_init_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p)
@@ -370,6 +388,7 @@ static int dec_init_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p)
         // mpeg4audio.c:137-139), which decode_audio_specific_config turns into ps = 1 (:476-477): the reference then gives
         // every SCE of the layout a second, Parametric Stereo output channel (che_configure, :203-206).  Not decoded here.
         if (p->have_layout && p->m4ac.sbr == 1 && p->m4ac.ps == -1) return -1;
+        if (p->m4ac.sbr == 1 && heaac_sbr_output_mode(&p->m4ac) < 0) return -1;
         p->have_m4ac = 1;
     }
     const size_t words = HEAAC_STATE_WORDS_HEV2 > HEAAC_STATE_WORDS_HEV1 ? HEAAC_STATE_WORDS_HEV2 : HEAAC_STATE_WORDS_HEV1;
@@ -400,11 +419,11 @@ static int dec_init_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p)
     if (p->have_m4ac && p->have_layout) {
         if (!(p->lay = heaac_layout_dec_create(p->dev, &p->m4ac, &p->layout))) return -1;
         // tentative (output_configure with OC_GLOBAL_HDR); the first access unit settles implicit SBR
-        const int he = p->m4ac.sbr == 1;
+        const int doubled = p->m4ac.sbr == 1 && heaac_sbr_output_mode(&p->m4ac) == 0;
         avctx->channels = p->layout.channels;
         avctx->channel_layout = p->layout.channel_layout;
-        avctx->frame_size = he ? 2048 : 1024;
-        avctx->sample_rate = he ? 2 * p->m4ac.sample_rate : p->m4ac.sample_rate;
+        avctx->frame_size = doubled ? 2048 : 1024;
+        avctx->sample_rate = doubled ? 2 * p->m4ac.sample_rate : p->m4ac.sample_rate;
     } else if (p->have_m4ac) {
         // tentative, as decode_audio_specific_config leaves it; the first access unit settles implicit SBR
         const int he = p->m4ac.sbr == 1;
@@ -433,7 +452,9 @@ static int dec_frame_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p, vo
         p->m4ac.chan_config = ah.chan_config;
         p->m4ac.sbr = -1;
         p->m4ac.ps = -1;
-        if (p->m4ac.object_type != HEAAC_AOT_AAC_LC && p->m4ac.object_type != HEAAC_AOT_AAC_MAIN) return -1;
+        // The header's two profile bits give object types 1 .. 4, and unlike decode_audio_specific_config (:481-491)
+        // this way in asks nothing of them: an SSR or LTP profile stream decodes as AAC-LC does until an element uses
+        // what the reference lacks (gain control :1373, the predictor bit :694), which fails that frame.
         if (ah.chan_config != 1 && ah.chan_config != 2) {
             // set_default_channel_config (:1946), or -- channel configuration 0 -- the program config element the
             // raw data block starts with (:2036-2046, OC_TRIAL_PCE)
@@ -484,7 +505,7 @@ static int dec_frame_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p, vo
         publish_cfg(avctx, p);
         p->configured = 1;
     }
-    const int he = p->out_len == 2048;
+    const int he = cfg_is_he(p->cfg);
     const int ch = fi.channels;
     uint8_t *d_ics = p->d_side, *d_sbr = p->d_side + 16, *d_ps = p->d_side + 16 + 688;
     if (hipMemcpy(p->d_coeffs, p->h_coeffs, (size_t)ch * 4096, hipMemcpyHostToDevice) != hipSuccess ||
@@ -511,9 +532,10 @@ static int dec_frame_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p, vo
         if (heaac_validate_frame(p->cfg, &sbr, p->hdr, MAX_HDRS, p->cfg == HEAAC_CFG_HEV2 ? &ps : NULL)) return -1;
         if (hipMemcpy(d_sbr, &sbr, sizeof(sbr), hipMemcpyHostToDevice) != hipSuccess) return -1;
         if (p->cfg == HEAAC_CFG_HEV2 && hipMemcpy(d_ps, &ps, sizeof(ps), hipMemcpyHostToDevice) != hipSuccess) return -1;
-        rc = heaac_he_decode_batch(p->dev, p->cfg, p->d_coeffs, (const HeaacIcs *)d_ics, (const HeaacSbrFrame *)d_sbr,
-                                   p->d_hdr, MAX_HDRS, p->cfg == HEAAC_CFG_HEV2 ? (const HeaacPsFrame *)d_ps : NULL,
-                                   p->d_state, p->d_state, p->d_pcm, HEAAC_PCM_S16_INTERLEAVED, 1, NULL);
+        rc = heaac_he_decode_batch_ex(p->dev, p->cfg, p->downsampled ? HEAAC_HE_DOWNSAMPLED : 0, p->d_coeffs,
+                                      (const HeaacIcs *)d_ics, (const HeaacSbrFrame *)d_sbr,
+                                      p->d_hdr, MAX_HDRS, p->cfg == HEAAC_CFG_HEV2 ? (const HeaacPsFrame *)d_ps : NULL,
+                                      p->d_state, p->d_state, p->d_pcm, HEAAC_PCM_S16_INTERLEAVED, 1, NULL);
     }
     if (rc != HEAAC_OK) return -1;
     const int bytes = p->out_len * p->nout * 2;

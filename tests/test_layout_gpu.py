@@ -56,12 +56,12 @@ def test_interleave_refuses_what_it_cannot_do(pkg, dev):
 SCE, CPE, CCE, LFE = 0, 1, 2, 3
 
 
-def _asc(aot, si, cc, he=False, pce=None):
+def _asc(aot, si, cc, he=False, pce=None, ext_si=None):
     """AudioSpecificConfig (mpeg4audio.c:79-143): explicit SBR puts object type 5 and the extension rate in front."""
     import aac_bitwriter as W
     bw = W.BitWriter()
     if he:
-        bw.put(5, 5); bw.put(si, 4); bw.put(cc, 4); bw.put(si - 3, 4); bw.put(aot, 5)
+        bw.put(5, 5); bw.put(si, 4); bw.put(cc, 4); bw.put(si - 3 if ext_si is None else ext_si, 4); bw.put(aot, 5)
     else:
         bw.put(aot, 5); bw.put(si, 4); bw.put(cc, 4)
     bw.put(0, 3)                                                       # GASpecificConfig: 1024 samples, no core coder, no extension
@@ -79,6 +79,7 @@ MODES = {
     "main_5_0": (5, [(SCE, 3), (CPE, 1), (CPE, 0)], False, "asc"),      # tags as the encoder pleases: taken by position
     "he_5_1": (6, [(SCE, 0), (CPE, 0), (CPE, 1), (LFE, 0)], True, "asc"),
     "he_5_1_implicit": (6, [(SCE, 0), (CPE, 0), (CPE, 1), (LFE, 0)], True, "asc_implicit"),
+    "he_5_0_downsampled": (5, [(SCE, 0), (CPE, 0), (CPE, 1)], True, "asc_downsampled"),   # extension rate = core rate
     "lc_pce_asc": (0, [(CPE, 1), (LFE, 2), (SCE, 0), (CPE, 0)], False, "asc"),
     "lc_pce_adts": (0, [(SCE, 0), (CPE, 0), (CPE, 1), (LFE, 0)], False, "adts"),
 }
@@ -88,7 +89,8 @@ MODES = {
 def test_codec_decodes_multichannel_streams(pkg, oracle, dev, mode):
     """aac_decode_frame for layouts with several output elements, through heaac_codec_decode on the reference's own
     AVCodecContext / AVPacket records: 3.0, 5.0, 5.1, 7.1, a program config element in the extradata and one at the
-    head of the first ADTS frame, AAC-Main prediction, explicit and implicit SBR per element.  The checker parses the
+    head of the first ADTS frame, AAC-Main prediction, explicit and implicit SBR per element, downsampled SBR (1024
+    samples per frame at the core rate, aacsbr.c:1719).  The checker parses the
     same units with the layout parser (pinned by tests/test_parse_layout.py), runs the ORACLE's spectral tools through
     the elements in bitstream order (one noise generator), the oracle's decode per element on its own state, and
     ff_float_to_int16_interleave_c over the planes in layout order."""
@@ -108,7 +110,8 @@ def test_codec_decodes_multichannel_streams(pkg, oracle, dev, mode):
         back = [(1, 1)] if (CPE, 1) in elems else []
         pce_elems = (front, [], back, [g for t, g in elems if t == LFE])
     pce = (lambda bw: TL.write_pce_body(bw, rng, *pce_elems)) if cc == 0 else None
-    asc = None if how == "adts" else _asc(aot, si, cc, he=he and how == "asc", pce=pce)
+    down = how == "asc_downsampled"
+    asc = None if how == "adts" else _asc(aot, si, cc, he=he and how in ("asc", "asc_downsampled"), pce=pce, ext_si=si if down else None)
     ctx = HeaacCodecContext(cfg=-1, extradata=asc, extradata_size=len(asc) if asc else 0)
     codec = C.c_void_p.in_dll(lib, "heaac_aac_decoder")
     assert lib.heaac_codec_open(C.byref(ctx), C.c_void_p(C.addressof(codec))) == 0
@@ -125,7 +128,7 @@ def test_codec_decodes_multichannel_streams(pkg, oracle, dev, mode):
     if asc is not None:
         assert ctx.channels == nch and ctx.channel_layout == int(layout[0]["channel_layout"])
     st = np.zeros(pkg.MAX_ELEMENTS, pkg.AAC_STREAM_DT)
-    length = 2048 if he else 1024
+    length = 2048 if he and not down else 1024
     slot_ch = [int(layout[0]["elem"][e]["channels"]) for e in range(ne)]
     state = [np.zeros((1, pkg.STATE_WORDS[(pkg.CFG_HEV1 if c == 2 else pkg.CFG_HEV1_MONO) if he else
                                           (pkg.CFG_LC_STEREO if c == 2 else pkg.CFG_LC_MONO)]), np.float32) for c in slot_ch]
@@ -162,7 +165,7 @@ def test_codec_decodes_multichannel_streams(pkg, oracle, dev, mode):
         size = C.c_int(192000)
         used = lib.heaac_codec_decode(C.byref(ctx), out, C.byref(size), C.byref(pkt))
         assert used == len(pkt_bytes), (t, used)
-        assert (ctx.channels, ctx.frame_size, ctx.sample_rate) == (nch, length, 48000), t
+        assert (ctx.channels, ctx.frame_size, ctx.sample_rate) == (nch, length, 24000 if down else 48000), t
         assert ctx.channel_layout == int(layout[0]["channel_layout"]) and size.value == length * nch * 2
         got = np.frombuffer(out, np.int16, size.value // 2).reshape(length, nch).copy()
         # ---- the checker ----
@@ -191,7 +194,7 @@ def test_codec_decodes_multichannel_streams(pkg, oracle, dev, mode):
                     sbr = pkg.sbr_no_payload(sst[e], c)              # an LFE: never started ("pure upsampling")
                     assert int(layout[0]["elem"][e]["type"]) == LFE
                 pcm, state[e] = oracle.he_decode_batch(pkg.CFG_HEV1 if c == 2 else pkg.CFG_HEV1_MONO, spec[e], ics, sbr,
-                                                       tab.headers(), None, state[e], oracle.PCM_F32)
+                                                       tab.headers(), None, state[e], oracle.PCM_F32, downsampled=down)
             else:
                 pcm, state[e] = oracle.lc_decode_batch(c, spec[e], ics, state[e], oracle.PCM_F32)
             for j in range(c):

@@ -163,6 +163,16 @@ def test_codec_surface_decodes_a_stream(pkg, oracle, dev, cfgname):
     assert lib.heaac_codec_close(C.byref(ctx)) == 0
 
 
+def test_codec_refuses_sbr_rates_that_contradict_each_other(pkg):
+    """An extension rate strictly between the core rate and twice the core rate: ff_sbr_apply would synthesise 1024
+    samples (aacsbr.c:1719) and aac_decode_frame hand out 2048 (aacdec.c:2080-2081).  Refused at open."""
+    lib = pkg.lib()
+    asc = bytes([0x2B, 0x12, 0x88, 0x00])                  # SBR, 24 kHz core, 32 kHz extension rate, AAC-LC pair
+    ctx = HeaacCodecContext(cfg=-1, extradata=asc, extradata_size=len(asc))
+    codec = C.c_void_p.in_dll(lib, "heaac_aac_decoder")
+    assert lib.heaac_codec_open(C.byref(ctx), C.c_void_p(C.addressof(codec))) == -1
+
+
 def _adts(au, aot, si, chan):
     """ADTS frame around one raw_data_block (aac_parser.c:29-70)."""
     import aac_bitwriter as W
@@ -173,31 +183,40 @@ def _adts(au, aot, si, chan):
     return bw.bytes(pad=0) + au
 
 
-@pytest.mark.parametrize("mode", ["lc_asc", "lc_adts_mono", "hev1_asc", "hev2_asc", "hev2_implicit", "sbr_too_late"])
+@pytest.mark.parametrize("mode", ["lc_asc", "lc_adts_mono", "ltp_profile_adts_mono", "hev1_asc", "hev2_asc", "hev2_implicit", "sbr_too_late",
+                                  "hev1_downsampled_asc", "hev2_downsampled_asc"])
 def test_codec_decodes_access_units(pkg, oracle, dev, mode):
     """cfg = HEAAC_CFG_FROM_STREAM: the packets are AAC access units, as avcodec_decode_audio3 hands them to the
-    reference's aac_decode_frame.  Configuration from extradata or the first ADTS header, SBR explicit or implicit
-    (first access unit only), mono + SBR decoded as Parametric Stereo.  int16 PCM against the oracle's spectral tools
+    reference's aac_decode_frame.  Configuration from extradata or the first ADTS header (whose profile bits may say
+    SSR or LTP: parse_adts_frame_header aacdec.c:1935-1971 takes any, and the stream decodes as AAC-LC until an element
+    uses the missing tool), SBR explicit or implicit (first access unit only), mono + SBR decoded as Parametric Stereo;
+    "downsampled SBR" -- an extension rate equal to the core rate: the 32-band synthesis bank, 1024 samples per frame at
+    the core rate (aacsbr.c:1719, aacdec.c:2080-2084).  int16 PCM against the oracle's spectral tools
     + decode on the separately parsed records, state chained over six frames."""
     import test_parse as TP
     import sbr_bitwriter as SW
     lib = pkg.lib()
     rng = np.random.default_rng(hash(mode) % 1000)
-    asc = dict(lc_asc=bytes([0x11, 0x90]), lc_adts_mono=None, hev1_asc=bytes([0x2B, 0x11, 0x88, 0x00]),
+    asc = dict(lc_asc=bytes([0x11, 0x90]), lc_adts_mono=None, ltp_profile_adts_mono=None, hev1_asc=bytes([0x2B, 0x11, 0x88, 0x00]),
                hev2_asc=bytes([0xEB, 0x09, 0x88, 0x00]), hev2_implicit=bytes([0x13, 0x08]),
-               sbr_too_late=bytes([0x13, 0x08]))[mode]
-    si = 3 if mode in ("lc_asc", "lc_adts_mono") else 6
-    cpe = mode in ("lc_asc", "hev1_asc")
+               sbr_too_late=bytes([0x13, 0x08]), hev1_downsampled_asc=bytes([0x2B, 0x13, 0x08, 0x00]),
+               hev2_downsampled_asc=bytes([0xEB, 0x0B, 0x08, 0x00]))[mode]
+    si = 3 if mode in ("lc_asc", "lc_adts_mono", "ltp_profile_adts_mono") else 6
+    aot = 4 if mode == "ltp_profile_adts_mono" else 2
+    cpe = mode in ("lc_asc", "hev1_asc", "hev1_downsampled_asc")
+    down = "downsampled" in mode
     ch = 2 if cpe else 1
     he = mode.startswith("hev")
-    hcfg = {"lc_asc": pkg.CFG_LC_STEREO, "lc_adts_mono": pkg.CFG_LC_MONO, "hev1_asc": pkg.CFG_HEV1,
-            "hev2_asc": pkg.CFG_HEV2, "hev2_implicit": pkg.CFG_HEV2, "sbr_too_late": pkg.CFG_LC_MONO}[mode]
+    hcfg = {"lc_asc": pkg.CFG_LC_STEREO, "lc_adts_mono": pkg.CFG_LC_MONO, "ltp_profile_adts_mono": pkg.CFG_LC_MONO, "hev1_asc": pkg.CFG_HEV1,
+            "hev2_asc": pkg.CFG_HEV2, "hev2_implicit": pkg.CFG_HEV2, "sbr_too_late": pkg.CFG_LC_MONO,
+            "hev1_downsampled_asc": pkg.CFG_HEV1, "hev2_downsampled_asc": pkg.CFG_HEV2}[mode]
+    length = 1024 if down else pkg.OUT_LEN[hcfg]
     ctx = HeaacCodecContext(cfg=-1, extradata=asc, extradata_size=len(asc) if asc else 0)
     codec = C.c_void_p.in_dll(lib, "heaac_aac_decoder")
     assert lib.heaac_codec_open(C.byref(ctx), C.c_void_p(C.addressof(codec))) == 0
     # the checker's own parse of the same units
     m4 = pkg.AacConfig()
-    m4.object_type, m4.sampling_index, m4.sample_rate, m4.chan_config = 2, si, 48000 if si == 3 else 24000, ch
+    m4.object_type, m4.sampling_index, m4.sample_rate, m4.chan_config = aot, si, 48000 if si == 3 else 24000, ch
     m4.sbr, m4.ps = (1 if he else 0), (1 if hcfg == pkg.CFG_HEV2 else 0)
     tab = pkg.SbrHeaderTable(64)
     st, sst = np.zeros(1, pkg.AAC_STREAM_DT), pkg.sbr_streams(1)
@@ -219,16 +238,16 @@ def test_codec_decodes_access_units(pkg, oracle, dev, mode):
             au, _ = TP._write_au(rng, si, 2, cpe, extras=False, sbr=(bits, False), quiet=True)
         else:
             au, _ = TP._write_au(rng, si, 2, cpe, extras=False, quiet=True)
-        pkt_bytes = _adts(au, 2, si, ch) if asc is None else au
+        pkt_bytes = _adts(au, aot, si, ch) if asc is None else au
         buf = C.create_string_buffer(pkt_bytes, len(pkt_bytes))
         pkt = HeaacPacket(C.cast(buf, C.c_void_p), len(pkt_bytes))
         size = C.c_int(192000)
         used = lib.heaac_codec_decode(C.byref(ctx), out, C.byref(size), C.byref(pkt))
         assert used == len(pkt_bytes), (t, used)                       # only zero padding follows the END element
-        assert (ctx.channels, ctx.frame_size) == (pkg.OUT_CH[hcfg], pkg.OUT_LEN[hcfg]), t
-        assert ctx.sample_rate == (24000 if mode == "sbr_too_late" else 48000)
-        assert size.value == pkg.OUT_LEN[hcfg] * pkg.OUT_CH[hcfg] * 2
-        got = np.frombuffer(out, np.int16, size.value // 2).reshape(pkg.OUT_LEN[hcfg], pkg.OUT_CH[hcfg]).copy()
+        assert (ctx.channels, ctx.frame_size) == (pkg.OUT_CH[hcfg], length), t
+        assert ctx.sample_rate == (24000 if mode == "sbr_too_late" or down else 48000)
+        assert size.value == length * pkg.OUT_CH[hcfg] * 2
+        got = np.frombuffer(out, np.int16, size.value // 2).reshape(length, pkg.OUT_CH[hcfg]).copy()
         if he:
             p = pkg.heaac_parse_batch(m4, st, sst, tab, [pkt_bytes], threads=1, with_ps=hcfg == pkg.CFG_HEV2)
         else:
@@ -239,7 +258,7 @@ def test_codec_decodes_access_units(pkg, oracle, dev, mode):
         ics = np.ascontiguousarray(p["ics"][:, :ch])
         if he:
             ref, state = oracle.he_decode_batch(hcfg, ref_c, ics, p["sbr"], tab.headers(), p["ps"] if hcfg == pkg.CFG_HEV2 else None,
-                                                state, oracle.PCM_S16)
+                                                state, oracle.PCM_S16, downsampled=down)
         else:
             ref, state = oracle.lc_decode_batch(ch, ref_c, ics, state, oracle.PCM_S16)
         assert np.array_equal(got, ref[0]), "frame %d" % t
