@@ -464,7 +464,8 @@ COUPLING_DT = np.dtype([("gain", "<f4", (2,)), ("on", "u1", (2,)), ("pad", "u1",
 AAC_STREAM_DT = np.dtype([("window_sequence", "u1", (2,)), ("use_kb_window", "u1", (2,)),
                           ("cce_window_sequence", "u1", (2,)), ("cce_use_kb_window", "u1", (2,))])
 AAC_INFO_DT = np.dtype([("channels", "<i4"), ("bits_consumed", "<i4"), ("sbr_payload_bit", "<i4"),
-                        ("sbr_payload_bytes", "<i4"), ("sbr_crc", "<i4"), ("elem_id", "<i4"), ("n_cce", "<i4")])
+                        ("sbr_payload_bytes", "<i4"), ("sbr_crc", "<i4"), ("elem_id", "<i4"), ("n_cce", "<i4"),
+                        ("sbr_misplaced", "<i4")])
 
 
 def asc_parse(buf):
@@ -573,7 +574,7 @@ AAC_LAYOUT_DT = np.dtype([("chan_config", "<i4"), ("n_elements", "<i4"), ("chann
                           ("channel_layout", "<i8"), ("elem", AAC_ELEM_SLOT_DT, (MAX_ELEMENTS,)),
                           ("slot_of", "i1", (4, 16)), ("tag_map", "i1", (4, 16))])
 AAC_ELEM_INFO_DT = np.dtype([("present", "u1"), ("type", "u1"), ("tag", "u1"), ("seq", "u1"), ("sbr_crc", "u1"),
-                             ("pad", "u1", (3,)), ("sbr_payload_bit", "<i4"), ("sbr_payload_bytes", "<i4")])
+                             ("sbr_misplaced", "u1"), ("pad", "u1", (2,)), ("sbr_payload_bit", "<i4"), ("sbr_payload_bytes", "<i4")])
 assert AAC_LAYOUT_DT.itemsize == 216 and AAC_ELEM_INFO_DT.itemsize == 16
 
 
@@ -691,7 +692,7 @@ def sbr_streams(n):
     return st
 
 
-def sbr_parse_payload(stream, table, sample_rate, payload, channels, allow_ps, crc=False, bit=0, cnt=None):
+def sbr_parse_payload(stream, table, sample_rate, payload, channels, allow_ps, crc=False, bit=0, cnt=None, misplaced=False):
     """heaac_sbr_parse_payload on ONE stream record (a row of sbr_streams()).  `payload`: the bytes that
     follow the 4-bit extension type when bit = 0 (tests), or a whole access unit with `bit` set.
     Returns (status, sbr record, ps record, info)."""
@@ -703,7 +704,7 @@ def sbr_parse_payload(stream, table, sample_rate, payload, channels, allow_ps, c
     r = lib().heaac_sbr_parse_payload(stream.ctypes.data_as(C.c_void_p), C.c_void_p(table._h), C.c_int(sample_rate),
                                       payload, C.c_int(len(payload)), C.c_int(bit),
                                       C.c_int(len(payload) if cnt is None else cnt), C.c_int(bool(crc)),
-                                      C.c_int(channels), C.c_int(bool(allow_ps)),
+                                      C.c_int(channels), C.c_int(int(bool(allow_ps)) | (2 if misplaced else 0)),
                                       sbr.ctypes.data_as(C.c_void_p), ps.ctypes.data_as(C.c_void_p),
                                       info.ctypes.data_as(C.c_void_p))
     return r, sbr, ps, info[0]

@@ -470,7 +470,7 @@ static int read_ics(const HeaacAacConfig *cfg, Bits *b, int common_window, Heaac
 /* access unit                                                                                   */
 /* ------------------------------------------------------------------------------------------ */
 enum { TYPE_SCE, TYPE_CPE, TYPE_CCE, TYPE_LFE, TYPE_DSE, TYPE_PCE, TYPE_FIL, TYPE_END };
-enum { EXT_SBR_DATA = 0xd, EXT_SBR_DATA_CRC = 0xe };
+enum { EXT_DYNAMIC_RANGE = 0xb, EXT_SBR_DATA = 0xd, EXT_SBR_DATA_CRC = 0xe };
 
 /* channel_pair_element behind its instance tag (decode_cpe, :1453-1492) without the spectral tools (GPU stages);
  * w[2] = the two channels' window history, coeffs [2][1024] */
@@ -531,6 +531,49 @@ static int skip_pce(Bits *b)
     if (bits_left(b) < comment) return HEAAC_PARSE_ERR_OVERREAD;
     skip(b, comment);
     return HEAAC_PARSE_OK;
+}
+
+/* decode_dynamic_range (:1596-1641) behind the payload's type nibble: nothing of it is used on this path, but it
+ * says how long it is -- the one extension payload that does not take all that is left of its fill element. */
+static int drc_bytes(Bits *b)
+{
+    int n = 1, bands = 1;
+    if (bit1(b)) { skip(b, 8); n++; }                  /* pce_instance_tag, reserved */
+    if (bit1(b)) {                                     /* excluded channels (decode_drc_channel_exclusions :1575-1587) */
+        int num = 0;
+        do { skip(b, 7); num += 7; } while (num < 64 - 7 && bit1(b));
+        n += num / 7;
+    }
+    if (bit1(b)) {                                     /* band_incr, interpolation_scheme, band_top[] */
+        bands += (int)bits(b, 4);
+        skip(b, 4 + 8 * bands);
+        n += 1 + bands;
+    }
+    if (bit1(b)) { skip(b, 8); n++; }                  /* prog_ref_level */
+    skip(b, 8 * bands);                                /* dyn_rng_sgn, dyn_rng_ctl */
+    return n + bands;
+}
+
+/* The body of a fill element of `cnt` bytes: extension payloads until they are used up (aac_decode_frame :2050-2060,
+ * decode_extension_payload :1650-1690).  *sbr_bit = where an SBR payload starts (behind its type nibble; it takes
+ * all that is left, :1044-1050), -1 for none. */
+static void read_fil(Bits *b, int cnt, int *sbr_bit, int *sbr_bytes, int *sbr_crc)
+{
+    *sbr_bit = -1;
+    while (cnt > 0) {
+        const int type = (int)bits(b, 4);
+        if (type == EXT_DYNAMIC_RANGE) {
+            cnt -= drc_bytes(b);
+            continue;
+        }
+        if (type == EXT_SBR_DATA || type == EXT_SBR_DATA_CRC) {
+            *sbr_bit = b->pos;
+            *sbr_bytes = cnt;
+            *sbr_crc = type == EXT_SBR_DATA_CRC;
+        }
+        skip(b, 8 * cnt - 4);
+        cnt = 0;
+    }
 }
 
 /* coupling_channel_element (decode_cce, aacdec.c:1503-1570) */
@@ -681,7 +724,8 @@ int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
         w[c].window_sequence[1] = w[c].use_kb_window[1] = 0;
     }
     memset(tools, 0, sizeof(*tools));
-    HeaacAacFrameInfo fi = { 0, 0, -1, 0, 0, 0, 0 };
+    HeaacAacFrameInfo fi = { 0, 0, -1, 0, 0, 0, 0, 0 };
+    int last_che = 0, prev_type = TYPE_END;            /* 1 + type of the channel element last seen; the element in front */
     /* The coupling elements name their targets by (type, tag): the output element of this slice is the one SCE /
      * CPE of the configuration (set_default_channel_config: tag 0), known before the walk starts. */
     const int target_type = cfg->chan_config == 2 ? TYPE_CPE : TYPE_SCE;
@@ -747,22 +791,26 @@ int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
         case TYPE_FIL: {
             if (elem_id == 15) elem_id += (int)bits(&b, 8) - 1;
             if (bits_left(&b) < 8 * elem_id) return HEAAC_PARSE_ERR_OVERREAD;
-            /* decode_extension_payload (:1650-1690): every payload type is `cnt` bytes here; an SBR
-             * payload is located here and parsed by sbr_parse.c */
-            if (elem_id > 0) {
-                const int type = (int)bits(&b, 4);
-                if ((type == EXT_SBR_DATA || type == EXT_SBR_DATA_CRC) && fi.channels && fi.sbr_payload_bit < 0) {
-                    fi.sbr_payload_bit = b.pos;
-                    fi.sbr_payload_bytes = elem_id;
-                    fi.sbr_crc = type == EXT_SBR_DATA_CRC;
-                }
-                b.pos += 8 * elem_id - 4;
+            /* an SBR payload is located here and parsed by sbr_parse.c.  decode_extension_payload hands it to the
+             * channel element last seen, together with the type of the element directly in front (:2059) */
+            int at, bytes = 0, crc = 0;
+            read_fil(&b, elem_id, &at, &bytes, &crc);
+            if (at >= 0) {
+                if (!last_che) return HEAAC_PARSE_ERR_DATA;            /* "SBR was found before the first channel element" */
+                if (last_che == TYPE_CCE + 1) return HEAAC_PARSE_ERR_UNSUPPORTED;   /* the coupling element's own SBR */
+                if (fi.sbr_payload_bit >= 0) return HEAAC_PARSE_ERR_UNSUPPORTED;    /* a second payload for the element */
+                fi.sbr_payload_bit = at;
+                fi.sbr_payload_bytes = bytes;
+                fi.sbr_crc = crc;
+                fi.sbr_misplaced = prev_type != TYPE_SCE && prev_type != TYPE_CPE;
             }
             break;
         }
         default:
             return HEAAC_PARSE_ERR_UNSUPPORTED;
         }
+        if (elem < TYPE_DSE) last_che = elem + 1;
+        prev_type = elem;
         if (b.over) return HEAAC_PARSE_ERR_OVERREAD;
         if (bits_left(&b) < 3) return HEAAC_PARSE_ERR_OVERREAD;
     }
@@ -971,7 +1019,7 @@ int heaac_aac_parse_frame_layout_ex(const HeaacAacConfig *cfg, HeaacAacLayout *l
     for (int e = 0; e < ne; e++) elem[e].sbr_payload_bit = -1;
     uint8_t seen[4][16];
     memset(seen, 0, sizeof(seen));
-    int n_seen = 0, prev_slot = -1, prev_is_output = 0, type, r;
+    int n_seen = 0, prev_slot = -1, last_is_cce = 0, prev_type = TYPE_END, type, r;
     /* coupling elements: slot k of the layout's list; lists[k] until the output elements are all known */
     WinInfo wc[HEAAC_MAX_CCE];
     HeaacCceFrame cbase[HEAAC_MAX_CCE];
@@ -1031,19 +1079,19 @@ int heaac_aac_parse_frame_layout_ex(const HeaacAacConfig *cfg, HeaacAacLayout *l
             int cnt = tag;
             if (cnt == 15) cnt += (int)bits(&b, 8) - 1;
             if (bits_left(&b) < 8 * cnt) return HEAAC_PARSE_ERR_OVERREAD;
-            if (cnt > 0) {
-                const int ext = (int)bits(&b, 4);
-                if (ext == EXT_SBR_DATA || ext == EXT_SBR_DATA_CRC) {
-                    /* decode_extension_payload (:1650-1690) hands the payload to the element in front of it */
-                    if (prev_slot < 0) return HEAAC_PARSE_ERR_DATA;    /* "SBR was found before the first channel element" */
-                    if (!prev_is_output) return HEAAC_PARSE_ERR_UNSUPPORTED;
-                    if (elem[prev_slot].type != TYPE_LFE) {
-                        elem[prev_slot].sbr_payload_bit = b.pos;
-                        elem[prev_slot].sbr_payload_bytes = cnt;
-                        elem[prev_slot].sbr_crc = ext == EXT_SBR_DATA_CRC;
-                    }
-                }
-                b.pos += 8 * cnt - 4;
+            int at, bytes = 0, crc = 0;
+            read_fil(&b, cnt, &at, &bytes, &crc);
+            if (at >= 0) {
+                /* decode_extension_payload (:1650-1690) hands the payload to the channel element last seen, and to its
+                 * SBR reader the type of the element directly in front (:2059): anything but that element itself and
+                 * the reader switches the element's SBR off (aacsbr.c:996-1000) -- so it does for an LFE */
+                if (prev_slot < 0 && !last_is_cce) return HEAAC_PARSE_ERR_DATA;   /* "SBR was found before the first channel element" */
+                if (last_is_cce) return HEAAC_PARSE_ERR_UNSUPPORTED;              /* the coupling element's own SBR */
+                if (elem[prev_slot].sbr_payload_bit >= 0) return HEAAC_PARSE_ERR_UNSUPPORTED;   /* a second payload for the element */
+                elem[prev_slot].sbr_payload_bit = at;
+                elem[prev_slot].sbr_payload_bytes = bytes;
+                elem[prev_slot].sbr_crc = (uint8_t)crc;
+                elem[prev_slot].sbr_misplaced = (uint8_t)(prev_type != TYPE_SCE && prev_type != TYPE_CPE);
             }
             break;
         }
@@ -1051,7 +1099,8 @@ int heaac_aac_parse_frame_layout_ex(const HeaacAacConfig *cfg, HeaacAacLayout *l
             return HEAAC_PARSE_ERR_UNSUPPORTED;
         }
         if (slot >= 0) prev_slot = slot;
-        prev_is_output = slot >= 0;
+        if (type < TYPE_DSE) last_is_cce = type == TYPE_CCE;
+        prev_type = type;
         if (b.over) return HEAAC_PARSE_ERR_OVERREAD;
         if (bits_left(&b) < 3) return HEAAC_PARSE_ERR_OVERREAD;
     }

@@ -6,7 +6,9 @@
 //     draws from ac->random_state as it parses, :1049-1054);
 //   * SBR per element (che->sbr): an element's payload is the fill element directly behind it; once the stream has
 //     SBR (explicitly, or implicitly by a payload in the FIRST access unit, :1666-1675) every element goes through
-//     ff_sbr_apply, with a start = 0 record ("pure upsampling") where it has no payload -- an LFE never has one;
+//     ff_sbr_apply, with a start = 0 record ("pure upsampling") where it has no payload; a payload behind an LFE, or
+//     with another fill / data stream element between it and its element, is read for its header and switches the
+//     element's SBR off (aacsbr.c:996-1000);
 //   * an access unit that leaves an element of the layout out is refused: the reference transforms whatever that
 //     element's buffers still hold from an earlier frame, which no record of this path carries;
 //   * coupling channel elements (AAC-LC / Main streams without SBR): those the program config element names
@@ -313,7 +315,8 @@ int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void
             if (ei.sbr_payload_bit >= 0) {
                 // a failed payload leaves its degraded record (start = 0) and the decode goes on, as ff_sbr_apply does
                 (void)heaac_sbr_parse_payload(&e.sst, d->tab, d->m4ac.sample_rate, buf, size, ei.sbr_payload_bit,
-                                              ei.sbr_payload_bytes, ei.sbr_crc, e.channels, 0, &sbr, NULL, NULL);
+                                              ei.sbr_payload_bytes, ei.sbr_crc, e.channels, ei.sbr_misplaced ? HEAAC_SBR_MISPLACED : 0,
+                                              &sbr, NULL, NULL);
             } else {
                 heaac_sbr_no_payload(&e.sst, e.channels, &sbr, NULL);
             }

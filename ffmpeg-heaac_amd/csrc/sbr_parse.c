@@ -783,8 +783,11 @@ int heaac_sbr_parse_payload(HeaacSbrStream *st, HeaacSbrHeaderTable *tab, int sa
                             HeaacSbrFrame *sbr, HeaacPsFrame *ps, HeaacSbrParseInfo *info)
 {
     if (!st || !tab || !au || !sbr || size < 0 || bit < 0 || bit > 8 * size || cnt < 0 ||
-        (channels != 1 && channels != 2) || (allow_ps && !ps))
+        (channels != 1 && channels != 2) || (allow_ps & ~(HEAAC_SBR_ALLOW_PS | HEAAC_SBR_MISPLACED)) ||
+        ((allow_ps & HEAAC_SBR_ALLOW_PS) && !ps))
         return HEAAC_PARSE_ERR_ARG;
+    const int misplaced = allow_ps & HEAAC_SBR_MISPLACED;
+    allow_ps &= HEAAC_SBR_ALLOW_PS;
     pthread_once(&g_once, tables_init);
     if (g_tables_bad) return HEAAC_PARSE_ERR_ARG;
 
@@ -820,7 +823,12 @@ int heaac_sbr_parse_payload(HeaacSbrStream *st, HeaacSbrHeaderTable *tab, int sa
         }
     }
 
-    if (st->start) {
+    if (st->start && misplaced) {
+        /* read_sbr_data with the type of a fill / data stream / program config element or an LFE (aacsbr.c:996-1000):
+         * "Invalid bitstream - cannot apply SBR to element type %d" */
+        st->start = 0;
+        ret = HEAAC_PARSE_ERR_DATA;
+    } else if (st->start) {
         const HeaacSbrHeader *h = &tab->h[st->hdr];
         const HeaacSbrChanState keep0 = st->data[0], keep1 = st->data[1];
         const uint8_t keep_coupling = st->bs_coupling;
@@ -880,7 +888,8 @@ int heaac_heaac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st, He
     const int r = heaac_aac_parse_frame_ex(cfg, st, au, size, coeff_channels, coeffs, ics, tools, NULL, &fi);
     if (r) return r;                                   /* info->channels = 0: the core element failed */
     if (info) *info = fi;
-    const int allow_ps = cfg->ps != 0 && fi.channels == 1 && ps != NULL;
+    const int allow_ps = (cfg->ps != 0 && fi.channels == 1 && ps != NULL ? HEAAC_SBR_ALLOW_PS : 0) |
+                         (fi.sbr_misplaced ? HEAAC_SBR_MISPLACED : 0);
     if (fi.sbr_payload_bit < 0 || cfg->sbr == 0) {
         heaac_sbr_no_payload(sst, fi.channels, sbr, ps);
         return HEAAC_PARSE_NO_SBR;

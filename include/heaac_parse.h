@@ -128,6 +128,10 @@ typedef struct HeaacAacFrameInfo {
     int sbr_crc;
     int elem_id;                  /* instance tag of the output element */
     int n_cce;                    /* coupling elements found (heaac_aac_parse_frame_ex, heaac_aac_parse_frame_layout_ex) */
+    int sbr_misplaced;            /* 1: the payload's fill element does not stand directly behind the SCE / CPE: the
+                                     reference hands its SBR reader the type of the element in between, which reads a
+                                     header if there is one and then switches the element's SBR off (aacdec.c:2059,
+                                     aacsbr.c:996-1000).  Pass HEAAC_SBR_MISPLACED to heaac_sbr_parse_payload. */
 } HeaacAacFrameInfo;
 
 /* What heaac_aac_parse_frame_ex adds for access units that carry coupling channel elements: per slot (ascending
@@ -228,10 +232,11 @@ typedef struct HeaacAacElementInfo {
     uint8_t seq;                  /* position among the access unit's output elements (bitstream order: the order the
                                    * noise generator of heaac_spectral_tools_batch has to run through them) */
     uint8_t sbr_crc;
-    uint8_t pad[3];
-    int32_t sbr_payload_bit;      /* as in HeaacAacFrameInfo: the EXT_SBR_DATA fill payload DIRECTLY behind the element,
-                                   * -1: none.  Behind an LFE the reference's SBR reader refuses the payload and the
-                                   * element stays "pure upsampling" (aacsbr.c:989-1000): reported as none. */
+    uint8_t sbr_misplaced;        /* as in HeaacAacFrameInfo; also 1 behind an LFE, whose type the SBR reader refuses
+                                   * the same way (aacsbr.c:986-1000) */
+    uint8_t pad[2];
+    int32_t sbr_payload_bit;      /* as in HeaacAacFrameInfo: the first EXT_SBR_DATA fill payload behind the element
+                                   * (before the next channel element), -1: none */
     int32_t sbr_payload_bytes;
 } HeaacAacElementInfo;
 
@@ -365,6 +370,7 @@ typedef struct HeaacSbrStream {
 void   heaac_sbr_stream_init(HeaacSbrStream *st, size_t n);
 size_t heaac_sbr_stream_bytes(void);
 
+enum { HEAAC_SBR_ALLOW_PS = 1, HEAAC_SBR_MISPLACED = 2 };
 typedef struct HeaacSbrParseInfo {
     int sbr_bits;                 /* num_sbr_bits of ff_decode_sbr_extension, crc and header included */
     int header;                   /* 1: the payload carried a header */
@@ -374,8 +380,9 @@ typedef struct HeaacSbrParseInfo {
 
 /* One SBR payload: `bit` = position in `au` just after the 4-bit extension type (HeaacAacFrameInfo.
  * sbr_payload_bit), cnt = the fill element's byte count, crc = EXT_SBR_DATA_CRC, channels = 1 (SCE) or
- * 2 (CPE), allow_ps = m4ac.ps != 0.  `ps` may be NULL when allow_ps is 0.  sample_rate = the AAC core's
- * (the SBR tables are built for twice that, aacsbr.c:1056).
+ * 2 (CPE), allow_ps = HEAAC_SBR_ALLOW_PS when m4ac.ps != 0 (`ps` may be NULL without it), plus
+ * HEAAC_SBR_MISPLACED for a payload the frame parser flagged so (header read, then SBR off: a start = 0 record and
+ * HEAAC_PARSE_ERR_DATA).  sample_rate = the AAC core's (the SBR tables are built for twice that, aacsbr.c:1056).
  * Returns HEAAC_PARSE_OK, or a negative error with the records written as described above. */
 int heaac_sbr_parse_payload(HeaacSbrStream *st, HeaacSbrHeaderTable *tab, int sample_rate,
                             const uint8_t *au, int size, int bit, int cnt, int crc,

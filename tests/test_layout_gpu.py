@@ -136,21 +136,24 @@ def test_codec_decodes_multichannel_streams(pkg, oracle, dev, mode):
     ref_rng = np.full(1, 0x1f2e3d4c, np.int32)
     tab = pkg.SbrHeaderTable(64)
     sst = pkg.sbr_streams(ne)
-    writers = {k: SW.SbrStreamWriter(pkg, 2 if t == CPE else 1) for k, (t, _) in enumerate(elems) if t != LFE}
+    writers = {k: SW.SbrStreamWriter(pkg, 2 if t == CPE else 1) for k, (t, _) in enumerate(elems)}
+    # an LFE with SBR payloads of its own (mode he_5_1, frames 1 and 3): the reference's SBR reader takes their headers
+    # and refuses the data (aacsbr.c:996-1000)
+    lfe_payload = lambda t: mode == "he_5_1" and t in (1, 3)
     out = (C.c_int16 * (192000 // 2))()
-    loud = 0
+    loud = lfe_headers = 0
     for t in range(5):
         payloads = None
         if he:
             payloads = []
             for k, (typ, _) in enumerate(elems):
-                if typ == LFE:
+                if typ == LFE and not lfe_payload(t):
                     payloads.append(None)
                     continue
                 w = writers[k]
                 while True:
                     keep = copy.deepcopy((w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling))
-                    bits, _ = w.frame(rng, new_header=(t == 3 and k == 1), respec=(t == 3 and k == 1))
+                    bits, _ = w.frame(rng, new_header=(t == 3 and k == 1) or typ == LFE, respec=(t == 3 and (k == 1 or typ == LFE)))
                     if (4 + len(bits) + 7) // 8 <= 269:
                         break
                     w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling = keep
@@ -188,10 +191,14 @@ def test_codec_decodes_multichannel_streams(pkg, oracle, dev, mode):
                 ei = p["elem"][e]
                 if int(ei["sbr_payload_bit"]) >= 0:
                     rr, sbr, _, _ = pkg.sbr_parse_payload(sst[e], tab, 24000, pkt_bytes, c, False, bit=int(ei["sbr_payload_bit"]),
-                                                          cnt=int(ei["sbr_payload_bytes"]))
-                    assert rr == 0
+                                                          cnt=int(ei["sbr_payload_bytes"]), misplaced=bool(ei["sbr_misplaced"]))
+                    assert rr == (-1 if ei["sbr_misplaced"] else 0)
+                    assert bool(ei["sbr_misplaced"]) == (int(layout[0]["elem"][e]["type"]) == LFE)
+                    if ei["sbr_misplaced"]:
+                        assert int(sbr["start"][0]) == 0 and int(sbr["hdr"][0]) > 0
+                        lfe_headers += 1
                 else:
-                    sbr = pkg.sbr_no_payload(sst[e], c)              # an LFE: never started ("pure upsampling")
+                    sbr = pkg.sbr_no_payload(sst[e], c)              # an LFE without a payload ("pure upsampling")
                     assert int(layout[0]["elem"][e]["type"]) == LFE
                 pcm, state[e] = oracle.he_decode_batch(pkg.CFG_HEV1 if c == 2 else pkg.CFG_HEV1_MONO, spec[e], ics, sbr,
                                                        tab.headers(), None, state[e], oracle.PCM_F32, downsampled=down)
@@ -202,7 +209,7 @@ def test_codec_decodes_multichannel_streams(pkg, oracle, dev, mode):
         want = oracle.float_to_int16_interleave(planes)
         assert np.array_equal(got, want), ("frame %d" % t, np.argwhere(got != want)[:4])
         loud = max(loud, int(np.abs(got.astype(int)).max()))
-    assert loud > 50
+    assert loud > 50 and lfe_headers == (2 if mode == "he_5_1" else 0)
     # an access unit that leaves an element out is refused (the reference would transform stale buffers)
     au, _ = TL.build(rng, si, aot, elems[:-1], extras=False)
     pkt_bytes = _adts(au, aot, si, cc) if how == "adts" else au

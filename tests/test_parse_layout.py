@@ -131,10 +131,11 @@ def build(rng, si, aot, elems, sbr_prob=0.0, extras=True, payloads=None, lead=No
 def check_slot(got, slot, e, si, seq):
     rec = got["elem"][slot]
     assert (int(rec["present"]), int(rec["type"]), int(rec["tag"]), int(rec["seq"])) == (1, e["type"], e["tag"], seq)
-    lfe_sbr = e["type"] == LFE
-    assert int(rec["sbr_payload_bit"]) == (-1 if lfe_sbr else e["sbr_bit"])
-    if e["sbr_bit"] >= 0 and not lfe_sbr:
+    assert int(rec["sbr_payload_bit"]) == e["sbr_bit"]
+    if e["sbr_bit"] >= 0:
         assert int(rec["sbr_payload_bytes"]) == e["sbr_bytes"] and int(rec["sbr_crc"]) == e["sbr_crc"]
+        # the SBR reader is handed the type of the element in front (aacdec.c:2059) and refuses an LFE's (aacsbr.c:996-1000)
+        assert int(rec["sbr_misplaced"]) == int(e["type"] == LFE or e.get("sbr_misplaced", 0))
     wrapped = dict(tools=got["tools"][slot:slot + 1], ics=got["ics"][slot:slot + 1], coeffs=got["coeffs"][slot:slot + 1])
     for c, d in enumerate(e["ch"]):
         TP._check_channel(wrapped, 0, c, d, e["sf"][c], si)
@@ -206,11 +207,12 @@ def test_duplicate_tags_move_up_and_an_sce_may_stand_for_the_lfe(pkg):
     for seq, (slot, e) in enumerate(zip([1, 0, 3, 2], exp)):
         check_slot(got, slot, e, si, seq)
     assert int(got["elem"][2]["sbr_payload_bit"]) >= 0
-    # a real LFE with a payload behind it: the reference's SBR reader refuses it, the element stays without SBR
+    # a real LFE with a payload behind it: the reference's SBR reader is handed the LFE's type and switches SBR off
     r, l = pkg.aac_layout_default(6)
     au, exp = build(rng, si, aot, [(SCE, 0), (CPE, 0), (CPE, 1), (LFE, 0)], sbr_prob=1.0, extras=False)
     r, got = pkg.aac_parse_frame_layout(TP._cfg(pkg, aot, si, 6), l, st, au)
-    assert r == 0 and int(got["elem"][2]["sbr_payload_bit"]) == -1 and int(got["elem"][3]["sbr_payload_bit"]) >= 0
+    assert r == 0 and int(got["elem"][2]["sbr_payload_bit"]) >= 0 and int(got["elem"][2]["sbr_misplaced"]) == 1
+    assert int(got["elem"][3]["sbr_payload_bit"]) >= 0 and int(got["elem"][3]["sbr_misplaced"]) == 0
 
 
 def test_what_a_layout_has_no_place_for_is_refused(pkg):
@@ -243,7 +245,13 @@ def test_what_a_layout_has_no_place_for_is_refused(pkg):
     r, l = pkg.aac_layout_default(3)
     assert pkg.aac_parse_frame_layout(TP._cfg(pkg, aot, si, 3), l, st.copy(), bw.bytes())[0] == -1
     bw = W.BitWriter()
-    write_elem(bw, rng, si, aot, SCE, 0); write_dse(bw, rng); write_fill(bw, rng, 0xd, 5); bw.put(7, 3)
+    write_elem(bw, rng, si, aot, SCE, 0); write_dse(bw, rng); at = write_fill(bw, rng, 0xd, 5); bw.put(7, 3)
+    r, l = pkg.aac_layout_default(3)
+    r, got = pkg.aac_parse_frame_layout(TP._cfg(pkg, aot, si, 3), l, st.copy(), bw.bytes())
+    assert r == 0 and int(got["elem"][1]["sbr_payload_bit"]) == at and int(got["elem"][1]["sbr_misplaced"]) == 1
+    # a second payload for the same element (the reference would run its SBR reader twice over one frame's state)
+    bw = W.BitWriter()
+    write_elem(bw, rng, si, aot, SCE, 0); write_fill(bw, rng, 0xd, 5); write_fill(bw, rng, 0xe, 7); bw.put(7, 3)
     r, l = pkg.aac_layout_default(3)
     assert pkg.aac_parse_frame_layout(TP._cfg(pkg, aot, si, 3), l, st.copy(), bw.bytes())[0] == -3
     # a failed unit leaves the window history alone
@@ -253,6 +261,126 @@ def test_what_a_layout_has_no_place_for_is_refused(pkg):
     s1 = s0.copy()
     assert pkg.aac_parse_frame_layout(TP._cfg(pkg, aot, si, 3), l, s1, au[:len(au) // 2])[0] < 0
     assert s1.tobytes() == s0.tobytes()
+
+
+def write_drc(bw, rng):
+    """dynamic_range_info() behind its type nibble (decode_dynamic_range, aacdec.c:1596-1641); returns its length in
+    bytes, the nibble's byte included."""
+    bw.put(0xb, 4)
+    n, bands = 1, 1
+    f = int(rng.integers(0, 2)); bw.put(f, 1)
+    if f:
+        bw.put(int(rng.integers(0, 16)), 4); bw.put(0, 4); n += 1
+    f = int(rng.integers(0, 2)); bw.put(f, 1)
+    if f:
+        rounds = int(rng.integers(1, 4))
+        for k in range(rounds):
+            bw.put(int(rng.integers(0, 128)), 7); bw.put(int(k < rounds - 1), 1)
+        n += rounds
+    f = int(rng.integers(0, 2)); bw.put(f, 1)
+    if f:
+        incr = int(rng.integers(0, 5))
+        bw.put(incr, 4); bw.put(int(rng.integers(0, 16)), 4); n += 1
+        bands += incr
+        for _ in range(bands):
+            bw.put(int(rng.integers(0, 256)), 8)
+        n += bands
+    f = int(rng.integers(0, 2)); bw.put(f, 1)
+    if f:
+        bw.put(int(rng.integers(0, 128)), 7); bw.put(0, 1); n += 1
+    for _ in range(bands):
+        bw.put(int(rng.integers(0, 256)), 8)
+    return n + bands
+
+
+def put_fil_count(bw, cnt):
+    bw.put(6, 3)
+    if cnt >= 15:
+        bw.put(15, 4); bw.put(cnt - 14, 8)
+    else:
+        bw.put(cnt, 4)
+
+
+@pytest.mark.parametrize("layout", [False, True])
+def test_fill_elements_hold_several_payloads_and_sbr_goes_to_the_element_in_front(pkg, layout):
+    """aac_decode_frame :2050-2060 walks a fill element payload by payload; dynamic range control says its own length
+    (decode_dynamic_range :1596-1641), every other payload takes what is left.  An SBR payload goes to the channel
+    element last seen, its reader is handed the type of the element DIRECTLY in front (:2059) and switches SBR off for
+    anything but an SCE / CPE (aacsbr.c:996-1000): reported as `sbr_misplaced`."""
+    rng = np.random.default_rng(40 + layout)
+    si, aot = 3, 2
+
+    def parse(au):
+        if layout:
+            r, l = pkg.aac_layout_default(3)
+            r, got = pkg.aac_parse_frame_layout(TP._cfg(pkg, aot, si, 3), l, np.zeros(pkg.MAX_ELEMENTS, pkg.AAC_STREAM_DT), au)
+            e = got["elem"][1]                             # the SCE of a 3.0 layout
+            return r, int(e["sbr_payload_bit"]), int(e["sbr_payload_bytes"]), int(e["sbr_crc"]), int(e["sbr_misplaced"]), got
+        r, got = pkg.aac_parse_frame_ex(TP._cfg(pkg, aot, si, 1), np.zeros(1, pkg.AAC_STREAM_DT), au, coeff_channels=1)
+        i = got["info"][0]
+        return r, int(i["sbr_payload_bit"]), int(i["sbr_payload_bytes"]), int(i["sbr_crc"]), int(i["sbr_misplaced"]), got
+
+    def noise(bw, nbits):
+        for _ in range(nbits):
+            bw.put(int(rng.integers(0, 2)), 1)
+    for trial in range(60):
+        case = trial % 6
+        bw = W.BitWriter()
+        write_elem(bw, rng, si, aot, SCE, 0)
+        want = None
+        if case == 0:       # dynamic range control alone, exactly as long as it says; the SBR payload in the next fill element
+            body = W.BitWriter(); n = write_drc(body, rng)
+            put_fil_count(bw, n); bw.bits.extend(body.bits)
+            at = write_fill(bw, rng, 0xd, 9)
+            want = (at, 9, 0, 1)                           # ... whose predecessor is a fill element: SBR off
+        elif case == 1:     # dynamic range control, then the SBR payload inside the SAME fill element
+            body = W.BitWriter(); n = write_drc(body, rng)
+            extra = int(rng.integers(2, 12))
+            put_fil_count(bw, n + extra); bw.bits.extend(body.bits)
+            crc = int(rng.integers(0, 2))
+            bw.put(0xe if crc else 0xd, 4)
+            at = len(bw.bits)
+            noise(bw, 8 * extra - 4)
+            want = (at, extra, crc, 0)                     # directly behind the SCE
+        elif case == 2:     # two dynamic range payloads and plain fill in one element; no SBR
+            body = W.BitWriter(); n = write_drc(body, rng) + write_drc(body, rng)
+            extra = int(rng.integers(1, 6))
+            put_fil_count(bw, n + extra); bw.bits.extend(body.bits)
+            bw.put(int(rng.choice([0, 1, 2, 5])), 4); noise(bw, 8 * extra - 4)
+        elif case == 3:     # dynamic range control longer than its fill element says: the reader ends up past it
+            body = W.BitWriter(); n = write_drc(body, rng)
+            short = int(rng.integers(1, n + 1)) if n > 1 else 1
+            put_fil_count(bw, short); bw.bits.extend(body.bits)
+            if short == n:
+                at = write_fill(bw, rng, 0xd, 4); want = (at, 4, 0, 1)
+            else:
+                crc_at = write_fill(bw, rng, 0xe, 6); want = (crc_at, 6, 1, 1)
+        elif case == 4:     # a data stream element between the element and its payload
+            write_dse(bw, rng)
+            at = write_fill(bw, rng, 0xd, 7); want = (at, 7, 0, 1)
+        else:               # the ordinary case
+            at = write_fill(bw, rng, 0xd, 11); want = (at, 11, 0, 0)
+            write_fill(bw, rng, 0x0, int(rng.integers(0, 5)))
+        if layout:
+            write_elem(bw, rng, si, aot, CPE, 0)
+        bw.put(7, 3)
+        r, bit, nbytes, crc, misplaced, got = parse(bw.bytes())
+        assert r == 0, (trial, r)
+        assert (bit, nbytes, crc, misplaced) == (want if want else (-1, 0, 0, 0)), (trial, case)
+        assert int(got["info"][0]["bits_consumed"]) == len(bw.bits)
+    # a second SBR payload for the same element; one in front of every channel element
+    bw = W.BitWriter()
+    write_elem(bw, rng, si, aot, SCE, 0); write_fill(bw, rng, 0xd, 5); write_fill(bw, rng, 0xd, 5)
+    if layout:
+        write_elem(bw, rng, si, aot, CPE, 0)
+    bw.put(7, 3)
+    assert parse(bw.bytes())[0] == -3
+    bw = W.BitWriter()
+    write_fill(bw, rng, 0xd, 5); write_elem(bw, rng, si, aot, SCE, 0)
+    if layout:
+        write_elem(bw, rng, si, aot, CPE, 0)
+    bw.put(7, 3)
+    assert parse(bw.bytes())[0] == -1
 
 
 def write_pce_body(bw, rng, front, side, back, lfe, cc=()):

@@ -180,6 +180,39 @@ def test_malformed_grids_drop_the_element_and_keep_the_stream(pkg, case):
     _same(sbr, exp["sbr"], "after the bad frame")
 
 
+def test_payload_handed_over_with_the_wrong_element_type_switches_sbr_off(pkg):
+    """A payload that does not stand directly behind its SCE / CPE (or stands behind an LFE) reaches read_sbr_data
+    with the type of the element in between: the header, if it carries one, is read and applied, then "cannot apply
+    SBR to element type %d" and start = 0 (aacsbr.c:996-1000) -- until the next header."""
+    rng = np.random.default_rng(77)
+    tab = pkg.SbrHeaderTable(8)
+    st = pkg.sbr_streams(1)
+    w = SW.SbrStreamWriter(pkg, 1, ps=False)
+    bits, exp = w.frame(rng)
+    r, sbr0, _, _ = pkg.sbr_parse_payload(st[0], tab, 24000, SW.to_bytes(bits), 1, False)
+    assert r == 0 and sbr0["start"][0] == 1 and sbr0["hdr"][0] == 1
+    before = st.copy()
+    # no header: nothing but the flag is read
+    bits, _ = w.frame(rng)
+    r, sbr, _, info = pkg.sbr_parse_payload(st[0], tab, 24000, SW.to_bytes(bits), 1, False, misplaced=True)
+    assert r == -1 and sbr["start"][0] == 0 and sbr["hdr"][0] == 1 and info["header"] == 0 and info["sbr_bits"] == 1
+    assert pkg.validate_frame(pkg.CFG_HEV1_MONO, sbr, tab.headers(), None) == "NONE"
+    assert (st != before).sum() <= 4                              # start and the "old" range: no channel data
+    # without a header the stream stays off, placed right or not
+    bits, _ = w.frame(rng)
+    r, sbr, _, _ = pkg.sbr_parse_payload(st[0], tab, 24000, SW.to_bytes(bits), 1, False)
+    assert r == 0 and sbr["start"][0] == 0
+    # a misplaced payload WITH a new header: the header takes effect (tables, kx / m), the data is not read
+    bits, exp = w.frame(rng, new_header=True, respec=True)
+    r, sbr, _, info = pkg.sbr_parse_payload(st[0], tab, 24000, SW.to_bytes(bits), 1, False, misplaced=True)
+    assert r == -1 and sbr["start"][0] == 0 and info["header"] == 1 and sbr["reset"][0] == 1
+    assert tab.headers()[int(sbr["hdr"][0])].tobytes() == exp["hdr"][0].tobytes()
+    # the next header brings it back
+    bits, exp = w.frame(rng, new_header=True)
+    r, sbr, _, _ = pkg.sbr_parse_payload(st[0], tab, 24000, SW.to_bytes(bits), 1, False)
+    assert r == 0 and sbr["start"][0] == 1
+
+
 def test_header_that_cannot_build_tables_switches_to_upsampling(pkg):
     """sbr_reset failing (aacsbr.c:1022-1033): start = 0, no table entry is made."""
     tab = pkg.SbrHeaderTable(8)
