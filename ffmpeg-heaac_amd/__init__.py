@@ -123,7 +123,7 @@ EXPORTED = [
     # heaac_codec.h
     "heaac_aac_decoder", "heaac_codec_open", "heaac_codec_decode", "heaac_codec_close",
     # heaac_parse.h
-    "heaac_asc_parse", "heaac_ga_specific_config", "heaac_aac_parse_frame_ex", "heaac_pcm_interleave_batch", "heaac_aac_layout_default", "heaac_aac_layout_from_pce", "heaac_asc_layout", "heaac_aac_parse_frame_layout", "heaac_aac_parse_frame_layout_ex", "heaac_spectral_tools_batch_ex", "heaac_codec_get_context_defaults", "heaac_adts_parse_header", "heaac_adts_probe", "heaac_adts_split",
+    "heaac_asc_parse", "heaac_ga_specific_config", "heaac_aac_parse_frame_ex", "heaac_pcm_interleave_batch", "heaac_aac_layout_default", "heaac_aac_layout_from_pce", "heaac_aac_layout_from_au", "heaac_asc_layout", "heaac_aac_parse_frame_layout", "heaac_aac_parse_frame_layout_ex", "heaac_spectral_tools_batch_ex", "heaac_codec_get_context_defaults", "heaac_adts_parse_header", "heaac_adts_probe", "heaac_adts_split",
     "heaac_heaac_parse_frame_ex", "heaac_pipeline_create", "heaac_pipeline_destroy", "heaac_pipeline_submit",
     "heaac_pipeline_collect", "heaac_pipeline_timing",
     "heaac_multi_shard", "heaac_multi_create", "heaac_multi_destroy", "heaac_multi_devices", "heaac_multi_device",
@@ -591,6 +591,13 @@ def aac_layout_from_pce(buf, bit_offset):
     buf = bytes(buf)
     r = lib().heaac_aac_layout_from_pce(l.ctypes.data_as(C.c_void_p), buf, len(buf), int(bit_offset), C.byref(used))
     return r, l, used.value
+
+
+def aac_layout_from_au(au):
+    """heaac_aac_layout_from_au: (status, layout)."""
+    l = np.zeros(1, AAC_LAYOUT_DT)
+    au = bytes(au)
+    return lib().heaac_aac_layout_from_au(l.ctypes.data_as(C.c_void_p), au, len(au)), l
 
 
 def asc_layout(buf):

@@ -937,6 +937,42 @@ int heaac_aac_layout_from_pce(HeaacAacLayout *l, const uint8_t *buf, int size, i
     return 0;
 }
 
+int heaac_aac_layout_from_au(HeaacAacLayout *l, const uint8_t *au, int size)
+{
+    if (!l || !au || size <= 0) return HEAAC_PARSE_ERR_ARG;
+    Bits b;
+    bits_init(&b, au, size);
+    if (peek(&b, 12) == 0xfff) {
+        HeaacAdtsHeader h;
+        const int hs = heaac_adts_parse_header(&h, au, size);
+        if (hs < 0) return HEAAC_PARSE_ERR_DATA;
+        b.pos = hs * 8;
+    }
+    /* aac_decode_frame's element loop (:1999-2075) as far as the first program config element: with nothing allocated
+     * yet only data stream and fill elements can stand in front of it */
+    int type, r;
+    while ((type = (int)bits(&b, 3)) != TYPE_END) {
+        int tag = (int)bits(&b, 4);
+        if (type == TYPE_PCE) {
+            if (b.over) return HEAAC_PARSE_ERR_OVERREAD;
+            return heaac_aac_layout_from_pce(l, au, size, b.pos, NULL);
+        }
+        if (type == TYPE_DSE) {
+            if ((r = skip_dse(&b)) < 0) return r;
+        } else if (type == TYPE_FIL) {
+            if (tag == 15) tag += (int)bits(&b, 8) - 1;
+            if (bits_left(&b) < 8 * tag) return HEAAC_PARSE_ERR_OVERREAD;
+            int at, bytes, crc;
+            read_fil(&b, tag, &at, &bytes, &crc);
+            if (at >= 0) return HEAAC_PARSE_ERR_DATA;                  /* "SBR was found before the first channel element" */
+        } else {
+            return HEAAC_PARSE_ERR_DATA;                               /* "channel element %d.%d is not allocated" */
+        }
+        if (b.over || bits_left(&b) < 3) return HEAAC_PARSE_ERR_OVERREAD;
+    }
+    return HEAAC_PARSE_ERR_DATA;                                       /* no program: nothing this stream could decode */
+}
+
 int heaac_asc_layout(HeaacAacConfig *c, HeaacAacLayout *l, const uint8_t *buf, int size)
 {
     if (!c || !l) return HEAAC_PARSE_ERR_ARG;

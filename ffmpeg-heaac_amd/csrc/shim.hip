@@ -456,13 +456,12 @@ static int dec_frame_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p, vo
         // this way in asks nothing of them: an SSR or LTP profile stream decodes as AAC-LC does until an element uses
         // what the reference lacks (gain control :1373, the predictor bit :694), which fails that frame.
         if (ah.chan_config != 1 && ah.chan_config != 2) {
-            // set_default_channel_config (:1946), or -- channel configuration 0 -- the program config element the
-            // raw data block starts with (:2036-2046, OC_TRIAL_PCE)
+            // set_default_channel_config (:1946), or -- channel configuration 0 -- the program config element ahead of
+            // the raw data block's channel elements (:2036-2046, OC_TRIAL_PCE)
             if (ah.chan_config) {
                 if (heaac_aac_layout_default(&p->layout, ah.chan_config) < 0) return -1;
             } else {
-                if (size < hs + 2 || (buf[hs] >> 5) != 5) return -1;              // id_syn_ele PCE
-                if (heaac_aac_layout_from_pce(&p->layout, buf, size, hs * 8 + 7, NULL) < 0) return -1;
+                if (heaac_aac_layout_from_au(&p->layout, buf, size) < 0) return -1;
             }
             if (!(p->lay = heaac_layout_dec_create(p->dev, &p->m4ac, &p->layout))) return -1;
             p->have_layout = 1;

@@ -219,6 +219,12 @@ int heaac_aac_layout_default(HeaacAacLayout *l, int chan_config);
  * than HEAAC_MAX_LAYOUT_CHANNELS channels. */
 int heaac_aac_layout_from_pce(HeaacAacLayout *l, const uint8_t *buf, int size, int bit_offset, int *bits_used);
 
+/* The layout of a stream that configures itself: the program config element an access unit of a channel-
+ * configuration-0 ADTS stream carries ahead of its channel elements (aac_decode_frame :2036-2046, OC_TRIAL_PCE).  `au`
+ * with or without its ADTS header; data stream and fill elements may stand in front of the program config element.
+ * HEAAC_PARSE_ERR_DATA when a channel element (nothing is allocated yet) or an SBR payload comes first, or there is none. */
+int heaac_aac_layout_from_au(HeaacAacLayout *l, const uint8_t *au, int size);
+
 /* AudioSpecificConfig -> configuration and layout in one step (decode_audio_specific_config, aacdec.c:462-493):
  * heaac_asc_parse, the GASpecificConfig checks, and the layout of its channel configuration or of the program
  * config element it carries.  Returns 0 or a negative HEAAC_PARSE_ERR_*. */

@@ -202,6 +202,8 @@ int main(int argc, char **argv)
                 v |= chs != pl.channels || chs > HEAAC_MAX_LAYOUT_CHANNELS;
                 if (v) { layout_bad++; if (layout_bad < 5) printf("iteration %ld: layout out of range\n", it); }
             }
+            /* and as the first access unit of a stream that configures itself */
+            if (heaac_aac_layout_from_au(&pl, au, (int)len) == 0 && (pl.n_elements < 0 || pl.n_elements > HEAAC_MAX_ELEMENTS)) layout_bad++;
             free(au);
             continue;
         }

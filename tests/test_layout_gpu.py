@@ -160,7 +160,9 @@ def test_codec_decodes_multichannel_streams(pkg, oracle, dev, mode):
                 payloads.append(bits)
         lead = None
         if how == "adts" and cc == 0:
-            lead = lambda bw: (bw.put(5, 3), bw.put(0, 4), TL.write_pce_body(bw, np.random.default_rng(1), *pce_elems))
+            # a data stream and a fill element may stand in front of the program config element (first frame)
+            lead = lambda bw: (TL.write_dse(bw, rng) if t == 0 else None, TL.write_fill(bw, rng, 0x1, 3) if t == 0 else None,
+                               bw.put(5, 3), bw.put(0, 4), TL.write_pce_body(bw, np.random.default_rng(1), *pce_elems))
         au, _ = TL.build(rng, si, aot, elems, extras=t & 1, payloads=payloads, lead=lead)
         pkt_bytes = _adts(au, aot, si, cc) if how == "adts" else au
         buf = C.create_string_buffer(pkt_bytes, len(pkt_bytes))

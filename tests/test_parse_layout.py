@@ -554,6 +554,37 @@ def test_coupling_elements_of_a_program_config_layout(pkg):
     assert pkg.aac_parse_frame_layout(cfg, l0.copy(), st.copy(), bw.bytes(), with_cce=True)[0] == -1
 
 
+def test_a_self_configuring_stream_finds_its_program_config_element(pkg):
+    """aac_decode_frame evaluates a program config element wherever it stands ahead of the channel elements while
+    nothing is configured (:2036-2046); data stream and fill elements in front of it are read past."""
+    from test_shim_gpu import _adts
+    rng = np.random.default_rng(37)
+    si, aot = 3, 2
+    for trial in range(20):
+        bw = W.BitWriter()
+        for _ in range(int(rng.integers(0, 3))):
+            write_dse(bw, rng) if rng.random() < 0.5 else write_fill(bw, rng, int(rng.choice([0, 1, 2])), int(rng.integers(0, 20)))
+        if rng.random() < 0.5:
+            body = W.BitWriter(); n = write_drc(body, rng)
+            put_fil_count(bw, n); bw.bits.extend(body.bits)
+        bw.put(5, 3); bw.put(int(rng.integers(0, 16)), 4)
+        write_pce_body(bw, rng, [(0, 0), (1, 0)], [], [(1, 1)], [0], cc=[(1, 7)])
+        write_elem(bw, rng, si, aot, SCE, 0)
+        bw.put(7, 3)
+        au = bw.bytes()
+        for pkt in (au, _adts(au, aot, si, 0)):
+            r, l = pkg.aac_layout_from_au(pkt)
+            assert r == 0 and slots(l) == [(SCE, 0), (CPE, 0), (LFE, 0), (CPE, 1)] and int(l[0]["tag_map"][CCE][7]) == 1
+    # a channel element first (nothing is allocated), an SBR payload first, no program at all, a truncated unit
+    bw = W.BitWriter(); write_elem(bw, rng, si, aot, SCE, 0); bw.put(7, 3)
+    assert pkg.aac_layout_from_au(bw.bytes())[0] == -1
+    bw = W.BitWriter(); write_fill(bw, rng, 0xd, 6); bw.put(5, 3); bw.put(0, 4); write_pce_body(bw, rng, [(0, 0)], [], [], []); bw.put(7, 3)
+    assert pkg.aac_layout_from_au(bw.bytes())[0] == -1
+    bw = W.BitWriter(); write_dse(bw, rng); bw.put(7, 3)
+    assert pkg.aac_layout_from_au(bw.bytes())[0] == -1
+    assert pkg.aac_layout_from_au(au[:2])[0] in (-1, -2)
+
+
 def test_audio_specific_config_with_and_without_a_program_config_element(pkg):
     rng = np.random.default_rng(34)
     for cc in range(1, 8):
