@@ -369,7 +369,9 @@ static void publish_cfg(HeaacCodecContext *avctx, HeaacDecoderPriv *p)
     p->downsampled = he && p->bitstream && heaac_sbr_output_mode(&p->m4ac) == 1;
     if (he) p->out_len = p->downsampled ? 1024 : 2048;
     avctx->channels = p->nout;
-    avctx->channel_layout = p->nout == 2 ? HEAAC_CH_LAYOUT_STEREO : HEAAC_CH_LAYOUT_MONO;   // output_configure, aacdec.c:224-301
+    // output_configure (aacdec.c:247): aac_channel_layout[channel_config - 1] -- by the channel CONFIGURATION, so a mono
+    // stream decoded with Parametric Stereo has two channels and says AV_CH_LAYOUT_MONO
+    avctx->channel_layout = p->ncore == 2 ? HEAAC_CH_LAYOUT_STEREO : HEAAC_CH_LAYOUT_MONO;
     avctx->frame_size = p->out_len;
     avctx->sample_rate = he && !p->downsampled ? 2 * p->m4ac.sample_rate : p->m4ac.sample_rate;
 }
@@ -566,7 +568,7 @@ static int dec_init(HeaacCodecContext *avctx)
     for (int i = 0; i < MAX_HDRS; i++) p->hdr[i].kx = 32;      // kx' = 32, m = 0 (aacsbr.c:130)
     if (hipMemcpy(p->d_hdr, p->hdr, sizeof(p->hdr), hipMemcpyHostToDevice) != hipSuccess) return -1;
     avctx->channels = p->nout;
-    avctx->channel_layout = p->nout == 2 ? HEAAC_CH_LAYOUT_STEREO : HEAAC_CH_LAYOUT_MONO;
+    avctx->channel_layout = p->ncore == 2 ? HEAAC_CH_LAYOUT_STEREO : HEAAC_CH_LAYOUT_MONO;   // as publish_cfg
     avctx->frame_size = p->out_len;
     if (!avctx->sample_rate) avctx->sample_rate = 48000;
     return 0;

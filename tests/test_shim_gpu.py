@@ -245,6 +245,8 @@ def test_codec_decodes_access_units(pkg, oracle, dev, mode):
         used = lib.heaac_codec_decode(C.byref(ctx), out, C.byref(size), C.byref(pkt))
         assert used == len(pkt_bytes), (t, used)                       # only zero padding follows the END element
         assert (ctx.channels, ctx.frame_size) == (pkg.OUT_CH[hcfg], length), t
+        # aac_channel_layout[channel_config - 1] (aacdec.c:247): a mono stream says MONO even with two PS channels out
+        assert ctx.channel_layout == (0x3 if cpe else 0x4), t
         assert ctx.sample_rate == (24000 if mode == "sbr_too_late" or down else 48000)
         assert size.value == length * pkg.OUT_CH[hcfg] * 2
         got = np.frombuffer(out, np.int16, size.value // 2).reshape(length, pkg.OUT_CH[hcfg]).copy()
