@@ -11,7 +11,7 @@
 //     element's SBR off (aacsbr.c:996-1000);
 //   * an access unit that leaves an element of the layout out is refused: the reference transforms whatever that
 //     element's buffers still hold from an earlier frame, which no record of this path carries;
-//   * coupling channel elements (AAC-LC / Main streams without SBR): those the program config element names
+//   * coupling channel elements (independent ones: streams without SBR only): those the program config element names
 //     (che_configure allocates no others).  They are individual channel streams of their own -- tools, and an
 //     IMDCT when they couple AFTER_IMDCT -- processed before their targets (spectral_to_sample walks the element
 //     types downwards, :1907); dependent coupling sits around a target's TNS, independent coupling behind its
@@ -203,8 +203,13 @@ int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void
         n_cce += cce_here[k];
         if (c->seen[k] && !cce_here[k]) return -1;
     }
-    if (n_cce) {
-        // coupling together with SBR (apply_independent_coupling over 1024 << sbr samples) is outside this path
+    int cce_after = 0;
+    for (int k = 0; k < HEAAC_MAX_CCE; k++)
+        cce_after += cce_here[k] && c->h_cce[0][k].coupling_point == HEAAC_CC_AFTER_IMDCT;
+    if (cce_after) {
+        // Independent coupling together with SBR is outside this path: the coupling channel goes through ff_sbr_apply
+        // itself (:1924-1926) and couples over 1024 << sbr samples (:1858).  Dependent coupling happens in the spectrum,
+        // before any of that, and is the same with and without SBR.
         int sbr = d->m4ac.sbr;
         if (!d->locked && sbr == -1)
             for (int i = 0; i < d->n; i++)

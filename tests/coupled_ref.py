@@ -20,19 +20,26 @@ def pce_args(elems, cc_tags):
     return front, [], [], [g for t, g in elems if t == LFE], [(int(k & 1), g) for k, g in enumerate(cc_tags)]
 
 
-def asc(aot, si, elems, cc_tags, rng):
-    """AudioSpecificConfig with channel configuration 0 and the program config element inside."""
+def asc(aot, si, elems, cc_tags, rng, he=False):
+    """AudioSpecificConfig with channel configuration 0 and the program config element inside; he: SBR signalled by
+    the backward-compatible sync extension behind it (object type 5 in front would leave ps = -1, which the reference
+    turns into Parametric Stereo channels for every SCE of the layout, aacdec.c:476-477, :203-206)."""
     bw = W.BitWriter()
     bw.put(aot, 5); bw.put(si, 4); bw.put(0, 4)
     bw.put(0, 3)                                           # GASpecificConfig: 1024 samples, no core coder, no extension
     bw.put(0, 4)                                           # element_instance_tag
     a = pce_args(elems, cc_tags)
     TL.write_pce_body(bw, rng, *a[:4], cc=a[4])
+    if he:
+        bw.put(0x2b7, 11); bw.put(5, 5); bw.put(1, 1); bw.put(si - 3, 4)      # syncExtensionType, SBR, present, rate
+        bw.put(0x548, 11); bw.put(0, 1)                                        # PS signalled absent
+        bw.put(0, 16)
     return bw.bytes()
 
 
-def write_unit(rng, si, aot, elems, tags, points, quiet=False):
-    """One access unit: the output elements in a random order, the coupling elements `tags` anywhere between them."""
+def write_unit(rng, si, aot, elems, tags, points, quiet=False, payloads=None):
+    """One access unit: the output elements in a random order, the coupling elements `tags` anywhere between them;
+    payloads: {index into elems: bits of an SBR payload for the fill element behind that element}."""
     order = list(range(len(elems)))
     rng.shuffle(order)
     at = sorted(int(x) for x in rng.integers(0, len(elems) + 1, len(tags)))
@@ -51,17 +58,26 @@ def write_unit(rng, si, aot, elems, tags, points, quiet=False):
             k += 1
         if pos < len(elems):
             TL.write_elem(bw, rng, si, aot, *elems[order[pos]], quiet=quiet)
+            bits = payloads.get(order[pos]) if payloads else None
+            if bits is not None:
+                cnt = (4 + len(bits) + 7) // 8
+                TL.put_fil_count(bw, cnt)
+                bw.put(0xd, 4)
+                bw.bits.extend(bits)
+                bw.bits.extend([0] * (8 * cnt - 4 - len(bits)))
     bw.put(7, 3)
     return bw.bytes()
 
 
 class Checker:
-    def __init__(self, pkg, oracle, m4, layout, aot):
-        self.pkg, self.oracle, self.m4, self.layout, self.aot = pkg, oracle, m4, layout, aot
+    def __init__(self, pkg, oracle, m4, layout, aot, he=False):
+        self.pkg, self.oracle, self.m4, self.layout, self.aot, self.he = pkg, oracle, m4, layout, aot, he
         self.ne, self.nch = int(layout[0]["n_elements"]), int(layout[0]["channels"])
         self.slot_ch = [int(layout[0]["elem"][e]["channels"]) for e in range(self.ne)]
         self.st = np.zeros(pkg.MAX_ELEMENTS, pkg.AAC_STREAM_DT)
-        self.state = [np.zeros((1, 512 * c), np.float32) for c in self.slot_ch]
+        self.state = [np.zeros((1, pkg.STATE_WORDS[pkg.CFG_HEV1 if c == 2 else pkg.CFG_HEV1_MONO] if he else 512 * c), np.float32)
+                      for c in self.slot_ch]
+        self.tab, self.sst = pkg.SbrHeaderTable(64), pkg.sbr_streams(self.ne)
         fresh = lambda c: np.tile(np.array([0, 0, 1, 1, 0, 0], np.float32), (1, c * pkg.MAX_PREDICTORS, 1)).reshape(1, -1)
         self.pred = [fresh(c) for c in self.slot_ch]
         self.cpred = [fresh(1) for _ in range(pkg.MAX_CCE)]
@@ -109,8 +125,20 @@ class Checker:
             c = self.slot_ch[e]
             post, _, _ = oracle.spectral_tools_batch_ex(c, oracle.TOOLS_POST, pre[e], g["tools"][e:e + 1], cce=g["cce"][e][None],
                                                         cce_coeffs=cc)
-            f32, self.state[e] = oracle.lc_decode_batch(c, post, np.ascontiguousarray(g["ics"][e:e + 1, :c]), self.state[e],
-                                                        oracle.PCM_F32)
+            ics = np.ascontiguousarray(g["ics"][e:e + 1, :c])
+            if self.he:
+                ei = g["elem"][e]
+                if int(ei["sbr_payload_bit"]) >= 0:
+                    rr, sbr, _, _ = pkg.sbr_parse_payload(self.sst[e], self.tab, self.m4.sample_rate, au, c, False,
+                                                          bit=int(ei["sbr_payload_bit"]), cnt=int(ei["sbr_payload_bytes"]),
+                                                          misplaced=bool(ei["sbr_misplaced"]))
+                    assert rr == (-1 if ei["sbr_misplaced"] else 0)
+                else:
+                    sbr = pkg.sbr_no_payload(self.sst[e], c)
+                f32, self.state[e] = oracle.he_decode_batch(pkg.CFG_HEV1 if c == 2 else pkg.CFG_HEV1_MONO, post, ics, sbr,
+                                                            self.tab.headers(), None, self.state[e], oracle.PCM_F32)
+            else:
+                f32, self.state[e] = oracle.lc_decode_batch(c, post, ics, self.state[e], oracle.PCM_F32)
             for k in range(pkg.MAX_CCE):
                 rec = g["cce"][e, k]
                 if not rec["present"]:

@@ -98,6 +98,8 @@ STREAMS = {
     "mono_independent": (2, [(SCE, 0)], [5], [3]),
     "five_one": (2, [(SCE, 0), (CPE, 0), (CPE, 1), (LFE, 0)], [3, 9], [0, 1, 3]),
     "main_three": (1, [(SCE, 2), (CPE, 4)], [7], [0, 1, 3]),
+    # dependent coupling in an HE-AAC stream: in the spectrum, before the IMDCT and SBR of the targets
+    "he_three_dependent": (2, [(SCE, 0), (CPE, 0), (LFE, 1)], [4, 11], [0, 1]),
 }
 
 
@@ -108,26 +110,41 @@ def test_codec_decodes_access_units_with_coupling_elements(pkg, oracle, dev, nam
     every target's TNS and independent coupling behind its IMDCT, onto one and onto several output elements, the
     coupling elements anywhere between them; state chained over six frames.  int16 PCM against tests/coupled_ref.py
     (the oracle's tools, coupling, IMDCTs and interleave on the separately parsed records)."""
+    import copy
     import coupled_ref as R
+    import sbr_bitwriter as SW
     from test_shim_gpu import HeaacCodecContext, HeaacPacket
     lib = pkg.lib()
     aot, elems, cc_tags, points = STREAMS[name]
     rng = np.random.default_rng(sum(map(ord, name)))
-    si = 3
-    asc = R.asc(aot, si, elems, cc_tags, rng)
+    he = name.startswith("he_")
+    si = 6 if he else 3
+    length = 2048 if he else 1024
+    asc = R.asc(aot, si, elems, cc_tags, rng, he=he)
+    writers = {k: SW.SbrStreamWriter(pkg, 2 if t == CPE else 1) for k, (t, _) in enumerate(elems) if t != LFE} if he else {}
     ctx = HeaacCodecContext(cfg=-1, extradata=asc, extradata_size=len(asc))
     codec = C.c_void_p.in_dll(lib, "heaac_aac_decoder")
     assert lib.heaac_codec_open(C.byref(ctx), C.c_void_p(C.addressof(codec))) == 0
     r, m4, layout = pkg.asc_layout(asc)
     assert r == 0
-    chk = R.Checker(pkg, oracle, m4, layout, aot)
+    assert m4.sbr == (1 if he else -1) and m4.ps == 0 if he else True
+    chk = R.Checker(pkg, oracle, m4, layout, aot, he=he)
     assert ctx.channels == chk.nch
     out = (C.c_int16 * (192000 // 2))()
     loud = 0
 
     def unit(tags, check=True):
+        payloads = {}
+        for k, w in writers.items():
+            while True:
+                keep = copy.deepcopy((w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling))
+                bits, _ = w.frame(rng)
+                if (4 + len(bits) + 7) // 8 <= 269:
+                    break
+                w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling = keep
+            payloads[k] = bits
         while True:
-            au = R.write_unit(rng, si, aot, elems, tags, points)
+            au = R.write_unit(rng, si, aot, elems, tags, points, quiet=he, payloads=payloads)
             if not check or chk.parses(au):
                 return au
 
@@ -140,12 +157,18 @@ def test_codec_decodes_access_units_with_coupling_elements(pkg, oracle, dev, nam
     for t in range(6):
         au = unit(cc_tags)
         used, size = decode(au)
-        assert used == len(au) and size == 1024 * chk.nch * 2, (t, used)
-        got = np.frombuffer(out, np.int16, 1024 * chk.nch).reshape(1024, chk.nch).copy()
+        assert used == len(au) and size == length * chk.nch * 2, (t, used)
+        got = np.frombuffer(out, np.int16, length * chk.nch).reshape(length, chk.nch).copy()
         want, _ = chk.frame(au)
         assert np.array_equal(got, want), ("frame %d" % t, np.argwhere(got != want)[:4])
         loud = max(loud, int(np.abs(got.astype(int)).max()))
     assert loud > 50 and (chk.dependent >= 2 or points == [3]) and (chk.independent >= 2 or 3 not in points)
+    if he:
+        # independent coupling together with SBR stays outside (the coupling channel would go through ff_sbr_apply itself)
+        keep_points = points[:]
+        points[:] = [3]
+        assert decode(unit(cc_tags))[0] < 0
+        points[:] = keep_points
     # a coupling element the stream has carried so far is left out: refused, as an output element would be (the
     # reference couples whatever the element's buffers still hold)
     assert decode(unit([]))[0] < 0
