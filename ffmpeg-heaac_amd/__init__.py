@@ -547,7 +547,7 @@ class Pipeline:
 
 
 class _CceOut(C.Structure):
-    _fields_ = [("cce", C.c_void_p), ("coeffs", C.c_void_p), ("ics", C.c_void_p), ("tools", C.c_void_p)]
+    _fields_ = [("cce", C.c_void_p), ("coeffs", C.c_void_p), ("ics", C.c_void_p), ("tools", C.c_void_p), ("elem", C.c_void_p)]
 
 
 def aac_parse_frame_ex(cfg, stream, au, coeff_channels=2, with_cce=True):
@@ -612,7 +612,8 @@ def aac_parse_frame_layout(cfg, layout, streams, au, with_cce=False):
     """heaac_aac_parse_frame_layout (with_cce: heaac_aac_parse_frame_layout_ex) on one access unit.  layout: one
     AAC_LAYOUT_DT record (its tag map is updated), streams: AAC_STREAM_DT [n_elements] (updated).  Returns (status,
     dict(coeffs [ne][2][1024], ics [ne][2], tools [ne], elem [ne], info; with_cce: cce [ne][MAX_CCE], cce_coeffs
-    [MAX_CCE][1024], cce_ics [MAX_CCE], cce_tools [MAX_CCE]))."""
+    [MAX_CCE][1024], cce_ics [MAX_CCE], cce_tools [MAX_CCE], cce_elem [MAX_CCE] (not handed over when
+    with_cce == "no_sbr")))."""
     au = bytes(au)
     ne = int(layout[0]["n_elements"])
     assert streams.dtype == AAC_STREAM_DT and streams.shape[0] >= ne
@@ -625,9 +626,10 @@ def aac_parse_frame_layout(cfg, layout, streams, au, with_cce=False):
     if not with_cce:
         return lib().heaac_aac_parse_frame_layout(*args, out["info"].ctypes.data_as(C.c_void_p)), out
     out.update(cce=np.zeros((ne, MAX_CCE), CCE_FRAME_DT), cce_coeffs=np.zeros((MAX_CCE, 1024), np.float32),
-               cce_ics=np.zeros(MAX_CCE, ICS_DT), cce_tools=np.zeros(MAX_CCE, TOOLS_FRAME_DT))
+               cce_ics=np.zeros(MAX_CCE, ICS_DT), cce_tools=np.zeros(MAX_CCE, TOOLS_FRAME_DT),
+               cce_elem=np.zeros(MAX_CCE, AAC_ELEM_INFO_DT))
     co = _CceOut(out["cce"].ctypes.data, out["cce_coeffs"].ctypes.data, out["cce_ics"].ctypes.data,
-                 out["cce_tools"].ctypes.data)
+                 out["cce_tools"].ctypes.data, out["cce_elem"].ctypes.data if with_cce != "no_sbr" else None)
     return lib().heaac_aac_parse_frame_layout_ex(*args, C.byref(co), out["info"].ctypes.data_as(C.c_void_p)), out
 
 

@@ -1055,7 +1055,7 @@ int heaac_aac_parse_frame_layout_ex(const HeaacAacConfig *cfg, HeaacAacLayout *l
     for (int e = 0; e < ne; e++) elem[e].sbr_payload_bit = -1;
     uint8_t seen[4][16];
     memset(seen, 0, sizeof(seen));
-    int n_seen = 0, prev_slot = -1, last_is_cce = 0, prev_type = TYPE_END, type, r;
+    int n_seen = 0, prev_slot = -1, last_cce = -1, prev_type = TYPE_END, type, r;      /* last_cce: the channel element last seen is coupling slot k */
     /* coupling elements: slot k of the layout's list; lists[k] until the output elements are all known */
     WinInfo wc[HEAAC_MAX_CCE];
     HeaacCceFrame cbase[HEAAC_MAX_CCE];
@@ -1063,6 +1063,10 @@ int heaac_aac_parse_frame_layout_ex(const HeaacAacConfig *cfg, HeaacAacLayout *l
     int n_cce = 0;
     memset(cbase, 0, sizeof(cbase));
     if (cce) memset(cce->cce, 0, (size_t)ne * HEAAC_MAX_CCE * sizeof(HeaacCceFrame));
+    if (cce && cce->elem) {
+        memset(cce->elem, 0, HEAAC_MAX_CCE * sizeof(*cce->elem));
+        for (int k = 0; k < HEAAC_MAX_CCE; k++) cce->elem[k].sbr_payload_bit = -1;
+    }
     while ((type = (int)bits(&b, 3)) != TYPE_END) {
         int tag = (int)bits(&b, 4);
         int slot = -1;
@@ -1103,6 +1107,13 @@ int heaac_aac_parse_frame_layout_ex(const HeaacAacConfig *cfg, HeaacAacLayout *l
             if (r < 0) return r;
             cbase[k].outputs_before = (uint8_t)n_seen;
             cbase[k].seq = (uint8_t)n_cce++;
+            last_cce = k;
+            if (cce->elem) {
+                cce->elem[k].present = 1;
+                cce->elem[k].type = TYPE_CCE;
+                cce->elem[k].tag = (uint8_t)tag;
+                cce->elem[k].seq = cbase[k].seq;
+            }
             break;
         }
         case TYPE_DSE:
@@ -1121,13 +1132,20 @@ int heaac_aac_parse_frame_layout_ex(const HeaacAacConfig *cfg, HeaacAacLayout *l
                 /* decode_extension_payload (:1650-1690) hands the payload to the channel element last seen, and to its
                  * SBR reader the type of the element directly in front (:2059): anything but that element itself and
                  * the reader switches the element's SBR off (aacsbr.c:996-1000) -- so it does for an LFE */
-                if (prev_slot < 0 && !last_is_cce) return HEAAC_PARSE_ERR_DATA;   /* "SBR was found before the first channel element" */
-                if (last_is_cce) return HEAAC_PARSE_ERR_UNSUPPORTED;              /* the coupling element's own SBR */
-                if (elem[prev_slot].sbr_payload_bit >= 0) return HEAAC_PARSE_ERR_UNSUPPORTED;   /* a second payload for the element */
-                elem[prev_slot].sbr_payload_bit = at;
-                elem[prev_slot].sbr_payload_bytes = bytes;
-                elem[prev_slot].sbr_crc = (uint8_t)crc;
-                elem[prev_slot].sbr_misplaced = (uint8_t)(prev_type != TYPE_SCE && prev_type != TYPE_CPE);
+                if (prev_slot < 0 && last_cce < 0) return HEAAC_PARSE_ERR_DATA;   /* "SBR was found before the first channel element" */
+                HeaacAacElementInfo *to;
+                if (last_cce >= 0) {
+                    /* the coupling element's own SBR (it goes through ff_sbr_apply when it couples AFTER_IMDCT, :1924) */
+                    if (!cce->elem) return HEAAC_PARSE_ERR_UNSUPPORTED;
+                    to = &cce->elem[last_cce];
+                } else {
+                    to = &elem[prev_slot];
+                }
+                if (to->sbr_payload_bit >= 0) return HEAAC_PARSE_ERR_UNSUPPORTED;  /* a second payload for the element */
+                to->sbr_payload_bit = at;
+                to->sbr_payload_bytes = bytes;
+                to->sbr_crc = (uint8_t)crc;
+                to->sbr_misplaced = (uint8_t)(prev_type != TYPE_SCE && prev_type != TYPE_CPE && prev_type != TYPE_CCE);
             }
             break;
         }
@@ -1135,7 +1153,7 @@ int heaac_aac_parse_frame_layout_ex(const HeaacAacConfig *cfg, HeaacAacLayout *l
             return HEAAC_PARSE_ERR_UNSUPPORTED;
         }
         if (slot >= 0) prev_slot = slot;
-        if (type < TYPE_DSE) last_is_cce = type == TYPE_CCE;
+        if (type < TYPE_DSE && type != TYPE_CCE) last_cce = -1;
         prev_type = type;
         if (b.over) return HEAAC_PARSE_ERR_OVERREAD;
         if (bits_left(&b) < 3) return HEAAC_PARSE_ERR_OVERREAD;

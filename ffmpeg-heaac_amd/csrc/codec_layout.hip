@@ -11,7 +11,7 @@
 //     element's SBR off (aacsbr.c:996-1000);
 //   * an access unit that leaves an element of the layout out is refused: the reference transforms whatever that
 //     element's buffers still hold from an earlier frame, which no record of this path carries;
-//   * coupling channel elements (independent ones: streams without SBR only): those the program config element names
+//   * coupling channel elements: those the program config element names
 //     (che_configure allocates no others).  They are individual channel streams of their own -- tools, and an
 //     IMDCT when they couple AFTER_IMDCT -- processed before their targets (spectral_to_sample walks the element
 //     types downwards, :1907); dependent coupling sits around a target's TNS, independent coupling behind its
@@ -23,6 +23,7 @@
 #include "codec_layout.h"
 
 #define LAY_MAX_HDRS 64
+#define CCE_STATE_WORDS HEAAC_STATE_WORDS_HEV1_MONO
 
 struct LayElem {
     int cfg_lc, cfg_he, channels;
@@ -43,14 +44,18 @@ struct LayCoupled {
     float h_coeffs[HEAAC_MAX_CCE][1024];
     HeaacIcs h_ics[HEAAC_MAX_CCE];
     HeaacToolsFrame h_tools[HEAAC_MAX_CCE];
+    HeaacAacElementInfo h_elem[HEAAC_MAX_CCE];                       // where each stands, the SBR payload behind it
+    HeaacSbrStream sst[HEAAC_MAX_CCE];                               // a coupling channel's own SBR (che->sbr)
+    HeaacSbrFrame *d_sbr;         // [MAX_CCE]
     HeaacCceFrame *d_cce;         // [n_elements][MAX_CCE]
     float *d_coeffs;              // [MAX_CCE][1024]
     HeaacIcs *d_ics;
     HeaacToolsFrame *d_tools;
-    float *d_state;               // [MAX_CCE][512] overlap of the coupling channels (AFTER_IMDCT elements)
+    float *d_state;               // [MAX_CCE][CCE_STATE_WORDS] state of the coupling channels that couple AFTER_IMDCT:
+                                  // the overlap, and behind SBR everything a mono element has
     HeaacPredictorState *d_pred;  // [MAX_CCE][672]
-    float *d_ret;                 // [MAX_CCE][1024] the coupling channels' own output
-    HeaacCoupling *d_gain;
+    float *d_ret;                 // [MAX_CCE][2048] the coupling channels' own output
+    HeaacCoupling *d_gain;        // [2]
     int seen[HEAAC_MAX_CCE];      // an earlier access unit carried this coupling element
 };
 
@@ -86,6 +91,7 @@ static void coupled_free(LayCoupled *c)
     if (c->d_pred) (void)hipFree(c->d_pred);
     if (c->d_ret) (void)hipFree(c->d_ret);
     if (c->d_gain) (void)hipFree(c->d_gain);
+    if (c->d_sbr) (void)hipFree(c->d_sbr);
     free(c);
 }
 
@@ -98,11 +104,13 @@ static LayCoupled *coupled_alloc(const HeaacPredictorState *ps_reset)
         hipMalloc((void **)&c->d_coeffs, sizeof(c->h_coeffs)) == hipSuccess &&
         hipMalloc((void **)&c->d_ics, sizeof(c->h_ics)) == hipSuccess &&
         hipMalloc((void **)&c->d_tools, sizeof(c->h_tools)) == hipSuccess &&
-        hipMalloc((void **)&c->d_state, HEAAC_MAX_CCE * 512 * 4) == hipSuccess &&
+        hipMalloc((void **)&c->d_state, HEAAC_MAX_CCE * CCE_STATE_WORDS * 4) == hipSuccess &&
         hipMalloc((void **)&c->d_pred, HEAAC_MAX_CCE * HEAAC_MAX_PREDICTORS * sizeof(*ps_reset)) == hipSuccess &&
-        hipMalloc((void **)&c->d_ret, HEAAC_MAX_CCE * 1024 * 4) == hipSuccess &&
-        hipMalloc((void **)&c->d_gain, sizeof(HeaacCoupling)) == hipSuccess &&
-        hipMemset(c->d_state, 0, HEAAC_MAX_CCE * 512 * 4) == hipSuccess;
+        hipMalloc((void **)&c->d_ret, HEAAC_MAX_CCE * 2048 * 4) == hipSuccess &&
+        hipMalloc((void **)&c->d_gain, 2 * sizeof(HeaacCoupling)) == hipSuccess &&
+        hipMalloc((void **)&c->d_sbr, HEAAC_MAX_CCE * sizeof(HeaacSbrFrame)) == hipSuccess &&
+        hipMemset(c->d_state, 0, HEAAC_MAX_CCE * CCE_STATE_WORDS * 4) == hipSuccess;
+    heaac_sbr_stream_init(c->sst, HEAAC_MAX_CCE);
     for (int k = 0; ok && k < HEAAC_MAX_CCE; k++)
         ok = hipMemcpy(c->d_pred + k * HEAAC_MAX_PREDICTORS, ps_reset, HEAAC_MAX_PREDICTORS * sizeof(*ps_reset),
                        hipMemcpyHostToDevice) == hipSuccess;
@@ -189,8 +197,8 @@ int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void
     HeaacAacStream st[HEAAC_MAX_ELEMENTS];
     for (int i = 0; i < d->n; i++) st[i] = d->e[i].ast;
     LayCoupled *c = d->cpl;
-    HeaacCceOut co = { NULL, NULL, NULL, NULL };
-    if (c) { co.cce = &c->h_cce[0][0]; co.coeffs = &c->h_coeffs[0][0]; co.ics = c->h_ics; co.tools = c->h_tools; }
+    HeaacCceOut co = { NULL, NULL, NULL, NULL, NULL };
+    if (c) { co.cce = &c->h_cce[0][0]; co.coeffs = &c->h_coeffs[0][0]; co.ics = c->h_ics; co.tools = c->h_tools; co.elem = c->h_elem; }
     if (heaac_aac_parse_frame_layout_ex(&d->m4ac, &d->layout, st, buf, size, d->h_coeffs, &d->h_ics[0][0], d->h_tools,
                                         d->h_elem, c ? &co : NULL, &fi) != HEAAC_PARSE_OK)
         return -1;
@@ -202,19 +210,6 @@ int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void
         cce_here[k] = c->h_cce[0][k].present;
         n_cce += cce_here[k];
         if (c->seen[k] && !cce_here[k]) return -1;
-    }
-    int cce_after = 0;
-    for (int k = 0; k < HEAAC_MAX_CCE; k++)
-        cce_after += cce_here[k] && c->h_cce[0][k].coupling_point == HEAAC_CC_AFTER_IMDCT;
-    if (cce_after) {
-        // Independent coupling together with SBR is outside this path: the coupling channel goes through ff_sbr_apply
-        // itself (:1924-1926) and couples over 1024 << sbr samples (:1858).  Dependent coupling happens in the spectrum,
-        // before any of that, and is the same with and without SBR.
-        int sbr = d->m4ac.sbr;
-        if (!d->locked && sbr == -1)
-            for (int i = 0; i < d->n; i++)
-                if (d->h_elem[i].sbr_payload_bit >= 0) sbr = 1;
-        if (sbr == 1) return -1;
     }
     for (int i = 0; i < d->n; i++) d->e[i].ast = st[i];
     for (int k = 0; k < HEAAC_MAX_CCE; k++)
@@ -231,6 +226,8 @@ int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void
             d->m4ac.sbr = 0;
             for (int i = 0; i < d->n; i++)
                 if (d->h_elem[i].sbr_payload_bit >= 0) d->m4ac.sbr = 1;
+            for (int k = 0; c && k < HEAAC_MAX_CCE; k++)
+                if (cce_here[k] && c->h_elem[k].sbr_payload_bit >= 0) d->m4ac.sbr = 1;
         }
         d->locked = 1;
     }
@@ -253,6 +250,19 @@ int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void
          hipMemcpy(c->d_ics, c->h_ics, sizeof(c->h_ics), hipMemcpyHostToDevice) != hipSuccess ||
          hipMemcpy(c->d_tools, c->h_tools, sizeof(c->h_tools), hipMemcpyHostToDevice) != hipSuccess))
         return -1;
+    // header records the SBR readers have added to the table since the last upload
+    auto sync_headers = [&]() -> int {
+        const size_t have = heaac_sbr_table_count(d->tab);
+        if (have > d->hdr_uploaded) {
+            memcpy(d->hdr + d->hdr_uploaded, heaac_sbr_table_data(d->tab) + d->hdr_uploaded,
+                   (have - d->hdr_uploaded) * sizeof(HeaacSbrHeader));
+            if (hipMemcpy(d->d_hdr + d->hdr_uploaded, d->hdr + d->hdr_uploaded,
+                          (have - d->hdr_uploaded) * sizeof(HeaacSbrHeader), hipMemcpyHostToDevice) != hipSuccess)
+                return -1;
+            d->hdr_uploaded = have;
+        }
+        return 0;
+    };
     // A coupling element's tools as a whole at its place in the stream (nothing couples INTO it); an output element's
     // first half there, its second half -- coupling, TNS, coupling -- once every coupling element is through.
     auto cce_tools = [&](int outputs_before) -> int {
@@ -286,12 +296,35 @@ int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void
                                               c->d_cce + (size_t)i * HEAAC_MAX_CCE, c->d_coeffs, HEAAC_MAX_CCE, 1, NULL) != HEAAC_OK)
                 return -1;
         }
-        // the coupling channels that couple behind the IMDCT: their own IMDCT first (type 2 before types 1 and 0)
-        for (int k = 0; k < HEAAC_MAX_CCE; k++)
-            if (cce_here[k] && c->h_cce[0][k].coupling_point == HEAAC_CC_AFTER_IMDCT &&
-                heaac_lc_decode_batch(d->dev, 1, c->d_coeffs + k * 1024, c->d_ics + k, c->d_state + k * 512, c->d_state + k * 512,
-                                      c->d_ret + k * 1024, HEAAC_PCM_F32_PLANAR, 1, NULL) != HEAAC_OK)
+        // the coupling channels that couple behind the IMDCT: their own IMDCT -- and SBR, as a mono element's
+        // (:1920-1927) -- first (type 2 before types 1 and 0).  A payload behind a coupling element that couples in
+        // the spectrum is read all the same (decode_extension_payload does not look at the coupling point).
+        for (int k = 0; k < HEAAC_MAX_CCE; k++) {
+            if (!cce_here[k]) continue;
+            const bool after = c->h_cce[0][k].coupling_point == HEAAC_CC_AFTER_IMDCT;
+            float *st_k = c->d_state + (size_t)k * CCE_STATE_WORDS;
+            if (!he) {
+                if (after && heaac_lc_decode_batch(d->dev, 1, c->d_coeffs + k * 1024, c->d_ics + k, st_k, st_k, c->d_ret + k * 2048,
+                                                   HEAAC_PCM_F32_PLANAR, 1, NULL) != HEAAC_OK)
+                    return -1;
+                continue;
+            }
+            HeaacSbrFrame sbr;
+            const HeaacAacElementInfo &ei = c->h_elem[k];
+            if (ei.sbr_payload_bit >= 0)
+                (void)heaac_sbr_parse_payload(&c->sst[k], d->tab, d->m4ac.sample_rate, buf, size, ei.sbr_payload_bit, ei.sbr_payload_bytes,
+                                              ei.sbr_crc, 1, ei.sbr_misplaced ? HEAAC_SBR_MISPLACED : 0, &sbr, NULL, NULL);
+            else if (after)
+                heaac_sbr_no_payload(&c->sst[k], 1, &sbr, NULL);
+            if (!after) continue;
+            if (sync_headers()) return -1;
+            if (heaac_validate_frame(HEAAC_CFG_HEV1_MONO, &sbr, d->hdr, LAY_MAX_HDRS, NULL)) return -1;
+            if (hipMemcpy(c->d_sbr + k, &sbr, sizeof(sbr), hipMemcpyHostToDevice) != hipSuccess) return -1;
+            if (heaac_he_decode_batch_ex(d->dev, HEAAC_CFG_HEV1_MONO, mode ? HEAAC_HE_DOWNSAMPLED : 0, c->d_coeffs + k * 1024, c->d_ics + k,
+                                         c->d_sbr + k, d->d_hdr, LAY_MAX_HDRS, NULL, st_k, st_k, c->d_ret + k * 2048,
+                                         HEAAC_PCM_F32_PLANAR, 1, NULL) != HEAAC_OK)
                 return -1;
+        }
     }
     HeaacPlaneRef planes[HEAAC_MAX_PCM_PLANES];
     for (int i = 0; i < d->n; i++) {
@@ -300,20 +333,6 @@ int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void
         if (!he) {
             rc = heaac_lc_decode_batch(d->dev, e.channels, e.d_coeffs, e.d_ics, e.d_state, e.d_state, e.d_f32,
                                        HEAAC_PCM_F32_PLANAR, 1, NULL);
-            // every AFTER_IMDCT element in tag order, every gain list it lands on this element (apply_channel_coupling)
-            for (int k = 0; rc == HEAAC_OK && k < HEAAC_MAX_CCE; k++) {
-                if (!cce_here[k] || c->h_cce[i][k].coupling_point != HEAAC_CC_AFTER_IMDCT) continue;
-                for (int l = 0; l < c->h_cce[i][k].n_links; l++) {
-                    HeaacCoupling g;
-                    memset(&g, 0, sizeof(g));
-                    const int t = c->h_cce[i][k].link[l].target_ch;
-                    g.on[t] = 1;
-                    g.gain[t] = c->h_cce[i][k].link[l].gain[0];
-                    if (hipMemcpy(c->d_gain, &g, sizeof(g), hipMemcpyHostToDevice) != hipSuccess) return -1;
-                    if (heaac_couple_after_imdct_batch(d->dev, e.channels, e.d_f32, c->d_ret + k * 1024, c->d_gain, NULL, 1, NULL) != HEAAC_OK)
-                        return -1;
-                }
-            }
         } else {
             HeaacSbrFrame sbr;
             const HeaacAacElementInfo &ei = d->h_elem[i];
@@ -325,21 +344,29 @@ int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void
             } else {
                 heaac_sbr_no_payload(&e.sst, e.channels, &sbr, NULL);
             }
-            const size_t have = heaac_sbr_table_count(d->tab);
-            if (have > d->hdr_uploaded) {
-                memcpy(d->hdr + d->hdr_uploaded, heaac_sbr_table_data(d->tab) + d->hdr_uploaded,
-                       (have - d->hdr_uploaded) * sizeof(HeaacSbrHeader));
-                if (hipMemcpy(d->d_hdr + d->hdr_uploaded, d->hdr + d->hdr_uploaded,
-                              (have - d->hdr_uploaded) * sizeof(HeaacSbrHeader), hipMemcpyHostToDevice) != hipSuccess)
-                    return -1;
-                d->hdr_uploaded = have;
-            }
+            if (sync_headers()) return -1;
             if (heaac_validate_frame(e.cfg_he, &sbr, d->hdr, LAY_MAX_HDRS, NULL)) return -1;
             if (hipMemcpy(e.d_sbr, &sbr, sizeof(sbr), hipMemcpyHostToDevice) != hipSuccess) return -1;
             rc = heaac_he_decode_batch_ex(d->dev, e.cfg_he, mode ? HEAAC_HE_DOWNSAMPLED : 0, e.d_coeffs, e.d_ics, e.d_sbr, d->d_hdr,
                                           LAY_MAX_HDRS, NULL, e.d_state, e.d_state, e.d_f32, HEAAC_PCM_F32_PLANAR, 1, NULL);
         }
         if (rc != HEAAC_OK) return -1;
+        // every AFTER_IMDCT element in tag order, every gain list it lands on this element (apply_channel_coupling
+        // :1870-1898; apply_independent_coupling :1849-1862 over 1024 << sbr samples): one target channel at a time,
+        // its plane and the coupling channel's as len / 1024 "frames" of the batched op
+        for (int k = 0; k < HEAAC_MAX_CCE; k++) {
+            if (!cce_here[k] || c->h_cce[i][k].coupling_point != HEAAC_CC_AFTER_IMDCT) continue;
+            for (int l = 0; l < c->h_cce[i][k].n_links; l++) {
+                HeaacCoupling g[2];
+                memset(g, 0, sizeof(g));
+                g[0].on[0] = g[1].on[0] = 1;
+                g[0].gain[0] = g[1].gain[0] = c->h_cce[i][k].link[l].gain[0];
+                if (hipMemcpy(c->d_gain, g, sizeof(g), hipMemcpyHostToDevice) != hipSuccess) return -1;
+                if (heaac_couple_after_imdct_batch(d->dev, 1, e.d_f32 + (size_t)c->h_cce[i][k].link[l].target_ch * len, c->d_ret + k * 2048,
+                                                   c->d_gain, NULL, len / 1024, NULL) != HEAAC_OK)
+                    return -1;
+            }
+        }
         for (int c = 0; c < e.channels; c++) {
             planes[d->layout.elem[i].first_channel + c].d_base = e.d_f32 + (size_t)c * len;
             planes[d->layout.elem[i].first_channel + c].frame_stride = (size_t)e.channels * len;

@@ -144,6 +144,10 @@ typedef struct HeaacCceOut {
     float *coeffs;                /* [HEAAC_MAX_CCE][1024] */
     HeaacIcs *ics;                /* [HEAAC_MAX_CCE] window info of the coupling channels (AFTER_IMDCT ones are transformed) */
     HeaacToolsFrame *tools;       /* [HEAAC_MAX_CCE]: channel 0 = the coupling channel */
+    struct HeaacAacElementInfo *elem;   /* [HEAAC_MAX_CCE] or NULL (heaac_aac_parse_frame_layout_ex only): where each coupling
+                                     element stands and the SBR payload behind it -- a coupling channel that couples
+                                     AFTER_IMDCT goes through ff_sbr_apply like an SCE (aacdec.c:1920-1927).  NULL: such
+                                     a payload is HEAAC_PARSE_ERR_UNSUPPORTED. */
 } HeaacCceOut;
 
 /* One access unit (raw_data_block; an ADTS header in front is skipped as aac_decode_frame does).

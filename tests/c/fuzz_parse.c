@@ -89,7 +89,8 @@ int main(int argc, char **argv)
     HeaacAacElementInfo lelem[HEAAC_MAX_ELEMENTS];
     long layouts_ok = 0, layout_units = 0, layout_bad = 0, coupled_units = 0, coupled_links = 0;
     HeaacCceFrame *lcce = malloc(HEAAC_MAX_ELEMENTS * HEAAC_MAX_CCE * sizeof(*lcce));
-    const HeaacCceOut lco = { lcce, cce_coeffs, cce_ics, cce_tools };
+    HeaacAacElementInfo lcce_elem[HEAAC_MAX_CCE];
+    const HeaacCceOut lco = { lcce, cce_coeffs, cce_ics, cce_tools, lcce_elem };
     HeaacAacStream cst[HEAAC_MAX_ELEMENTS];
     memset(cst, 0, sizeof(cst));
     for (long it = 0; it < iters; it++) {
@@ -159,6 +160,9 @@ int main(int argc, char **argv)
                         for (int l = 0; l < c->n_links && l < HEAAC_MAX_CCE_LINKS; l++) v |= c->link[l].target_ch >= clay.elem[e].channels;
                         coupled_links += c->n_links;
                     }
+                    if (lcce[c2].present && lcce_elem[c2].sbr_payload_bit >= 0)
+                        v |= lcce_elem[c2].sbr_payload_bytes < 1 ||
+                             (long)lcce_elem[c2].sbr_payload_bit + 8L * lcce_elem[c2].sbr_payload_bytes - 4 > 8L * (long)len;
                     if (v) { layout_bad++; if (layout_bad < 5) printf("iteration %ld: coupling record of a layout out of range\n", it); }
                 }
             }

@@ -37,9 +37,18 @@ def asc(aot, si, elems, cc_tags, rng, he=False):
     return bw.bytes()
 
 
-def write_unit(rng, si, aot, elems, tags, points, quiet=False, payloads=None):
+def put_sbr_fill(bw, bits):
+    cnt = (4 + len(bits) + 7) // 8
+    TL.put_fil_count(bw, cnt)
+    bw.put(0xd, 4)
+    bw.bits.extend(bits)
+    bw.bits.extend([0] * (8 * cnt - 4 - len(bits)))
+
+
+def write_unit(rng, si, aot, elems, tags, points, quiet=False, payloads=None, cce_payloads=None):
     """One access unit: the output elements in a random order, the coupling elements `tags` anywhere between them;
-    payloads: {index into elems: bits of an SBR payload for the fill element behind that element}."""
+    payloads: {index into elems: bits of an SBR payload for the fill element behind that element}, cce_payloads:
+    {coupling element tag: bits} the same for the coupling elements."""
     order = list(range(len(elems)))
     rng.shuffle(order)
     at = sorted(int(x) for x in rng.integers(0, len(elems) + 1, len(tags)))
@@ -55,16 +64,14 @@ def write_unit(rng, si, aot, elems, tags, points, quiet=False, payloads=None):
             if rng.random() < 0.3:
                 targets.insert(int(rng.integers(0, 2)), (int(rng.integers(0, 2)), 14, 3))       # nobody's
             TW.write_cce(bw, rng, si, aot, tags[k], targets, int(rng.choice(points)), quiet=quiet)
+            if cce_payloads and cce_payloads.get(tags[k]) is not None:
+                put_sbr_fill(bw, cce_payloads[tags[k]])
             k += 1
         if pos < len(elems):
             TL.write_elem(bw, rng, si, aot, *elems[order[pos]], quiet=quiet)
             bits = payloads.get(order[pos]) if payloads else None
             if bits is not None:
-                cnt = (4 + len(bits) + 7) // 8
-                TL.put_fil_count(bw, cnt)
-                bw.put(0xd, 4)
-                bw.bits.extend(bits)
-                bw.bits.extend([0] * (8 * cnt - 4 - len(bits)))
+                put_sbr_fill(bw, bits)
     bw.put(7, 3)
     return bw.bytes()
 
@@ -81,9 +88,10 @@ class Checker:
         fresh = lambda c: np.tile(np.array([0, 0, 1, 1, 0, 0], np.float32), (1, c * pkg.MAX_PREDICTORS, 1)).reshape(1, -1)
         self.pred = [fresh(c) for c in self.slot_ch]
         self.cpred = [fresh(1) for _ in range(pkg.MAX_CCE)]
-        self.cstate = [np.zeros((1, 512), np.float32) for _ in range(pkg.MAX_CCE)]
+        self.cstate = [np.zeros((1, pkg.STATE_WORDS[pkg.CFG_HEV1_MONO] if he else 512), np.float32) for _ in range(pkg.MAX_CCE)]
+        self.csst = pkg.sbr_streams(pkg.MAX_CCE)
         self.rng = np.full(1, 0x1f2e3d4c, np.int32)
-        self.dependent = self.independent = 0              # gain lists applied so far
+        self.dependent = self.independent = self.sbr_coupled = 0     # gain lists applied so far; coupling channels through SBR
 
     def parses(self, au):
         return self.pkg.aac_parse_frame_layout(self.m4, self.layout.copy(), self.st.copy(), au, with_cce=True)[0] == 0
@@ -117,9 +125,28 @@ class Checker:
         cce_tools(ne)
         rets = {}
         for k in range(pkg.MAX_CCE):
-            if g["cce"][0, k]["present"] and g["cce"][0, k]["coupling_point"] == 3:
-                rets[k], self.cstate[k] = oracle.lc_decode_batch(1, cc[:, k:k + 1], g["cce_ics"][k:k + 1][None], self.cstate[k],
-                                                                 oracle.PCM_F32)
+            if not g["cce"][0, k]["present"]:
+                continue
+            after = g["cce"][0, k]["coupling_point"] == 3
+            if not self.he:
+                if after:
+                    rets[k], self.cstate[k] = oracle.lc_decode_batch(1, cc[:, k:k + 1], g["cce_ics"][k:k + 1][None], self.cstate[k],
+                                                                     oracle.PCM_F32)
+                continue
+            # the coupling channel's own SBR: read whenever a payload stands behind it, applied when it couples AFTER_IMDCT
+            ei = g["cce_elem"][k]
+            sbr = None
+            if int(ei["sbr_payload_bit"]) >= 0:
+                rr, sbr, _, _ = pkg.sbr_parse_payload(self.csst[k], self.tab, self.m4.sample_rate, au, 1, False,
+                                                      bit=int(ei["sbr_payload_bit"]), cnt=int(ei["sbr_payload_bytes"]),
+                                                      misplaced=bool(ei["sbr_misplaced"]))
+                assert rr == 0 and not ei["sbr_misplaced"]
+            elif after:
+                sbr = pkg.sbr_no_payload(self.csst[k], 1)
+            if after:
+                rets[k], self.cstate[k] = oracle.he_decode_batch(pkg.CFG_HEV1_MONO, cc[:, k:k + 1], g["cce_ics"][k:k + 1][None], sbr,
+                                                                 self.tab.headers(), None, self.cstate[k], oracle.PCM_F32)
+                self.sbr_coupled += int(sbr["start"][0])
         planes = [None] * self.nch
         for e in range(ne):
             c = self.slot_ch[e]
@@ -147,10 +174,14 @@ class Checker:
                     self.dependent += int(rec["n_links"])
                     continue
                 for l in range(int(rec["n_links"])):
-                    cpl = np.zeros(1, pkg.COUPLING_DT)
-                    cpl["on"][0, rec["link"][l]["target_ch"]] = 1
-                    cpl["gain"][0, rec["link"][l]["target_ch"]] = rec["link"][l]["gain"][0]
-                    f32, _ = oracle.couple_after_imdct_batch(c, f32, rets[k].reshape(1, 1024), cpl)
+                    # apply_independent_coupling over 1024 << sbr samples (:1849-1862): elementwise, so the plane and the
+                    # coupling channel go through the oracle's 1024-sample form piece by piece
+                    t, units = int(rec["link"][l]["target_ch"]), f32.shape[2] // 1024
+                    cpl = np.zeros(units, pkg.COUPLING_DT)
+                    cpl["on"][:, 0] = 1
+                    cpl["gain"][:, 0] = rec["link"][l]["gain"][0]
+                    plane, _ = oracle.couple_after_imdct_batch(1, f32[0, t].reshape(units, 1, 1024), rets[k].reshape(units, 1024), cpl)
+                    f32[0, t] = plane.reshape(-1)
                     self.independent += 1
             for j in range(c):
                 planes[int(self.layout[0]["elem"][e]["first_channel"]) + j] = f32[0, j]

@@ -100,6 +100,9 @@ STREAMS = {
     "main_three": (1, [(SCE, 2), (CPE, 4)], [7], [0, 1, 3]),
     # dependent coupling in an HE-AAC stream: in the spectrum, before the IMDCT and SBR of the targets
     "he_three_dependent": (2, [(SCE, 0), (CPE, 0), (LFE, 1)], [4, 11], [0, 1]),
+    # ... and independent coupling there: the coupling channel goes through SBR with its own payload, and couples
+    # over 2048 samples
+    "he_three_all": (2, [(SCE, 0), (CPE, 0), (LFE, 1)], [4, 11], [0, 1, 3]),
 }
 
 
@@ -122,6 +125,7 @@ def test_codec_decodes_access_units_with_coupling_elements(pkg, oracle, dev, nam
     length = 2048 if he else 1024
     asc = R.asc(aot, si, elems, cc_tags, rng, he=he)
     writers = {k: SW.SbrStreamWriter(pkg, 2 if t == CPE else 1) for k, (t, _) in enumerate(elems) if t != LFE} if he else {}
+    cce_writers = {g: SW.SbrStreamWriter(pkg, 1) for g in cc_tags} if he and 3 in points else {}
     ctx = HeaacCodecContext(cfg=-1, extradata=asc, extradata_size=len(asc))
     codec = C.c_void_p.in_dll(lib, "heaac_aac_decoder")
     assert lib.heaac_codec_open(C.byref(ctx), C.c_void_p(C.addressof(codec))) == 0
@@ -133,18 +137,19 @@ def test_codec_decodes_access_units_with_coupling_elements(pkg, oracle, dev, nam
     out = (C.c_int16 * (192000 // 2))()
     loud = 0
 
-    def unit(tags, check=True):
-        payloads = {}
-        for k, w in writers.items():
-            while True:
-                keep = copy.deepcopy((w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling))
-                bits, _ = w.frame(rng)
-                if (4 + len(bits) + 7) // 8 <= 269:
-                    break
-                w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling = keep
-            payloads[k] = bits
+    def payload(w):
         while True:
-            au = R.write_unit(rng, si, aot, elems, tags, points, quiet=he, payloads=payloads)
+            keep = copy.deepcopy((w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling))
+            bits, _ = w.frame(rng)
+            if (4 + len(bits) + 7) // 8 <= 269:
+                return bits
+            w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling = keep
+
+    def unit(tags, check=True, pts=points):
+        payloads = {k: payload(w) for k, w in writers.items()}
+        cce_payloads = {g: payload(w) for g, w in cce_writers.items() if g in tags}
+        while True:
+            au = R.write_unit(rng, si, aot, elems, tags, pts, quiet=he, payloads=payloads, cce_payloads=cce_payloads)
             if not check or chk.parses(au):
                 return au
 
@@ -155,7 +160,7 @@ def test_codec_decodes_access_units_with_coupling_elements(pkg, oracle, dev, nam
         return lib.heaac_codec_decode(C.byref(ctx), out, C.byref(size), C.byref(pkt)), size.value
 
     for t in range(6):
-        au = unit(cc_tags)
+        au = unit(cc_tags, pts=[3] if 3 in points and t in (1, 4) else points)     # every point is met for certain
         used, size = decode(au)
         assert used == len(au) and size == length * chk.nch * 2, (t, used)
         got = np.frombuffer(out, np.int16, length * chk.nch).reshape(length, chk.nch).copy()
@@ -163,12 +168,8 @@ def test_codec_decodes_access_units_with_coupling_elements(pkg, oracle, dev, nam
         assert np.array_equal(got, want), ("frame %d" % t, np.argwhere(got != want)[:4])
         loud = max(loud, int(np.abs(got.astype(int)).max()))
     assert loud > 50 and (chk.dependent >= 2 or points == [3]) and (chk.independent >= 2 or 3 not in points)
-    if he:
-        # independent coupling together with SBR stays outside (the coupling channel would go through ff_sbr_apply itself)
-        keep_points = points[:]
-        points[:] = [3]
-        assert decode(unit(cc_tags))[0] < 0
-        points[:] = keep_points
+    if cce_writers:
+        assert chk.sbr_coupled >= 2                        # coupling channels really went through SBR
     # a coupling element the stream has carried so far is left out: refused, as an output element would be (the
     # reference couples whatever the element's buffers still hold)
     assert decode(unit([]))[0] < 0

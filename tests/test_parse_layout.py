@@ -546,6 +546,24 @@ def test_coupling_elements_of_a_program_config_layout(pkg):
         bw.put(7, 3)
         return pkg.aac_parse_frame_layout(cfg, l0.copy(), st.copy(), bw.bytes(), with_cce=with_cce)[0]
     assert one(3, True) == 0 and one(3, False) == -3 and one(12, True) == -3 and one(5, True) == -1 and one(5, False) == -1
+    # an SBR payload behind a coupling element is that element's own (decode_extension_payload hands it to che_prev,
+    # :2059; read_sbr_data takes TYPE_CCE as a single channel, aacsbr.c:986): reported in cce_elem, or outside the entry
+    bw = W.BitWriter()
+    write_elem(bw, rng, si, aot, SCE, 4)
+    TW.write_cce(bw, rng, si, aot, 9, [(0, 4, 2)], 3)
+    at = write_fill(bw, rng, 0xe, 9)
+    write_dse(bw, rng)
+    TW.write_cce(bw, rng, si, aot, 3, [(0, 4, 2)], 0)
+    write_fill(bw, rng, 0x0, 2)
+    at2 = write_fill(bw, rng, 0xd, 5)                      # a fill element in between: the reader will switch this one's SBR off
+    bw.put(7, 3)
+    r, got = pkg.aac_parse_frame_layout(cfg, l0.copy(), st.copy(), bw.bytes(), with_cce=True)
+    assert r == 0 and int(got["elem"][2]["sbr_payload_bit"]) == -1
+    e9, e3 = got["cce_elem"][1], got["cce_elem"][0]
+    assert (int(e9["present"]), int(e9["type"]), int(e9["tag"]), int(e9["seq"])) == (1, CCE, 9, 0)
+    assert (int(e9["sbr_payload_bit"]), int(e9["sbr_payload_bytes"]), int(e9["sbr_crc"]), int(e9["sbr_misplaced"])) == (at, 9, 1, 0)
+    assert (int(e3["tag"]), int(e3["seq"]), int(e3["sbr_payload_bit"]), int(e3["sbr_misplaced"])) == (3, 1, at2, 1)
+    assert pkg.aac_parse_frame_layout(cfg, l0.copy(), st.copy(), bw.bytes(), with_cce="no_sbr")[0] == -3
     # the same coupling element twice: the second moves up to the next tag (get_che :121-127), which nobody named
     bw = W.BitWriter()
     write_elem(bw, rng, si, aot, SCE, 4)
