@@ -76,6 +76,35 @@ def write_unit(rng, si, aot, elems, tags, points, quiet=False, payloads=None, cc
     return bw.bytes()
 
 
+class UnitWriter:
+    """Access units of one stream: SBR payloads (HE streams) from per-element writers whose state runs along."""
+    def __init__(self, pkg, rng, si, aot, elems, cc_tags, points, he, quiet=None):
+        import sbr_bitwriter as SW
+        self.rng, self.si, self.aot, self.elems, self.points, self.he = rng, si, aot, elems, points, he
+        self.quiet = he if quiet is None else quiet
+        self.writers = {k: SW.SbrStreamWriter(pkg, 2 if t == CPE else 1) for k, (t, _) in enumerate(elems) if t != LFE} if he else {}
+        self.cce_writers = {g: SW.SbrStreamWriter(pkg, 1) for g in cc_tags} if he and 3 in points else {}
+
+    def _payload(self, w):
+        import copy
+        while True:
+            keep = copy.deepcopy((w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling))
+            bits, _ = w.frame(self.rng)
+            if (4 + len(bits) + 7) // 8 <= 269:            # one fill element
+                return bits
+            w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling = keep
+
+    def unit(self, tags, accept=None, pts=None):
+        """accept: a predicate on the bytes (the checker's `parses`), None = take the first."""
+        payloads = {k: self._payload(w) for k, w in self.writers.items()}
+        cce_payloads = {g: self._payload(w) for g, w in self.cce_writers.items() if g in tags}
+        while True:
+            au = write_unit(self.rng, self.si, self.aot, self.elems, tags, pts or self.points, quiet=self.quiet,
+                            payloads=payloads, cce_payloads=cce_payloads)
+            if accept is None or accept(au):
+                return au
+
+
 class Checker:
     def __init__(self, pkg, oracle, m4, layout, aot, he=False):
         self.pkg, self.oracle, self.m4, self.layout, self.aot, self.he = pkg, oracle, m4, layout, aot, he
@@ -92,6 +121,7 @@ class Checker:
         self.csst = pkg.sbr_streams(pkg.MAX_CCE)
         self.rng = np.full(1, 0x1f2e3d4c, np.int32)
         self.dependent = self.independent = self.sbr_coupled = 0     # gain lists applied so far; coupling channels through SBR
+        self.finite = True                                 # every output plane so far
 
     def parses(self, au):
         return self.pkg.aac_parse_frame_layout(self.m4, self.layout.copy(), self.st.copy(), au, with_cce=True)[0] == 0
@@ -185,4 +215,5 @@ class Checker:
                     self.independent += 1
             for j in range(c):
                 planes[int(self.layout[0]["elem"][e]["first_channel"]) + j] = f32[0, j]
+        self.finite = self.finite and all(np.isfinite(p).all() for p in planes)
         return oracle.float_to_int16_interleave(planes), g

@@ -113,9 +113,7 @@ def test_codec_decodes_access_units_with_coupling_elements(pkg, oracle, dev, nam
     every target's TNS and independent coupling behind its IMDCT, onto one and onto several output elements, the
     coupling elements anywhere between them; state chained over six frames.  int16 PCM against tests/coupled_ref.py
     (the oracle's tools, coupling, IMDCTs and interleave on the separately parsed records)."""
-    import copy
     import coupled_ref as R
-    import sbr_bitwriter as SW
     from test_shim_gpu import HeaacCodecContext, HeaacPacket
     lib = pkg.lib()
     aot, elems, cc_tags, points = STREAMS[name]
@@ -124,8 +122,7 @@ def test_codec_decodes_access_units_with_coupling_elements(pkg, oracle, dev, nam
     si = 6 if he else 3
     length = 2048 if he else 1024
     asc = R.asc(aot, si, elems, cc_tags, rng, he=he)
-    writers = {k: SW.SbrStreamWriter(pkg, 2 if t == CPE else 1) for k, (t, _) in enumerate(elems) if t != LFE} if he else {}
-    cce_writers = {g: SW.SbrStreamWriter(pkg, 1) for g in cc_tags} if he and 3 in points else {}
+    uw = R.UnitWriter(pkg, rng, si, aot, elems, cc_tags, points, he)
     ctx = HeaacCodecContext(cfg=-1, extradata=asc, extradata_size=len(asc))
     codec = C.c_void_p.in_dll(lib, "heaac_aac_decoder")
     assert lib.heaac_codec_open(C.byref(ctx), C.c_void_p(C.addressof(codec))) == 0
@@ -137,21 +134,8 @@ def test_codec_decodes_access_units_with_coupling_elements(pkg, oracle, dev, nam
     out = (C.c_int16 * (192000 // 2))()
     loud = 0
 
-    def payload(w):
-        while True:
-            keep = copy.deepcopy((w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling))
-            bits, _ = w.frame(rng)
-            if (4 + len(bits) + 7) // 8 <= 269:
-                return bits
-            w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling = keep
-
-    def unit(tags, check=True, pts=points):
-        payloads = {k: payload(w) for k, w in writers.items()}
-        cce_payloads = {g: payload(w) for g, w in cce_writers.items() if g in tags}
-        while True:
-            au = R.write_unit(rng, si, aot, elems, tags, pts, quiet=he, payloads=payloads, cce_payloads=cce_payloads)
-            if not check or chk.parses(au):
-                return au
+    def unit(tags, check=True, pts=None):
+        return uw.unit(tags, chk.parses if check else None, pts)
 
     def decode(au):
         b = C.create_string_buffer(au, len(au))
@@ -168,7 +152,7 @@ def test_codec_decodes_access_units_with_coupling_elements(pkg, oracle, dev, nam
         assert np.array_equal(got, want), ("frame %d" % t, np.argwhere(got != want)[:4])
         loud = max(loud, int(np.abs(got.astype(int)).max()))
     assert loud > 50 and (chk.dependent >= 2 or points == [3]) and (chk.independent >= 2 or 3 not in points)
-    if cce_writers:
+    if uw.cce_writers:
         assert chk.sbr_coupled >= 2                        # coupling channels really went through SBR
     # a coupling element the stream has carried so far is left out: refused, as an output element would be (the
     # reference couples whatever the element's buffers still hold)
