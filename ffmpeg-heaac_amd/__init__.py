@@ -513,6 +513,8 @@ class Pipeline:
     def __init__(self, aac_cfg, he_cfg, n_streams, threads=0):
         self._h = C.c_void_p()
         self.n, self.ch, self.len = n_streams, OUT_CH[he_cfg], OUT_LEN[he_cfg]
+        if self.len == 2048 and aac_cfg.ext_sample_rate and aac_cfg.ext_sample_rate < 2 * aac_cfg.sample_rate:
+            self.len = 1024                                # downsampled SBR: the output at the core rate
         _check(lib().heaac_pipeline_create(C.byref(self._h), C.byref(aac_cfg), he_cfg, C.c_size_t(n_streams), threads),
                "heaac_pipeline_create")
 

@@ -17,6 +17,7 @@
 #include <time.h>
 #include <unistd.h>
 #include "heaac_pipeline.h"
+#include "codec_layout.h"        // heaac_sbr_output_mode
 
 #define PL_MAX_HDRS 4096
 #define PL_DEPTH HEAAC_PIPELINE_DEPTH
@@ -39,6 +40,8 @@ struct HeaacPipeline {
     hipStream_t in, run, out;
     Set set[PL_DEPTH];
     float *d_state; int32_t *d_rng;
+    HeaacPredictorState *d_pred;  // AAC-Main streams: [n][ncore][672] (aacdec.c:1271-1322), else NULL
+    int downsampled;              // SBR with the output at the core rate (aacsbr.c:1719)
     HeaacSbrHeader *d_hdr; size_t hdr_uploaded;
     HeaacSbrHeaderTable *tab;
     HeaacAacStream *ast; HeaacSbrStream *sst;
@@ -142,6 +145,7 @@ extern "C" void heaac_pipeline_destroy(HeaacPipeline *p)
     }
     if (p->d_state) (void)hipFree(p->d_state);
     if (p->d_rng) (void)hipFree(p->d_rng);
+    if (p->d_pred) (void)hipFree(p->d_pred);
     if (p->d_hdr) (void)hipFree(p->d_hdr);
     if (p->in) (void)hipStreamDestroy(p->in);
     if (p->run) (void)hipStreamDestroy(p->run);
@@ -165,7 +169,11 @@ extern "C" int heaac_pipeline_create(HeaacPipeline **out, const HeaacAacConfig *
     p->aac = *aac;
     p->he_cfg = he_cfg;
     p->he = !lc;
-    p->out_len = lc ? 1024 : 2048;
+    // the configuration's two sample rates decide between 2048 samples at twice the core rate and "downsampled SBR"
+    const int mode = lc ? 0 : heaac_sbr_output_mode(aac);
+    if (mode < 0) { free(p); return HEAAC_ERR_ARG; }
+    p->downsampled = mode;
+    p->out_len = lc || mode ? 1024 : 2048;
     p->ncore = (he_cfg == HEAAC_CFG_HEV1 || he_cfg == HEAAC_CFG_LC_STEREO) ? 2 : 1;
     p->nout = (he_cfg == HEAAC_CFG_HEV1_MONO || he_cfg == HEAAC_CFG_LC_MONO) ? 1 : 2;
     p->words = he_cfg == HEAAC_CFG_HEV1 ? HEAAC_STATE_WORDS_HEV1 : he_cfg == HEAAC_CFG_HEV2 ? HEAAC_STATE_WORDS_HEV2 :
@@ -204,6 +212,17 @@ extern "C" int heaac_pipeline_create(HeaacPipeline **out, const HeaacAacConfig *
     ok = ok && devmem((void **)&p->d_state, n * p->words * 4) && devmem((void **)&p->d_rng, n * 4) &&
          devmem((void **)&p->d_hdr, PL_MAX_HDRS * sizeof(HeaacSbrHeader)) &&
          hipMemset(p->d_state, 0, n * p->words * 4) == hipSuccess;
+    if (ok && aac->object_type == HEAAC_AOT_AAC_MAIN) {
+        // reset_predict_state (aacdec.c:507-515) for every predictor of every channel
+        const size_t np = n * (size_t)p->ncore * HEAAC_MAX_PREDICTORS;
+        HeaacPredictorState *ps = (HeaacPredictorState *)calloc(np, sizeof(*ps));
+        ok = ps != NULL && devmem((void **)&p->d_pred, np * sizeof(*ps));
+        if (ok) {
+            for (size_t i = 0; i < np; i++) ps[i].var0 = ps[i].var1 = 1.0f;
+            ok = hipMemcpy(p->d_pred, ps, np * sizeof(*ps), hipMemcpyHostToDevice) == hipSuccess;
+        }
+        free(ps);
+    }
     if (ok) {
         int32_t *seed = (int32_t *)malloc(n * 4);
         ok = seed != NULL;
@@ -303,11 +322,12 @@ extern "C" int heaac_pipeline_submit(HeaacPipeline *p, const uint8_t *const *au,
     // GPU
     HIP_OK(hipStreamWaitEvent(p->run, s->in_done, 0));
     if (s->used) HIP_OK(hipStreamWaitEvent(p->run, s->out_done, 0));
-    int rc = heaac_spectral_tools_batch(p->dev, p->ncore, s->d_coeffs, s->d_tools, p->d_rng, p->d_rng, NULL, NULL, n,
+    int rc = heaac_spectral_tools_batch(p->dev, p->ncore, s->d_coeffs, s->d_tools, p->d_rng, p->d_rng, p->d_pred, p->d_pred, n,
                                         (void *)p->run);
     if (rc == HEAAC_OK)
-        rc = p->he ? heaac_he_decode_batch(p->dev, p->he_cfg, s->d_coeffs, s->d_ics, s->d_sbr, p->d_hdr, PL_MAX_HDRS, s->d_ps,
-                                           p->d_state, p->d_state, s->d_pcm, HEAAC_PCM_S16_INTERLEAVED, n, (void *)p->run)
+        rc = p->he ? heaac_he_decode_batch_ex(p->dev, p->he_cfg, p->downsampled ? HEAAC_HE_DOWNSAMPLED : 0, s->d_coeffs, s->d_ics,
+                                              s->d_sbr, p->d_hdr, PL_MAX_HDRS, s->d_ps,
+                                              p->d_state, p->d_state, s->d_pcm, HEAAC_PCM_S16_INTERLEAVED, n, (void *)p->run)
                    : heaac_lc_decode_batch(p->dev, p->ncore, s->d_coeffs, s->d_ics, p->d_state, p->d_state, s->d_pcm,
                                            HEAAC_PCM_S16_INTERLEAVED, n, (void *)p->run);
     if (rc != HEAAC_OK) return rc;

@@ -30,7 +30,9 @@ typedef struct HeaacPipeline HeaacPipeline;
 #define HEAAC_PIPELINE_DEPTH 4        /* ticks that may be in flight (submitted, not yet collected) */
 
 /* aac: the configuration all streams share (AudioSpecificConfig as heaac_asc_parse leaves it; sbr = 1 for the
- * HE configurations).
+ * HE configurations).  AAC-Main streams get their predictor state; an extension rate equal to the core rate is
+ * "downsampled SBR" -- 1024 samples per channel and tick at the core rate (aacsbr.c:1719, aacdec.c:2080-2084) --
+ * and one strictly between the core rate and twice that is HEAAC_ERR_ARG.
  * he_cfg: HEAAC_CFG_HEV2 (mono core + SBR + PS), HEAAC_CFG_HEV1_MONO, HEAAC_CFG_HEV1 (pair), or HEAAC_CFG_LC_MONO /
  *         HEAAC_CFG_LC_STEREO (no SBR: 1024 samples per channel and tick).
  * threads: parser threads (<= 0: the CPUs the process may use -- online CPUs, capped at twice a cgroup CPU quota;
@@ -45,7 +47,7 @@ void heaac_pipeline_destroy(HeaacPipeline *p);
  * HEAAC_PIPELINE_DEPTH ticks may be in flight: one more submit before a collect returns HEAAC_ERR_ARG. */
 int heaac_pipeline_submit(HeaacPipeline *p, const uint8_t *const *au, const int *size, int *status);
 
-/* Waits for the OLDEST tick in flight and hands out its PCM: [n_streams][2048 (LC: 1024)][channels] int16 in pinned memory
+/* Waits for the OLDEST tick in flight and hands out its PCM: [n_streams][2048 (LC, downsampled SBR: 1024)][channels] int16 in pinned memory
  * owned by the pipeline, valid until HEAAC_PIPELINE_DEPTH more ticks have been submitted. */
 int heaac_pipeline_collect(HeaacPipeline *p, const int16_t **pcm);
 

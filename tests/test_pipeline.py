@@ -43,17 +43,21 @@ def _ticks(pkg, rng, channels, ps, n, ticks):
 
 
 @pytest.mark.gpu
-def test_pipeline_on_plain_aac_lc_streams(pkg, dev):
-    """AAC-LC stereo streams (no SBR): parse + tools + heaac_lc_decode_batch per tick."""
+@pytest.mark.parametrize("aot", [2, 1])
+def test_pipeline_on_plain_aac_lc_streams(pkg, dev, aot):
+    """AAC-LC / AAC-Main stereo streams (no SBR): parse + tools + heaac_lc_decode_batch per tick; the Main streams'
+    predictor state lives in the pipeline."""
     import torch
-    rng = np.random.default_rng(8)
+    rng = np.random.default_rng(8 + aot)
     n, ticks, si = 29, 6, 3
-    aus = [[TP._write_au(rng, si, 2, True, extras=True, quiet=True)[0] for _ in range(n)] for _ in range(ticks)]
-    cfg = TP._cfg(pkg, 2, si, 2)
+    aus = [[TP._write_au(rng, si, aot, True, extras=True, quiet=True)[0] for _ in range(n)] for _ in range(ticks)]
+    cfg = TP._cfg(pkg, aot, si, 2)
     pl = pkg.Pipeline(cfg, pkg.CFG_LC_STEREO, n, threads=2)
     st = np.zeros(n, pkg.AAC_STREAM_DT)
     d_state = torch.zeros((n, 1024), device="cuda")
     d_rng = torch.full((n,), 0x1f2e3d4c, dtype=torch.int32, device="cuda")
+    d_pred = torch.tensor([0, 0, 1, 1, 0, 0], dtype=torch.float32, device="cuda").repeat(n, 2 * pkg.MAX_PREDICTORS, 1) if aot == 1 else None
+    predicted = 0
     got = []
     for t in range(ticks):
         pl.submit(aus[t])
@@ -65,17 +69,20 @@ def test_pipeline_on_plain_aac_lc_streams(pkg, dev):
         q = pkg.aac_parse_batch(cfg, st, aus[t], threads=1)
         assert q["failed"] == 0
         coeffs = torch.from_numpy(q["coeffs"]).cuda()
-        dev.spectral_tools(2, coeffs, pkg.to_device(q["tools"]), rng=d_rng)
+        dev.spectral_tools(2, coeffs, pkg.to_device(q["tools"]), rng=d_rng, pred=d_pred)
+        predicted += int(q["tools"]["ch"]["pred"]["predictor_present"].sum())
         pcm, d_state = dev.lc_decode(2, coeffs, pkg.to_device(q["ics"]), d_state, pcm_format=pkg.PCM_S16)
         torch.cuda.synchronize()
         assert got[t].shape == (n, 1024, 2) and np.array_equal(got[t], pcm.cpu().numpy()), t
+    assert (predicted > 20) == (aot == 1)
     pl.close()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfgname", ["CFG_HEV2", "CFG_HEV1"])
+@pytest.mark.parametrize("cfgname", ["CFG_HEV2", "CFG_HEV1", "CFG_HEV1:downsampled"])
 def test_pipeline_equals_the_calls_made_one_after_the_other(pkg, dev, cfgname):
     import torch
+    cfgname, _, down = cfgname.partition(":")
     cfg = getattr(pkg, cfgname)
     ps = cfg == pkg.CFG_HEV2
     channels = 1 if ps else 2
@@ -83,6 +90,8 @@ def test_pipeline_equals_the_calls_made_one_after_the_other(pkg, dev, cfgname):
     n, ticks = 37, 7
     aus = _ticks(pkg, rng, channels, ps, n, ticks)
     m4 = TS._he_cfg(pkg, channels, ps)
+    if down:                                               # extension rate = core rate: 1024 samples per tick (aacsbr.c:1719)
+        m4.ext_sampling_index, m4.ext_sample_rate = m4.sampling_index, m4.sample_rate
     pl = pkg.Pipeline(m4, cfg, n, threads=3)
     # the direct path
     tab = pkg.SbrHeaderTable(4096)
@@ -96,7 +105,8 @@ def test_pipeline_equals_the_calls_made_one_after_the_other(pkg, dev, cfgname):
         dev.spectral_tools(channels, coeffs, pkg.to_device(q["tools"]), rng=d_rng)
         pcm, d_state = dev.he_decode(cfg, coeffs, pkg.to_device(np.ascontiguousarray(q["ics"][:, :channels])),
                                      pkg.to_device(q["sbr"]), pkg.to_device(tab.headers()),
-                                     pkg.to_device(q["ps"]) if ps else None, d_state, state_out=d_state, pcm_format=pkg.PCM_S16)
+                                     pkg.to_device(q["ps"]) if ps else None, d_state, state_out=d_state, pcm_format=pkg.PCM_S16,
+                                     **({"downsampled": True} if down else {}))
         torch.cuda.synchronize()
         want.append((pcm.cpu().numpy(), q["status"].copy()))
     # the pipeline, as many ticks in flight as it takes
@@ -113,7 +123,7 @@ def test_pipeline_equals_the_calls_made_one_after_the_other(pkg, dev, cfgname):
     loud = 0
     for t in range(ticks):
         assert np.array_equal(status[t], want[t][1]), t
-        assert np.array_equal(got[t], want[t][0]), "tick %d" % t
+        assert got[t].shape == (n, 1024 if down else 2048, 2) and np.array_equal(got[t], want[t][0]), "tick %d" % t
         loud = max(loud, int(np.abs(got[t].astype(int)).max()))
     assert loud > 50
     # one submit more than the depth without a collect is refused
