@@ -122,6 +122,7 @@ class Checker:
         self.rng = np.full(1, 0x1f2e3d4c, np.int32)
         self.dependent = self.independent = self.sbr_coupled = 0     # gain lists applied so far; coupling channels through SBR
         self.finite = True                                 # every output plane so far
+        self.ltp_skipped = 0                               # dependent gain lists an LTP-profile stream left unapplied
 
     def parses(self, au):
         return self.pkg.aac_parse_frame_layout(self.m4, self.layout.copy(), self.st.copy(), au, with_cce=True)[0] == 0
@@ -131,6 +132,11 @@ class Checker:
         pkg, oracle, ne, main = self.pkg, self.oracle, self.ne, self.aot == 1
         r, g = pkg.aac_parse_frame_layout(self.m4, self.layout, self.st, au, with_cce=True)
         assert r == 0, r
+        if self.m4.object_type == 4:
+            # "Dependent coupling is not supported together with LTP" (apply_dependent_coupling, aacdec.c:1822-1826, returns)
+            dep = g["cce"]["coupling_point"] != 3
+            self.ltp_skipped += int(g["cce"]["n_links"][dep].sum())
+            g["cce"]["n_links"][dep] = 0
         cc = g["cce_coeffs"][None].copy()
 
         def cce_tools(before):

@@ -162,6 +162,55 @@ def test_codec_decodes_access_units_with_coupling_elements(pkg, oracle, dev, nam
     assert lib.heaac_codec_close(C.byref(ctx)) == 0
 
 
+def test_ltp_profile_stream_keeps_its_coupling_elements_but_couples_nothing_in_the_spectrum(pkg, oracle, dev):
+    """A self-configuring ADTS stream (channel configuration 0, the program config element ahead of the first frame's
+    channel elements) whose header says LTP profile: parse_adts_frame_header takes the object type as it comes
+    (aacdec.c:1959), apply_dependent_coupling refuses to couple for it (:1822-1826), independent coupling goes on."""
+    import coupled_ref as R
+    import aac_bitwriter as W
+    import test_parse_layout as TL
+    from test_shim_gpu import HeaacCodecContext, HeaacPacket, _adts
+    lib = pkg.lib()
+    rng = np.random.default_rng(404)
+    si, elems, cc_tags, points = 3, [(SCE, 1), (CPE, 3)], [2, 8], [0, 1, 3]
+    ctx = HeaacCodecContext(cfg=-1, extradata=None, extradata_size=0)
+    codec = C.c_void_p.in_dll(lib, "heaac_aac_decoder")
+    assert lib.heaac_codec_open(C.byref(ctx), C.c_void_p(C.addressof(codec))) == 0
+    pce = W.BitWriter()
+    pce.put(5, 3); pce.put(0, 4)
+    a = R.pce_args(elems, cc_tags)
+    TL.write_pce_body(pce, np.random.default_rng(1), *a[:4], cc=a[4])
+    r, layout, _ = pkg.aac_layout_from_pce(pce.bytes(), 7)
+    assert r == 0
+    m4 = TP._cfg(pkg, 4, si, 0)                            # object type 4: what the checker's parser must be told too
+    chk = R.Checker(pkg, oracle, m4, layout, 4)
+    uw = R.UnitWriter(pkg, rng, si, 2, elems, cc_tags, points, False)
+    out = (C.c_int16 * (192000 // 2))()
+    for t in range(6):
+        # the units are written as AAC-LC ones (no predictor bit); the first carries the program config element
+        while True:
+            body = uw.unit(cc_tags, pts=[3] if t == 2 else None)
+            if t == 0:
+                # splice: program config element, byte aligned by its own rule, then the unit's bits
+                bw = W.BitWriter()
+                bw.bits.extend(pce.bits)
+                bw.bits.extend((b >> (7 - i)) & 1 for b in body for i in range(8))
+                body = bw.bytes()
+            pkt_bytes = _adts(body, 4, si, 0)
+            if chk.parses(pkt_bytes):
+                break
+        b = C.create_string_buffer(pkt_bytes, len(pkt_bytes))
+        pkt = HeaacPacket(C.cast(b, C.c_void_p), len(pkt_bytes))
+        size = C.c_int(192000)
+        used = lib.heaac_codec_decode(C.byref(ctx), out, C.byref(size), C.byref(pkt))
+        assert used == len(pkt_bytes) and size.value == 1024 * chk.nch * 2, (t, used)
+        got = np.frombuffer(out, np.int16, 1024 * chk.nch).reshape(1024, chk.nch).copy()
+        want, _ = chk.frame(pkt_bytes)
+        assert np.array_equal(got, want), ("frame %d" % t, np.argwhere(got != want)[:4])
+    assert chk.ltp_skipped >= 3 and chk.independent >= 1 and chk.dependent == 0
+    assert lib.heaac_codec_close(C.byref(ctx)) == 0
+
+
 @pytest.mark.parametrize("cpe", [False, True])
 def test_codec_refuses_a_coupling_element_in_a_channel_configuration_stream(pkg, dev, cpe):
     """Channel configurations 1..7 allocate no coupling element (set_default_channel_config aacdec.c:359-398, get_che
