@@ -308,7 +308,7 @@ extern "C" void av_fft_end(FFTContext *s) { if (s) { ff_fft_end(s); free(s); } }
 typedef struct HeaacDecoderPriv {
     HeaacDevice *dev;
     int cfg, ncore, nout, out_len;
-    int downsampled;              // SBR with the output at the core rate (bitstream mode; set_rates)
+    int downsampled;              // SBR with the output at the core rate (bitstream mode; publish_cfg)
     size_t words;
     float *d_state;               // one record, updated in place
     float *d_coeffs;
