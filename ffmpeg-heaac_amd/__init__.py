@@ -462,7 +462,7 @@ class AdtsHeader(C.Structure):
 
 COUPLING_DT = np.dtype([("gain", "<f4", (2,)), ("on", "u1", (2,)), ("pad", "u1", (2,))])
 AAC_STREAM_DT = np.dtype([("window_sequence", "u1", (2,)), ("use_kb_window", "u1", (2,)),
-                          ("cce_window_sequence", "u1", (2,)), ("cce_use_kb_window", "u1", (2,))])
+                          ("cce_window_sequence", "u1", (16,)), ("cce_use_kb_window", "u1", (16,))])
 AAC_INFO_DT = np.dtype([("channels", "<i4"), ("bits_consumed", "<i4"), ("sbr_payload_bit", "<i4"),
                         ("sbr_payload_bytes", "<i4"), ("sbr_crc", "<i4"), ("elem_id", "<i4"), ("n_cce", "<i4"),
                         ("sbr_misplaced", "<i4")])
@@ -518,14 +518,15 @@ class Pipeline:
         _check(lib().heaac_pipeline_create(C.byref(self._h), C.byref(aac_cfg), he_cfg, C.c_size_t(n_streams), threads),
                "heaac_pipeline_create")
 
-    def submit(self, aus):
-        """aus: n_streams access units (bytes).  Returns the parse status per stream."""
+    def submit(self, aus, with_status=True):
+        """aus: n_streams access units (bytes).  Returns the parse status per stream (None without a status array)."""
         assert len(aus) == self.n
         keep = [C.create_string_buffer(bytes(a), len(a)) for a in aus]
         ptrs = (C.c_char_p * self.n)(*[C.cast(k, C.c_char_p) for k in keep])
         sizes = (C.c_int * self.n)(*[len(a) for a in aus])
-        status = np.zeros(self.n, np.int32)
-        _check(lib().heaac_pipeline_submit(self._h, ptrs, sizes, status.ctypes.data_as(C.c_void_p)), "heaac_pipeline_submit")
+        status = np.zeros(self.n, np.int32) if with_status else None
+        _check(lib().heaac_pipeline_submit(self._h, ptrs, sizes, status.ctypes.data_as(C.c_void_p) if with_status else None),
+               "heaac_pipeline_submit")
         return status
 
     def submit_raw(self, ptrs, sizes):

@@ -345,6 +345,20 @@ static inline float dequant(unsigned q, int negative, float sf)
     return (negative ? -mag : mag) * sf;
 }
 
+/* A pulse of amplitude `amp` on a line that has already been dequantised and scaled (:1222-1236): the reference
+ * goes back to the quantised magnitude through float arithmetic -- x / sf, then x / x^(1/4) = |q| up to rounding --
+ * adds the amplitude AWAY from zero (towards minus infinity on an empty line) and raises to 4/3 again as
+ * cbrtf(|q|) * q.  All of it in float, in this order. */
+static inline float pulse_add(float line, int amp, float sf)
+{
+    float q = -(float)amp;
+    if (line != 0.0f) {
+        const float x = line / sf;
+        q = x / sqrtf(sqrtf(fabsf(x))) + (x > 0 ? (float)amp : -(float)amp);
+    }
+    return cbrtf(fabsf(q)) * q * sf;
+}
+
 /* decode_spectrum_and_dequant (:988-1245).  NOISE_BT bands are zeroed (the GPU fills them). */
 static int read_spectrum(Bits *b, const HeaacToolsIcs *ics, const uint8_t band_type[128], const float sf[128],
                          int pulse_present, const Pulse *pulse, float coef[1024])
@@ -375,14 +389,23 @@ static int read_spectrum(Bits *b, const HeaacToolsIcs *ics, const uint8_t band_t
                         const int code = tree_read(t, b);
                         if (code < 0) return HEAAC_PARSE_ERR_DATA;
                         int q[4] = { code / 27, code / 9 % 3, code / 3 % 3, code % 3 };
-                        for (int j = 0; j < 4; j++) {
-                            if (bt <= 2) {
+                        if (bt <= 2) {
+                            for (int j = 0; j < 4; j++) {
                                 const int v = q[j] - 1;
                                 cf[k + j] = dequant((unsigned)abs(v), v < 0, s);
-                            } else {
-                                const int neg = q[j] ? (int)bit1(b) : 0;
-                                cf[k + j] = dequant((unsigned)q[j], neg, s);
                             }
+                        } else {
+                            /* VMUL4S (:949-972) flips the scalefactor's sign by the sign bit at the head of the
+                             * pending ones and moves on only behind a non-zero line: a zero line is multiplied by
+                             * the scalefactor with the NEXT non-zero line's sign (none left: as it is) -- the sign of
+                             * a zero, which no value downstream depends on, kept for the coefficients' bit pattern. */
+                            int neg[4], pending = 0;
+                            for (int j = 0; j < 4; j++) neg[j] = q[j] ? (int)bit1(b) : 0;
+                            for (int j = 3; j >= 0; j--) {
+                                if (q[j]) pending = neg[j];
+                                else neg[j] = pending;
+                            }
+                            for (int j = 0; j < 4; j++) cf[k + j] = dequant((unsigned)q[j], neg[j], s);
                         }
                     }
                 } else {
@@ -400,6 +423,9 @@ static int read_spectrum(Bits *b, const HeaacToolsIcs *ics, const uint8_t band_t
                         } else {
                             int neg[2];
                             for (int j = 0; j < 2; j++) neg[j] = q[j] ? (int)bit1(b) : 0;
+                            /* book 11 ORs the pending sign bit into a zero line as well (:1199-1201); books 7 ... 10
+                             * (VMUL2S :935-947) do not */
+                            if (bt == 11 && !q[0]) neg[0] = neg[1];
                             for (int j = 0; j < 2; j++) {
                                 unsigned v = (unsigned)q[j];
                                 if (bt == 11 && q[j] == 16) {
@@ -421,19 +447,13 @@ static int read_spectrum(Bits *b, const HeaacToolsIcs *ics, const uint8_t band_t
         coef += g_len << 7;
     }
     if (pulse_present) {
-        /* :1222-1236 */
-        idx = 0;
+        int band = 0;
         for (int i = 0; i < pulse->num_pulse; i++) {
-            float co = base[pulse->pos[i]];
-            while (off[idx + 1] <= pulse->pos[i]) idx++;
-            if (band_type[idx] != HEAAC_NOISE_BT && sf[idx]) {
-                float ico = -(float)pulse->amp[i];
-                if (co) {
-                    co /= sf[idx];
-                    ico = co / sqrtf(sqrtf(fabsf(co))) + (co > 0 ? -ico : ico);
-                }
-                base[pulse->pos[i]] = cbrtf(fabsf(ico)) * ico * sf[idx];
-            }
+            const int line = pulse->pos[i];
+            while (off[band + 1] <= line) band++;
+            /* no pulses into noise bands or bands without a scalefactor (:1227) */
+            if (band_type[band] == HEAAC_NOISE_BT || sf[band] == 0.0f) continue;
+            base[line] = pulse_add(base[line], pulse->amp[i], sf[band]);
         }
     }
     return HEAAC_PARSE_OK;
@@ -586,71 +606,102 @@ typedef struct {
     float gl[16][120];
 } CceLists;
 
+/* One coupling gain.  The reference keeps the base in a `float scale` (aacdec.c:1508, :1528: 2^(1/8), 2^(1/4), 2^(1/2)
+ * are ROUNDED to float before anything is raised to a power), calls the double pow() on it and rounds the result to
+ * float (:1539, :1556; the sign is applied in double, which is exact). */
+static float cce_gain(float base, int step, int negative)
+{
+    const double mag = pow((double)base, (double)-step);
+    return (float)(negative ? -mag : mag);
+}
+
+/* The target list (:1511-1523).  Returns the number of gain lists that follow the channel stream: one per target,
+ * two for a pair coupled with a gain list per channel. */
+static int cce_read_targets(Bits *b, CceLists *ls)
+{
+    int lists = 0;
+    ls->num_coupled = (int)bits(b, 3);
+    for (int c = 0; c <= ls->num_coupled; c++) {
+        CceTarget *t = &ls->tg[c];
+        const int pair = (int)bit1(b);
+        t->type = pair ? TYPE_CPE : TYPE_SCE;
+        t->id = (int)bits(b, 4);
+        t->ch_select = pair ? (int)bits(b, 2) : 2;
+        lists += 1 + (t->ch_select == 3);
+    }
+    return lists;
+}
+
+/* How one gain list is coded. */
+typedef struct {
+    float base;            /* gain_element_scale as the reference's float */
+    int sign_coded;        /* gain_element_sign: the low bit of an accumulated step is the sign */
+    int common;            /* one gain for the whole list (always, for the first list: gain 1) */
+    int first;             /* the first list carries no common gain: it starts from 1.0f */
+} CceListCoding;
+
+/* One gain list over the coupling channel's scalefactor bands (:1534-1566).  A list with a common gain holds that
+ * value in every coded band; otherwise each coded band transmits a step that ACCUMULATES (`t = gain += t`), a zero
+ * step repeating the value before it -- which, before the first non-zero step, is the list's starting value. */
+static int cce_read_gain_list(Bits *b, const CceListCoding *k, const HeaacToolsChannel *ch, int after_imdct,
+                              float out[120])
+{
+    int acc = 0;
+    float cur = 1.0f;
+    if (!k->first) {
+        if (k->common) {
+            const int sym = tree_read(&g_sf_tree, b);
+            if (sym < 0) return HEAAC_PARSE_ERR_DATA;
+            acc = sym - 60;
+        }
+        cur = cce_gain(k->base, acc, 0);               /* unsigned whatever gain_element_sign says (:1539) */
+    }
+    if (after_imdct) {
+        out[0] = cur;
+        return HEAAC_PARSE_OK;
+    }
+    const int n_bands = ch->ics.num_window_groups * ch->ics.max_sfb;
+    if (n_bands > 120) return HEAAC_PARSE_ERR_DATA;
+    for (int band = 0; band < n_bands; band++) {
+        if (ch->band_type[band] == 0) continue;        /* ZERO_BT: no gain, no bits */
+        if (!k->common) {
+            const int sym = tree_read(&g_sf_tree, b);
+            if (sym < 0) return HEAAC_PARSE_ERR_DATA;
+            if (sym != 60) {
+                acc += sym - 60;
+                /* arithmetic shift of the accumulated step, the low bit being the sign (:1552-1555) */
+                cur = k->sign_coded ? cce_gain(k->base, acc >> 1, acc & 1) : cce_gain(k->base, acc, 0);
+            }
+        }
+        out[band] = cur;
+    }
+    return HEAAC_PARSE_OK;
+}
+
 static int read_cce(const HeaacAacConfig *cfg, Bits *b, int elem_id, HeaacCceFrame *out, CceLists *ls,
                     HeaacToolsChannel *ch, WinInfo *w, float coef[1024])
 {
-    CceTarget *tg = ls->tg;
-    int num_gain = 0;
     memset(out, 0, sizeof(*out));
     out->present = 1;
     out->elem_id = (uint8_t)elem_id;
-    int point = 2 * (int)bit1(b);                      /* ind_sw_cce_flag */
-    const int num_coupled = ls->num_coupled = (int)bits(b, 3);
-    for (int c = 0; c <= num_coupled; c++) {
-        num_gain++;
-        tg[c].type = bit1(b) ? TYPE_CPE : TYPE_SCE;
-        tg[c].id = (int)bits(b, 4);
-        tg[c].ch_select = 2;
-        if (tg[c].type == TYPE_CPE) {
-            tg[c].ch_select = (int)bits(b, 2);
-            if (tg[c].ch_select == 3) num_gain++;
-        }
-    }
-    point += (int)(bit1(b) || (point >> 1));           /* cc_domain; an independently switched element is always 3 */
+    const int independent = (int)bit1(b);              /* ind_sw_cce_flag */
+    const int n_lists = cce_read_targets(b, ls);
+    const int after_tns = (int)bit1(b);                /* cc_domain; read either way (:1524) */
+    const int point = independent ? HEAAC_CC_AFTER_IMDCT : after_tns;
     out->coupling_point = (uint8_t)point;
-    const int sign = (int)bit1(b);
-    const double scale = pow(2., pow(2., (int)bits(b, 2) - 3));
+    CceListCoding k;
+    k.sign_coded = (int)bit1(b);
+    k.base = (float)pow(2., pow(2., (int)bits(b, 2) - 3));
     int r = read_ics(cfg, b, 0, ch, w, coef);
     if (r < 0) return r;
     out->ics = ch->ics;
     memcpy(out->band_type, ch->band_type, sizeof(out->band_type));
 
-    /* the gain lists, in transmission order (:1538-1567) */
-    float (*gl)[120] = ls->gl;
     memset(ls->gl, 0, sizeof(ls->gl));
-    for (int c = 0; c < num_gain; c++) {
-        int idx = 0, cge = 1, gain = 0;
-        float gain_cache = 1.0f;
-        if (c) {
-            cge = point == HEAAC_CC_AFTER_IMDCT ? 1 : (int)bit1(b);
-            if (cge) {
-                const int sym = tree_read(&g_sf_tree, b);
-                if (sym < 0) return HEAAC_PARSE_ERR_DATA;
-                gain = sym - 60;
-            }
-            gain_cache = (float)pow(scale, -gain);
-        }
-        if (point == HEAAC_CC_AFTER_IMDCT) {
-            gl[c][0] = gain_cache;
-            continue;
-        }
-        for (int g = 0; g < ch->ics.num_window_groups; g++)
-            for (int sfb = 0; sfb < ch->ics.max_sfb; sfb++, idx++) {
-                if (idx >= 120) return HEAAC_PARSE_ERR_DATA;
-                if (ch->band_type[idx] == 0) continue;                 /* ZERO_BT */
-                if (!cge) {
-                    const int sym = tree_read(&g_sf_tree, b);
-                    if (sym < 0) return HEAAC_PARSE_ERR_DATA;
-                    int t = sym - 60;
-                    if (t) {
-                        int sgn = 1;
-                        t = gain += t;
-                        if (sign) { sgn -= 2 * (t & 1); t >>= 1; }
-                        gain_cache = (float)(pow(scale, -t) * sgn);
-                    }
-                }
-                gl[c][idx] = gain_cache;
-            }
+    for (int c = 0; c < n_lists; c++) {
+        k.first = c == 0;
+        k.common = k.first || point == HEAAC_CC_AFTER_IMDCT || bit1(b);
+        if ((r = cce_read_gain_list(b, &k, ch, point == HEAAC_CC_AFTER_IMDCT, ls->gl[c])) < 0) return r;
     }
     return HEAAC_PARSE_OK;
 }
@@ -765,9 +816,10 @@ int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
             }
             cce_tag[slot] = elem_id;
             n_cce++;
-            /* the coupling channel's window history: by slot (a stream keeps its elements' tags) */
-            wc[slot].window_sequence[0] = st->cce_window_sequence[slot];
-            wc[slot].use_kb_window[0] = st->cce_use_kb_window[slot];
+            /* the coupling channel's window history: by instance tag, as the reference keeps it (che[TYPE_CCE][tag]) --
+             * slots move with the tags an access unit happens to carry and the order they arrive in */
+            wc[slot].window_sequence[0] = st->cce_window_sequence[elem_id];
+            wc[slot].use_kb_window[0] = st->cce_use_kb_window[elem_id];
             wc[slot].window_sequence[1] = wc[slot].use_kb_window[1] = 0;
             memset(&cce->tools[slot], 0, sizeof(HeaacToolsFrame));
             CceLists ls;
@@ -833,8 +885,8 @@ int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
         cce->ics[k].window_sequence[1] = wc[k].window_sequence[1];
         cce->ics[k].use_kb_window[0] = wc[k].use_kb_window[0];
         cce->ics[k].use_kb_window[1] = wc[k].use_kb_window[1];
-        st->cce_window_sequence[k] = wc[k].window_sequence[0];
-        st->cce_use_kb_window[k] = wc[k].use_kb_window[0];
+        st->cce_window_sequence[cce_tag[k]] = wc[k].window_sequence[0];
+        st->cce_use_kb_window[cce_tag[k]] = wc[k].use_kb_window[0];
     }
     fi.n_cce = n_cce;
     fi.bits_consumed = b.pos;
@@ -1099,8 +1151,8 @@ int heaac_aac_parse_frame_layout_ex(const HeaacAacConfig *cfg, HeaacAacLayout *l
             const int k = layout->tag_map[TYPE_CCE][tag] - 1;
             if (k < 0) return HEAAC_PARSE_ERR_DATA;   /* "channel element 2.%d is not allocated" */
             if (!cce || k >= HEAAC_MAX_CCE) return HEAAC_PARSE_ERR_UNSUPPORTED;
-            wc[k].window_sequence[0] = st[0].cce_window_sequence[k];
-            wc[k].use_kb_window[0] = st[0].cce_use_kb_window[k];
+            wc[k].window_sequence[0] = st[0].cce_window_sequence[tag];
+            wc[k].use_kb_window[0] = st[0].cce_use_kb_window[tag];
             wc[k].window_sequence[1] = wc[k].use_kb_window[1] = 0;
             memset(&cce->tools[k], 0, sizeof(HeaacToolsFrame));
             r = read_cce(cfg, &b, tag, &cbase[k], &lists[k], &cce->tools[k].ch[0], &wc[k], cce->coeffs + k * 1024);
@@ -1176,8 +1228,8 @@ int heaac_aac_parse_frame_layout_ex(const HeaacAacConfig *cfg, HeaacAacLayout *l
         cce->ics[k].window_sequence[1] = wc[k].window_sequence[1];
         cce->ics[k].use_kb_window[0] = wc[k].use_kb_window[0];
         cce->ics[k].use_kb_window[1] = wc[k].use_kb_window[1];
-        st[0].cce_window_sequence[k] = wc[k].window_sequence[0];
-        st[0].cce_use_kb_window[k] = wc[k].use_kb_window[0];
+        st[0].cce_window_sequence[cbase[k].elem_id] = wc[k].window_sequence[0];
+        st[0].cce_use_kb_window[cbase[k].elem_id] = wc[k].use_kb_window[0];
     }
     for (int e = 0; e < ne; e++) {
         if (!elem[e].present) continue;

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <alloca.h>
 #include <unistd.h>
 #include "heaac_pipeline.h"
 #include "codec_layout.h"        // heaac_sbr_output_mode
@@ -30,6 +31,7 @@ struct Set {
     hipEvent_t in_start, in_done, run_done, out_done;
     int used;                       // a tick has gone through this set
     float parse_ms;
+    unsigned char *failed;          // [n] 1: the stream's access unit of this tick did not parse (core element)
 };
 
 struct HeaacPipeline {
@@ -40,6 +42,9 @@ struct HeaacPipeline {
     hipStream_t in, run, out;
     Set set[PL_DEPTH];
     float *d_state; int32_t *d_rng;
+    // A stream whose access unit fails keeps its decoder state and gets silence for the tick: its state
+    // rows are parked here around the decode launches.  Grown on demand -- damaged units are the exception.
+    float *d_park_state; int32_t *d_park_rng; HeaacPredictorState *d_park_pred; size_t park_rows;
     HeaacPredictorState *d_pred;  // AAC-Main streams: [n][ncore][672] (aacdec.c:1271-1322), else NULL
     int downsampled;              // SBR with the output at the core rate (aacsbr.c:1719)
     HeaacSbrHeader *d_hdr; size_t hdr_uploaded;
@@ -64,14 +69,36 @@ static void parse_slice(HeaacPipeline *p, int w)
     const size_t lo = p->n * (size_t)w / (size_t)p->threads, hi = p->n * (size_t)(w + 1) / (size_t)p->threads;
     Set *s = p->job_set;
     for (size_t i = lo; i < hi; i++) {
+        HeaacAacFrameInfo fi;
+        memset(&fi, 0, sizeof(fi));
+        HeaacSbrStream *sst_i = (HeaacSbrStream *)((char *)p->sst + i * heaac_sbr_stream_bytes());
         const int r = p->he
-            ? heaac_heaac_parse_frame_ex(&p->aac, &p->ast[i], &p->sst[i], p->tab, p->job_au[i], p->job_size[i],
+            ? heaac_heaac_parse_frame_ex(&p->aac, &p->ast[i], sst_i, p->tab, p->job_au[i], p->job_size[i],
                                          p->ncore, s->h_coeffs + i * (size_t)p->ncore * 1024, s->h_ics + i * p->ncore,
-                                         &s->h_tools[i], &s->h_sbr[i], s->h_ps ? &s->h_ps[i] : NULL, NULL)
+                                         &s->h_tools[i], &s->h_sbr[i], s->h_ps ? &s->h_ps[i] : NULL, &fi)
             : heaac_aac_parse_frame_ex(&p->aac, &p->ast[i], p->job_au[i], p->job_size[i], p->ncore,
                                        s->h_coeffs + i * (size_t)p->ncore * 1024, s->h_ics + i * p->ncore, &s->h_tools[i],
-                                       NULL, NULL);
+                                       NULL, &fi);
         if (p->job_status) p->job_status[i] = r;
+        // The core element did not parse (an SBR payload that fails leaves valid "SBR off" records and the unit decodes,
+        // as in the reference).  The reference returns an error and writes no samples, aac_decode_frame :2065-2068; here
+        // the stream's slot in the batch still runs, so it gets records that are safe to decode -- silence, no tools,
+        // no SBR payload -- and submit() parks its state rows around the launches: the stream is left as it was before
+        // the unit and its PCM of this tick is zero.  (What was half written by the failed parse, and the SBR / PS
+        // records of the tick that used this buffer set last, must not reach the kernels.)
+        const int core_failed = r < 0 && fi.channels == 0;
+        s->failed[i] = (unsigned char)core_failed;
+        if (core_failed) {
+            memset(s->h_coeffs + i * (size_t)p->ncore * 1024, 0, (size_t)p->ncore * 4096);
+            memset(s->h_ics + i * p->ncore, 0, p->ncore * sizeof(HeaacIcs));
+            memset(&s->h_tools[i], 0, sizeof(HeaacToolsFrame));
+            if (p->he) {
+                // the record of "no payload" from a COPY of the stream's SBR state (the call moves kx / m along)
+                void *tmp = alloca(heaac_sbr_stream_bytes());
+                memcpy(tmp, sst_i, heaac_sbr_stream_bytes());
+                heaac_sbr_no_payload((HeaacSbrStream *)tmp, p->ncore, &s->h_sbr[i], s->h_ps ? &s->h_ps[i] : NULL);
+            }
+        }
     }
 }
 
@@ -142,11 +169,15 @@ extern "C" void heaac_pipeline_destroy(HeaacPipeline *p)
         for (void *x : d) if (x) (void)hipFree(x);
         hipEvent_t ev[] = { s->in_start, s->in_done, s->run_done, s->out_done };
         for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+        free(s->failed);
     }
     if (p->d_state) (void)hipFree(p->d_state);
     if (p->d_rng) (void)hipFree(p->d_rng);
     if (p->d_pred) (void)hipFree(p->d_pred);
     if (p->d_hdr) (void)hipFree(p->d_hdr);
+    if (p->d_park_state) (void)hipFree(p->d_park_state);
+    if (p->d_park_rng) (void)hipFree(p->d_park_rng);
+    if (p->d_park_pred) (void)hipFree(p->d_park_pred);
     if (p->in) (void)hipStreamDestroy(p->in);
     if (p->run) (void)hipStreamDestroy(p->run);
     if (p->out) (void)hipStreamDestroy(p->out);
@@ -199,6 +230,7 @@ extern "C" int heaac_pipeline_create(HeaacPipeline **out, const HeaacAacConfig *
              (!p->he || devmem((void **)&s->d_sbr, n * sizeof(HeaacSbrFrame))) &&
              (!with_ps || devmem((void **)&s->d_ps, n * sizeof(HeaacPsFrame))) &&
              devmem((void **)&s->d_pcm, n * (size_t)p->nout * p->out_len * 2) &&
+             (s->failed = (unsigned char *)calloc(n, 1)) != NULL &&
              hipEventCreate(&s->in_start) == hipSuccess && hipEventCreate(&s->in_done) == hipSuccess &&
              hipEventCreate(&s->run_done) == hipSuccess && hipEventCreate(&s->out_done) == hipSuccess;
         if (ok) {
@@ -322,6 +354,37 @@ extern "C" int heaac_pipeline_submit(HeaacPipeline *p, const uint8_t *const *au,
     // GPU
     HIP_OK(hipStreamWaitEvent(p->run, s->in_done, 0));
     if (s->used) HIP_OK(hipStreamWaitEvent(p->run, s->out_done, 0));
+    // streams whose unit failed: park their state rows (state, noise generator, predictors) before the launches ...
+    size_t n_failed = 0;
+    for (size_t i = 0; i < n; i++) n_failed += s->failed[i];
+    const size_t pred_row = (size_t)p->ncore * HEAAC_MAX_PREDICTORS;
+    if (n_failed > p->park_rows) {
+        // (grown outside the streams' order: nothing of the old area is in flight once `run` has drained)
+        HIP_OK(hipStreamSynchronize(p->run));
+        if (p->d_park_state) (void)hipFree(p->d_park_state);
+        if (p->d_park_rng) (void)hipFree(p->d_park_rng);
+        if (p->d_park_pred) (void)hipFree(p->d_park_pred);
+        p->d_park_state = NULL; p->d_park_rng = NULL; p->d_park_pred = NULL; p->park_rows = 0;
+        size_t rows = 64;
+        while (rows < n_failed) rows *= 2;
+        if (rows > n) rows = n;
+        if (!devmem((void **)&p->d_park_state, rows * p->words * 4) || !devmem((void **)&p->d_park_rng, rows * 4) ||
+            (p->d_pred && !devmem((void **)&p->d_park_pred, rows * pred_row * sizeof(HeaacPredictorState))))
+            return HEAAC_ERR_NOMEM;
+        p->park_rows = rows;
+    }
+    if (n_failed) {
+        size_t j = 0;
+        for (size_t i = 0; i < n; i++) {
+            if (!s->failed[i]) continue;
+            HIP_OK(hipMemcpyAsync(p->d_park_state + j * p->words, p->d_state + i * p->words, p->words * 4, hipMemcpyDeviceToDevice, p->run));
+            HIP_OK(hipMemcpyAsync(p->d_park_rng + j, p->d_rng + i, 4, hipMemcpyDeviceToDevice, p->run));
+            if (p->d_pred)
+                HIP_OK(hipMemcpyAsync(p->d_park_pred + j * pred_row, p->d_pred + i * pred_row, pred_row * sizeof(HeaacPredictorState),
+                                      hipMemcpyDeviceToDevice, p->run));
+            j++;
+        }
+    }
     int rc = heaac_spectral_tools_batch(p->dev, p->ncore, s->d_coeffs, s->d_tools, p->d_rng, p->d_rng, p->d_pred, p->d_pred, n,
                                         (void *)p->run);
     if (rc == HEAAC_OK)
@@ -331,6 +394,21 @@ extern "C" int heaac_pipeline_submit(HeaacPipeline *p, const uint8_t *const *au,
                    : heaac_lc_decode_batch(p->dev, p->ncore, s->d_coeffs, s->d_ics, p->d_state, p->d_state, s->d_pcm,
                                            HEAAC_PCM_S16_INTERLEAVED, n, (void *)p->run);
     if (rc != HEAAC_OK) return rc;
+    // ... and put them back, with silence where the decode wrote
+    if (n_failed) {
+        const size_t pcm_row = (size_t)p->nout * p->out_len;
+        size_t j = 0;
+        for (size_t i = 0; i < n; i++) {
+            if (!s->failed[i]) continue;
+            HIP_OK(hipMemcpyAsync(p->d_state + i * p->words, p->d_park_state + j * p->words, p->words * 4, hipMemcpyDeviceToDevice, p->run));
+            HIP_OK(hipMemcpyAsync(p->d_rng + i, p->d_park_rng + j, 4, hipMemcpyDeviceToDevice, p->run));
+            if (p->d_pred)
+                HIP_OK(hipMemcpyAsync(p->d_pred + i * pred_row, p->d_park_pred + j * pred_row, pred_row * sizeof(HeaacPredictorState),
+                                      hipMemcpyDeviceToDevice, p->run));
+            HIP_OK(hipMemsetAsync(s->d_pcm + i * pcm_row, 0, pcm_row * 2, p->run));
+            j++;
+        }
+    }
     HIP_OK(hipEventRecord(s->run_done, p->run));
     // D2H
     HIP_OK(hipStreamWaitEvent(p->out, s->run_done, 0));

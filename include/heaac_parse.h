@@ -116,8 +116,8 @@ long heaac_adts_split(const uint8_t *buf, size_t size, HeaacAdtsPacket *out, siz
 typedef struct HeaacAacStream {
     uint8_t window_sequence[2];   /* of the previous frame, per channel */
     uint8_t use_kb_window[2];
-    uint8_t cce_window_sequence[2];   /* the same for the coupling channels in slot 0 / 1 (heaac_aac_parse_frame_ex) */
-    uint8_t cce_use_kb_window[2];
+    uint8_t cce_window_sequence[16];  /* the same for the coupling channels, by instance tag (che[TYPE_CCE][tag]) */
+    uint8_t cce_use_kb_window[16];
 } HeaacAacStream;
 
 typedef struct HeaacAacFrameInfo {

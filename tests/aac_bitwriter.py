@@ -303,7 +303,19 @@ def expected_coeffs(d, exp_sf):
                 for w in range(gl):
                     for k in range(v.shape[1]):
                         m = mag(v[w, k])
-                        out[base + 128 * w + off[i] + k] = (np.float32(-m) if v[w, k] < 0 else m) * s
+                        neg = v[w, k] < 0
+                        if v[w, k] == 0:
+                            # The sign of a ZERO line.  The reference multiplies by the scalefactor with its sign bit
+                            # flipped by "the sign bit now at the head of the pending ones", and only a non-zero line
+                            # consumes one: in the unsigned quad books (VMUL4S, aacdec.c:949-972) a zero line therefore
+                            # carries the sign of the next non-zero line of its quad, in book 11 (:1199-1201) the first
+                            # line of a pair that of the second; the signed books and VMUL2S (books 7-10) do not.
+                            if b in (3, 4):
+                                rest = [x for x in v[w, k + 1:(k // 4 + 1) * 4] if x != 0]
+                                neg = bool(rest) and rest[0] < 0
+                            elif b == 11 and k % 2 == 0:
+                                neg = v[w, k + 1] < 0
+                        out[base + 128 * w + off[i] + k] = (np.float32(-m) if neg else m) * s
             idx += 1
         base += gl * 128
     return out

@@ -136,3 +136,66 @@ def test_pipeline_equals_the_calls_made_one_after_the_other(pkg, dev, cfgname):
     tm = pl.timing()
     assert tm["parse"] > 0 and tm["gpu"] > 0
     pl.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfgname", ["CFG_HEV2", "CFG_LC_STEREO"])
+def test_a_damaged_access_unit_gives_silence_and_leaves_its_stream_as_it_was(pkg, dev, cfgname):
+    """one unit of one stream does not parse (a reserved window grouping / truncated core element).  That
+    stream's PCM of the tick is zero, and from the next tick on it decodes exactly as a stream that never saw the
+    damaged unit; every other stream is untouched.  With and without a status array."""
+    import torch
+    cfg = getattr(pkg, cfgname)
+    he = cfg == pkg.CFG_HEV2
+    rng = np.random.default_rng(404 + he)
+    n, ticks, bad_tick, bad = 9, 6, 2, [3, 7]
+    if he:
+        aus = _ticks(pkg, rng, 1, True, n, ticks)
+        m4 = TS._he_cfg(pkg, 1, True)
+    else:
+        aus = [[TP._write_au(rng, 3, 1, True, extras=True, quiet=True)[0] for _ in range(n)] for _ in range(ticks)]
+        m4 = TP._cfg(pkg, 1, 3, 2)                                   # AAC-Main: the predictors are state too
+    good = [list(a) for a in aus]
+    for i in bad:
+        aus[bad_tick][i] = aus[bad_tick][i][:5] + bytes(8)           # the core element ends inside its side info
+    results = []
+    for with_status in (True, False):
+        pl = pkg.Pipeline(m4, cfg, n, threads=2)
+        got = []
+        for t in range(ticks):
+            st = pl.submit(aus[t], with_status=with_status)
+            if t == bad_tick and with_status:
+                assert all(st[i] < 0 for i in bad) and all(st[i] >= 0 for i in range(n) if i not in bad)
+            got.append(pl.collect().copy())
+        pl.close()
+        results.append(got)
+    assert all(np.array_equal(a, b) for a, b in zip(*results))
+    got = results[0]
+    # the reference run: the damaged tick is simply absent for the damaged streams
+    pl = pkg.Pipeline(m4, cfg, n, threads=1)
+    ref = []
+    for t in range(ticks):
+        pl.submit(good[t])
+        ref.append(pl.collect().copy())
+    pl.close()
+    for i in range(n):
+        if i not in bad:
+            for t in range(ticks):
+                assert np.array_equal(got[t][i], ref[t][i]), (t, i)
+    # a damaged stream: silence at the tick, and afterwards what a pipeline gives that was fed the same units with
+    # the damaged one left out
+    for i in bad:
+        assert not got[bad_tick][i].any()
+        assert np.array_equal(got[bad_tick - 1][i], ref[bad_tick - 1][i])
+    pl = pkg.Pipeline(m4, cfg, n, threads=1)
+    skip = []
+    for t in range(ticks):
+        if t == bad_tick:
+            continue
+        pl.submit(good[t])
+        skip.append(pl.collect().copy())
+    pl.close()
+    for i in bad:
+        for t in range(bad_tick + 1, ticks):
+            assert np.array_equal(got[t][i], skip[t - 1][i]), (t, i)
+        assert any(got[t][i].any() for t in range(bad_tick + 1, ticks))
