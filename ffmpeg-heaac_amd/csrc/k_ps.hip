@@ -10,10 +10,12 @@
 // H-matrix interpolation) runs over time inside one lane, so the reference's operation order is
 // kept and parallelism comes from the 71 / 91 hybrid bands.  Plain QMF bands are columns held in
 // registers; the hybrid sub-subbands of the lowest 3 / 5 QMF bands are kept in LDS.
+#include <stdlib.h>
 #include "k_common.h"
 #include "kernels.h"
 
 #include "k_hf.h"
+#include "k_hfr.h"       // (hf_frame_is_fast; the register form of the HF stage is a measurement-build kernel's)
 #include "k_psf.h"
 
 template <bool GENERAL, int WAVES>
@@ -81,7 +83,7 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
             const HeaacSbrHeader *__restrict__ g_hdr, unsigned n_hdr, const HeaacPsFrame *__restrict__ g_ps,
             const float *g_W, const float *g_state_in, float *g_state_out, int state_words,
             int off_sbr, int off_ps, float *g_X, unsigned long long n_frames, unsigned *g_queue,
-            unsigned char *__restrict__ g_xtop)
+            unsigned char *__restrict__ g_xtop, int skip_fast)
 {
     using WT = PsWaveT<false>;
     static_assert(WT::SCR <= HF_XLOW_WORDS, "|s|^2 / subL / subR lie over X_low");
@@ -128,6 +130,11 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
             }
         };
         const bool base = __builtin_amdgcn_readfirstlane(!ps_frame_is_general(&g_ps[f]));
+        // the frames k_hfps12 takes (baseline PS on the common SBR configuration) are not this kernel's
+        if (skip_fast && base && __builtin_amdgcn_readfirstlane(hf_frame_is_fast(&g_sbr[f], g_hdr, n_hdr))) {
+            feed.advance();
+            continue;
+        }
         float *Xf = g_X + (f * 2) * HE_X_CHANNEL;
         v2f *Xf2 = reinterpret_cast<v2f *>(Xf);
         const float *st_in = g_state_in + f * state_words;
@@ -184,6 +191,114 @@ void k_hfps(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g
     l2_touch_drain();
 }
 
+
+#ifdef HEAAC_TUNING
+// ---------------------------------------------------------------------------
+// k_hfps12: the same fusion at TWELVE waves per CU (three per SIMD).  k_hfps stands at 256 VGPRs and 19.4 KB of LDS
+// per wave -- two waves per SIMD, each parked on its own LDS / memory round trips for nearly half its cycles
+// (profiles/r03_pmc_a.csv) -- and both budgets have to shrink for a third wave: <= 168 registers, <= 13.2 KB.
+//   * X_low leaves LDS: the HF stage keeps each band's row in its lane's registers (k_hfr.h), which are the very
+//     registers the PS stage's QMF column needs afterwards;
+//   * the PS arrays go on the general layout's diet (PsWaveT<false, true>: left mix in place, |s|^2 eight slots at a
+//     time) and lie over the HF stage's limiter sums and records;
+//   * the slot loop fetches the 14-slot delay tail as it goes.
+// It takes the frames with the baseline PS layout on the common SBR configuration (hf_frame_is_fast); k_hfps runs
+// behind it for the rest.
+// ---------------------------------------------------------------------------
+#define HFPS12_WAVES 12
+
+__global__ __launch_bounds__(HFPS12_WAVES * WAVE)
+void k_hfps12(const float *__restrict__ g_tab, const HeaacSbrFrame *__restrict__ g_sbr,
+              const HeaacSbrHeader *__restrict__ g_hdr, unsigned n_hdr, const HeaacPsFrame *__restrict__ g_ps,
+              const float *g_W, const float *g_state_in, float *g_state_out, int state_words,
+              int off_sbr, int off_ps, float *g_X, unsigned long long n_frames, unsigned *g_queue,
+              unsigned char *__restrict__ g_xtop)
+{
+    using WT = PsWaveT<false, true>;
+    static_assert(WT::SCR >= 8 + 5 * 3 * 64, "the limiter sums, then the per-envelope gains, lie under the |s|^2 / right-mix scratch");
+    static_assert(20 * 33 >= HFR_REC_WORDS, "header and channel record lie under the band powers");
+    __shared__ float s_scr[HFPS12_WAVES][WT::SCR];                    // HF: bw, sumA, sumB, bandv | PS: |s|^2, then right mix
+    __shared__ float s_sub[HFPS12_WAVES][WT::SUBROWS][SUB_STRIDE];    // PS: sub-subband rows, left mix in place
+    __shared__ float s_pw[HFPS12_WAVES][20 * 33];                     // HF: header, channel       | PS: band power / transient gain
+    __shared__ HeaacPsFrame s_p[HFPS12_WAVES];
+    __shared__ float s_inb[HFPS12_WAVES][WT::NLOW][44][2];
+    __shared__ float s_Hs[HFPS12_WAVES][6][WT::NH][WT::NPAR];
+    __shared__ signed char s_idx[HFPS12_WAVES][2][5][WT::NPAR];
+    __shared__ float s_noise[1024];
+    __shared__ float s_hyb[8 * 14 + 8];
+    __shared__ float s_dump[64];
+    wg_copy_f4(s_noise, g_tab + TB_NOISE, 1024);
+    if (threadIdx.x < 112) s_hyb[threadIdx.x] = g_tab[TB_F20_0_8 + threadIdx.x];
+    if (threadIdx.x < 8) s_hyb[112 + threadIdx.x] = g_tab[TB_G1_Q2 + threadIdx.x];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
+    const HfWave H = hf_wave_view(nullptr, s_scr[wave], s_pw[wave]);
+    WT W = { s_p[wave], s_inb[wave], s_scr[wave], s_sub[wave], s_sub[wave],
+             reinterpret_cast<float (*)[SUB_STRIDE]>(s_scr[wave]),
+             reinterpret_cast<float (*)[33]>(s_pw[wave]), s_Hs[wave], s_idx[wave][0], s_idx[wave][1],
+             s_idx[wave][0], s_idx[wave][0], s_hyb, s_hyb + 112 };
+    const unsigned sink = lds_addr(s_dump);
+    FrameFeed<HFPS_QUEUE_CHUNK> feed;
+    feed.init((unsigned long long)blockIdx.x * HFPS12_WAVES + wave, (unsigned long long)gridDim.x * HFPS12_WAVES, g_queue, lane);
+    while (feed.cur < n_frames) {
+        const unsigned long long f = feed.cur, f1 = feed.nxt;
+        feed.request(lane);
+        const bool mine = __builtin_amdgcn_readfirstlane(!ps_frame_is_general(&g_ps[f]) && hf_frame_is_fast(&g_sbr[f], g_hdr, n_hdr));
+        if (!mine) {
+            feed.advance();
+            continue;
+        }
+        constexpr int TOUCH_RECORDS_SLOT = 20;
+        auto prefetch_next = [&](int n) {
+            if (n == TOUCH_RECORDS_SLOT && f1 < n_frames) {
+                l2_touch(&g_sbr[f1], sizeof(HeaacSbrFrame), lane, sink);
+                l2_touch(&g_ps[f1], sizeof(HeaacPsFrame), lane, sink);
+            }
+        };
+        float *Xf = g_X + (f * 2) * HE_X_CHANNEL;
+        const float *st_in = g_state_in + f * state_words;
+        float *st_out = g_state_out + f * state_words;
+        float (*inb)[44][2] = s_inb[wave];
+        uint32_t preg[3];
+        float hist_re = 0.0f, hist_im = 0.0f;
+        {
+            const uint32_t *ps_ = reinterpret_cast<const uint32_t *>(&g_ps[f]);
+#pragma unroll
+            for (int r = 0; r < 3; r++) preg[r] = lane + 64 * r < (int)(sizeof(HeaacPsFrame) / 4) ? ps_[lane + 64 * r] : 0;
+            if (lane < WT::NLOW * 6) {
+                hist_re = st_in[off_ps + HEAAC_PS_INBUF + 2 * lane];
+                hist_im = st_in[off_ps + HEAAC_PS_INBUF + 2 * lane + 1];
+            }
+        }
+        v2f xl[40];
+        hf_channel_rx(H, s_noise, &g_sbr[f], g_hdr, n_hdr, g_W + f * 2048, st_in + off_sbr, st_out + off_sbr, lane, xl,
+                      [&]() {
+                          uint32_t *pd = reinterpret_cast<uint32_t *>(&s_p[wave]);
+#pragma unroll
+                          for (int r = 0; r < 3; r++)
+                              if (lane + 64 * r < (int)(sizeof(HeaacPsFrame) / 4)) pd[lane + 64 * r] = preg[r];
+                          if (lane < WT::NLOW * 6) { inb[lane / 6][lane % 6][0] = hist_re; inb[lane / 6][lane % 6][1] = hist_im; }
+                      });
+        // look-ahead slots of the hybrid analysis (aacps.c:362-367): X[.][32..37] of the three lowest bands
+        if (lane < WT::NLOW) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) { inb[lane][38 + j][0] = xl[34 + j].x; inb[lane][38 + j][1] = xl[34 + j].y; }
+        }
+        // (the header and the channel record are about to be overwritten by the band powers)
+        const int top = __builtin_amdgcn_readfirstlane(H.h.kx + H.h.m);
+        const int t_old = H.c[0].t_env_num_env_old;
+        const bool x_zero_above = __builtin_amdgcn_readfirstlane(
+            2 * t_old - 32 <= 0 || (int)g_sbr[f].kx_old + (int)g_sbr[f].m_old <= ((top + 15) & ~15));
+        wave_sync();
+        ps_frame<false, true>(W, g_tab, &g_ps[f], top, st_in + off_ps, st_out + off_ps, Xf, lane, wave,
+                              *reinterpret_cast<const v2f (*)[32]>(&xl[2]), prefetch_next, g_xtop + 2 * f, x_zero_above);
+        feed.advance();
+    }
+    l2_touch_drain();
+}
+
+#endif   // HEAAC_TUNING
+
 #define PS_WAVES_20 8
 #define PS_WAVES_GEN 5
 
@@ -217,11 +332,27 @@ extern "C" int heaac_launch_hfps(const float *d_tab, const HeaacSbrFrame *d_sbr,
                                  unsigned char *d_xtop, hipStream_t s)
 {
     if (!n) return HEAAC_OK;
+    int skip_fast = 0;
+#ifdef HEAAC_TUNING
+    // Measurement builds only (profiles/r04_experiments.md E1): HEAAC_HFPS12=1 hands the frames with the baseline PS layout
+    // on the common SBR configuration to the twelve-wave kernel first (queue head [0]); k_hfps then takes the rest
+    // ([3]).  The product runs k_hfps alone: the twelve-wave kernel is bit-exact but slower (168 VGPRs leave the
+    // slot loops spilling; see the experiment notes).
+    static const bool use12 = []() { const char *e = getenv("HEAAC_HFPS12"); return e && e[0] == '1'; }();
+    if (use12) {
+        unsigned long long g12 = (n + HFPS12_WAVES - 1) / HFPS12_WAVES;
+        if (g12 > 256) g12 = 256;
+        hipLaunchKernelGGL(k_hfps12, dim3((unsigned)g12), dim3(HFPS12_WAVES * WAVE), 0, s, d_tab, d_sbr, d_hdr, n_hdr, d_ps,
+                           d_ws_W, d_state_in, d_state_out, state_words, off_sbr, off_ps, d_ws_X,
+                           (unsigned long long)n, d_queue, d_xtop);
+        skip_fast = 1;
+    }
+#endif
     unsigned long long g = (n + HFPS_WAVES - 1) / HFPS_WAVES;
     if (g > 256) g = 256;
     hipLaunchKernelGGL(k_hfps, dim3((unsigned)g), dim3(HFPS_WAVES * WAVE), 0, s, d_tab, d_sbr, d_hdr, n_hdr, d_ps,
                        d_ws_W, d_state_in, d_state_out, state_words, off_sbr, off_ps, d_ws_X,
-                       (unsigned long long)n, d_queue, d_xtop);
+                       (unsigned long long)n, d_queue + (skip_fast ? 3 : 0), d_xtop, skip_fast);
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
 }
 

@@ -35,6 +35,7 @@ struct BandMembers {
     unsigned char first[36];      // first[i] .. first[i+1]: members of band i
     int split;                    // bands [0,split) and [split,nr_par) hold about half the members each
     int quarter[5];               // the same in four parts: bands [quarter[j], quarter[j + 1])
+    int eighth[9];                // and in eight
 };
 constexpr BandMembers make_members(const KtoI &t, int nr_bands, int nr_par)
 {
@@ -57,6 +58,13 @@ constexpr BandMembers make_members(const KtoI &t, int nr_bands, int nr_par)
         for (int i = m.quarter[j - 1]; i <= nr_par; i++)
             if (4 * m.first[i] >= j * pos) { m.quarter[j] = i; break; }
     }
+    m.eighth[0] = 0;
+    m.eighth[8] = nr_par;
+    for (int j = 1; j < 8; j++) {
+        m.eighth[j] = nr_par;
+        for (int i = m.eighth[j - 1]; i <= nr_par; i++)
+            if (8 * m.first[i] >= j * pos) { m.eighth[j] = i; break; }
+    }
     return m;
 }
 __device__ constexpr BandMembers kMem20 = make_members(k_to_i_20_c, 71, 20);
@@ -65,8 +73,12 @@ __device__ constexpr BandMembers kMem34 = make_members(k_to_i_34_c, 91, 34);
 // Per-wave LDS.  GENERAL = false: baseline PS -- frames that are and were 20-band with
 // IPD/OPD off (what HE-AACv2 encoders emit) -- small enough for 8 waves per CU.  GENERAL = true: any
 // layout, including 20 <-> 34 switches.
-template <bool GENERAL>
+// SLIM (the twelve-wave fused kernel, k_hfps12): the baseline layout on the general layout's diet -- left mix in place,
+// |s|^2 eight slots at a time, the 14-slot delay tail fetched as the slots need it -- 12.2 KB per wave all told.
+template <bool GENERAL, bool SLIM_ = false>
 struct PsWaveT {
+    static constexpr bool SLIM = SLIM_;
+    static constexpr bool INPLACE_L = GENERAL || SLIM_;      // the left mix overwrites the sub-subband row it was made from
     static constexpr int NSUB = GENERAL ? 32 : 10;
     static constexpr int NLOW = GENERAL ? 5 : 3;
     static constexpr int NB = GENERAL ? 91 : 71;
@@ -77,12 +89,14 @@ struct PsWaveT {
     // The general layout saves LDS for a fifth wave per CU (round 3): the left mix of a sub-subband overwrites the
     // sub-subband signal it was made from (one more row: the scratch row of the lanes that are not sub-subbands), and
     // |s|^2 is formed for sixteen slots at a time.
-    static constexpr int SUBROWS = GENERAL ? NSUB + 1 : NSUB;
-    static constexpr int PN_SLOTS = GENERAL ? 16 : 32;
-    static constexpr int MIXROWS = GENERAL ? (NSUB + 1) : 2 * (NSUB + 1);     // rows of mixed output kept in the scratch
+    static constexpr int SUBROWS = INPLACE_L ? NSUB + 1 : NSUB;
+    static constexpr int PN_SLOTS = SLIM_ ? 8 : GENERAL ? 16 : 32;
+    static constexpr int MIXROWS = INPLACE_L ? (NSUB + 1) : 2 * (NSUB + 1);     // rows of mixed output kept in the scratch
     // scratch shared by |s|^2 (until the band powers are formed) and the mixed
     // sub-subband outputs (written afterwards): max of the two, in floats
-    static constexpr int SCR = (PN_SLOTS * PNS > MIXROWS * SUB_STRIDE) ? PN_SLOTS * PNS : MIXROWS * SUB_STRIDE;
+    static constexpr int SCR0 = (PN_SLOTS * PNS > MIXROWS * SUB_STRIDE) ? PN_SLOTS * PNS : MIXROWS * SUB_STRIDE;
+    // (the slim kernel lays its HF stage's limiter sums and per-envelope gains under the scratch: 8 + 5 * 3 * 64 words)
+    static constexpr int SCR = SLIM_ && SCR0 < 968 ? 968 : SCR0;
     // Views of separate __shared__ arrays (distinct objects for the alias analysis).
     HeaacPsFrame &p;
     float (*inb)[44][2];               // [NLOW] hybrid analysis input: 6 history + 38 current slots
@@ -252,13 +266,20 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
     // last.  The other lanes aim the load at their slot 13 again (one line instead of fourteen: 6 KB less per frame).
     v2f hst[14];
     const int first_slot = allpass ? 12 : d14 ? 0 : 13;
-#pragma unroll
-    for (int j = HEAVY ? 0 : 13; j < 14; j++) {
+    // SLIM: slots 12 and 13 now (the all-pass and one-slot bands' whole tail), slots 0..11 -- which only the twelve
+    // 14-slot bands read -- HST_AHEAD slots before their use inside the loop: four live pairs instead of fourteen
+    constexpr int HST_AHEAD = 4;
+    auto hst_load = [&](int j) {
         const int kv = opaque(kh * 8);
         const int js = (HEAVY && j < 13 && j < first_slot) ? 13 : j;
         const v2f t = (HEAVY && j < 13) ? SI.ldb2(kv + js * (dl_stride * 4), HEAAC_PS_DELAY)
                                         : SI.ldb2(kv, HEAAC_PS_DELAY + j * dl_stride);
-        hst[j] = clear_state ? zero : t;
+        return clear_state ? zero : t;
+    };
+#pragma unroll
+    for (int j = HEAVY ? 0 : 13; j < 14; j++) {
+        if (W::SLIM && HEAVY && j >= HST_AHEAD && j < 12) continue;
+        hst[j] = hst_load(j);
     }
     // all-pass history: ring of 5 per link, position = time mod 5 (state j = time j - 5)
     v2f ring[3][5];
@@ -317,6 +338,9 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
 #pragma unroll
     for (int n = 0; n < 32; n++) {
         hook(n);
+        if constexpr (W::SLIM && HEAVY) {
+            if (n + HST_AHEAD < 12) hst[n + HST_AHEAD] = hst_load(n + HST_AHEAD);
+        }
         if ((!ALIGNED8 || (n & 7) == 0) && n > stop) {
             // next envelope (aacps.c:900-938)
             e++;
@@ -350,7 +374,7 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
             // exec-mask branch of its own.
             v2f subv = srow[n];
             v2f sub2;                                             // sub-subbands are all-pass bands: D = 2
-            if constexpr (W::IS_GENERAL) {
+            if constexpr (W::INPLACE_L) {
                 // (the row is being overwritten by the left mix: the two samples back are kept in registers)
                 sub2 = sub_back[n & 1];
                 sub_back[n & 1] = subv;
@@ -407,7 +431,7 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
         if (HEAVY) {
             *reinterpret_cast<v2f *>(lrow + 2 * n) = lv;
             *reinterpret_cast<v2f *>(rrow + 2 * n) = rr;
-            if constexpr (W::IS_GENERAL) {
+            if constexpr (W::INPLACE_L) {
                 // new delay-line tail = s[k][18..31], stored as the slots pass (the sub-subband rows do not survive the loop)
                 if (n >= 18) SO.stb2(sv, opaque(kh * 8), HEAAC_PS_DELAY + (n - 18) * dl_stride);
             }
@@ -436,7 +460,7 @@ __device__ __forceinline__ void ps_band(W &w, const float *__restrict__ g_tab, c
         if ((n & (PS_SCHED_GROUP - 1)) == PS_SCHED_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
     }
     // new delay-line tail = s[k][18..31]
-    if constexpr (!(HEAVY && W::IS_GENERAL))
+    if constexpr (!(HEAVY && W::INPLACE_L))
 #pragma unroll
     for (int j = 0; j < 14; j++) {
         v2f v = col[18 + j];
@@ -494,6 +518,18 @@ __device__ __forceinline__ void band_power4(const float *row, float *pw_col, int
     else if (quarter == 2) band_power_range<IS34, M.quarter[2], M.quarter[3]>(row, pw_col);
     else                   band_power_range<IS34, M.quarter[3], M.quarter[4]>(row, pw_col);
 }
+__device__ __forceinline__ void band_power8_20(const float *row, float *pw_col, int part)
+{
+    constexpr BandMembers M = kMem20;
+    if (part == 0)      band_power_range<false, M.eighth[0], M.eighth[1]>(row, pw_col);
+    else if (part == 1) band_power_range<false, M.eighth[1], M.eighth[2]>(row, pw_col);
+    else if (part == 2) band_power_range<false, M.eighth[2], M.eighth[3]>(row, pw_col);
+    else if (part == 3) band_power_range<false, M.eighth[3], M.eighth[4]>(row, pw_col);
+    else if (part == 4) band_power_range<false, M.eighth[4], M.eighth[5]>(row, pw_col);
+    else if (part == 5) band_power_range<false, M.eighth[5], M.eighth[6]>(row, pw_col);
+    else if (part == 6) band_power_range<false, M.eighth[6], M.eighth[7]>(row, pw_col);
+    else                band_power_range<false, M.eighth[7], M.eighth[8]>(row, pw_col);
+}
 template <bool IS34>
 __device__ __forceinline__ void band_power(const float *row, float *pw_col, int half)
 {
@@ -517,8 +553,8 @@ __device__ __forceinline__ bool ps_frame_is_general(const HeaacPsFrame *g_p)
 // FUSED also means: the caller has already copied the frame's PS record into w.p and the hybrid
 // filters' history (in_buf state) into w.inb[.][0..5] (k_hfps issues those loads at the start of the
 // frame, beside the HF stage's own).
-template <bool GENERAL, bool FUSED = false, class Hook = NoHook>
-__device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__restrict__ g_tab,
+template <bool GENERAL, bool FUSED = false, bool SLIM = false, class Hook = NoHook>
+__device__ __forceinline__ void ps_frame(PsWaveT<GENERAL, SLIM> &w, const float *__restrict__ g_tab,
                                          const HeaacPsFrame *g_p, int top_qmf,
                                          const float *st_in, float *st_out,
                                          float *Xrec /* [2][38][64][re, im]: in: mono in [0], out: left, right */,
@@ -526,11 +562,12 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
                                          unsigned char *x_bands_out = nullptr, bool x_zero_above_top = false)
 {
     static_assert(!(GENERAL && FUSED), "the fused path is the baseline layout only");
+    static_assert(!SLIM || (FUSED && !GENERAL), "the slim layout is the fused kernel's");
     // `lane` is redefined opaquely at every phase: values derived from it (LDS addresses,
     // band indices) then live for one phase instead of being hoisted out of the frame loop
     // into registers that end up spilled.
     int lane = opaque(lane_in);
-    using WT = PsWaveT<GENERAL>;
+    using WT = PsWaveT<GENERAL, SLIM>;
     constexpr int XC = HE_X_CHANNEL;
     const GBuf SI(st_in), X(Xrec);
     const GBufXR XR(Xrec);
@@ -586,7 +623,7 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
         // hybrid index of the lane's column (unless it is one of the nlow hybrid-filter inputs)
         const int kh_own = GENERAL ? (lane >= nsub ? lane : 64 + lane) : lane + 7;
         if (GENERAL ? (lane >= nsub || lane < P2) : lane >= 3) {
-            if constexpr (!GENERAL) {
+            if constexpr (!GENERAL && !SLIM) {
 #pragma unroll
                 for (int n = 0; n < 32; n++) w.pn[n * WT::PNS + kh_own] = col[n].x * col[n].x + col[n].y * col[n].y;
             }
@@ -662,7 +699,8 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
         tr_peak = SI.ld(lane, HEAAC_PS_PEAK); tr_smooth = SI.ld(lane, HEAAC_PS_PSMOOTH);
         tr_diff = SI.ld(lane, HEAAC_PS_PDIFF);
     }
-    if (lane < nr_par) {
+    auto fetch_lut = [&]() {
+      if (lane < nr_par) {
         const int b = lane;
         const float *LUT = g_tab + ((p.icc_mode < 3) ? TB_HA : TB_HB);
 #pragma unroll
@@ -675,7 +713,10 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
             const float4 h4 = *reinterpret_cast<const float4 *>(LUT + (row * 8 + colx) * 4);
             hl[e][0] = h4.x; hl[e][1] = h4.y; hl[e][2] = h4.z; hl[e][3] = h4.w;
         }
-    }
+      }
+    };
+    // (early, to land during the hybrid filters and the band powers -- unless registers are what is short)
+    if constexpr (!SLIM) fetch_lut();
 #pragma unroll
     for (int i = 0; i < NHL; i++) {
         const int t = lane + WAVE * i, j = t / WT::NPAR, b = t % WT::NPAR;
@@ -686,7 +727,7 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
     auto hybrid_put = [&](int ks, int n, float re, float im) {
         w.sub[ks][2 * n] = re;
         w.sub[ks][2 * n + 1] = im;
-        if constexpr (!GENERAL) w.pn[n * WT::PNS + ks] = re * re + im * im;
+        if constexpr (!GENERAL && !SLIM) w.pn[n * WT::PNS + ks] = re * re + im * im;
     };
     if (!is34) {
         // 20-band layout: 10 sub-subbands x 32 slots = five passes of the wave; pass `it` forms the
@@ -774,6 +815,31 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
             else      band_power4<false>(row, &w.pw[0][16 * r + n], quarter);
             wave_sync();
         }
+    } else if constexpr (SLIM) {
+        // eight slots at a time: |s|^2 of the lane's column (lanes 3..63: hybrid bands 10..70) and of the ten
+        // sub-subband rows, then the sums with eight lanes per slot, each an eighth of the parameter bands' members
+        const int kh_own = lane + 7;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (lane >= 3) {
+#pragma unroll
+                for (int n = 0; n < 8; n++) {
+                    const v2f c = col[8 * r + n];
+                    w.pn[n * WT::PNS + kh_own] = c.x * c.x + c.y * c.y;
+                }
+            }
+            if (lane < 10) {
+#pragma unroll
+                for (int n = 0; n < 8; n++) {
+                    const float re = w.sub[lane][2 * (8 * r + n)], im = w.sub[lane][2 * (8 * r + n) + 1];
+                    w.pn[n * WT::PNS + lane] = re * re + im * im;
+                }
+            }
+            wave_sync();
+            const int n = lane & 7, part = lane >> 3;
+            band_power8_20(w.pn + n * WT::PNS, &w.pw[0][8 * r + n], part);
+            wave_sync();
+        }
     } else {
         const int n = lane & 31, half = lane >> 5;
         const float *row = w.pn + n * WT::PNS;
@@ -787,12 +853,17 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
         const int i = lane;
         float peak = tr_peak, smooth = tr_smooth, diff = tr_diff;
         if (switched) { peak = 0.0f; smooth = 0.0f; diff = 0.0f; }
-        float prow[32];
-#pragma unroll
-        for (int n = 0; n < 32; n++) prow[n] = w.pw[i][n];
+        // (the slim layout reads the powers eight slots at a time: the QMF column holds 64 registers meanwhile)
+        constexpr int PG = SLIM ? 8 : 32;
+        float prow[PG];
 #pragma unroll
         for (int n = 0; n < 32; n++) {
-            const float pwr = prow[n];
+            if (n % PG == 0) {
+#pragma unroll
+                for (int q = 0; q < PG; q++) prow[q] = w.pw[i][n + q];
+                if (SLIM) __builtin_amdgcn_sched_barrier(0);
+            }
+            const float pwr = prow[n % PG];
             const float decayed_peak = 0.76592833836465f * peak;
             peak = decayed_peak > pwr ? decayed_peak : pwr;
             smooth += 0.25f * (pwr - smooth);
@@ -825,6 +896,7 @@ __device__ __forceinline__ void ps_frame(PsWaveT<GENERAL> &w, const float *__res
         }
     }
     wave_sync();
+    if constexpr (SLIM) fetch_lut();
     bool h_ok = true;
     float h_prev[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
     if (lane < nr_par) {
