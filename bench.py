@@ -188,6 +188,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse)")
     ap.add_argument("--gather", action="store_true",
                     help="also time the PCM gather onto rank 0 (BASELINE config 5), reported separately")
+    ap.add_argument("--gather-check", action="store_true",
+                    help="with --gather: SHA-256 of every rank's PCM shard and of what rank 0 gathered (tests)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearse launch / rendezvous / barriers / JSON without touching a GPU (CPU tests)")
     args = ap.parse_args()
@@ -289,14 +291,21 @@ def main():
     # device time of one step's launches: HIP events on the launch stream (the library launches on
     # torch's current stream, the one these events are recorded on)
     kern_ms = (sum(a.elapsed_time(b) for a, b in ev) if ev else elapsed * 1e3) / max(1, args.steps)
-    gather_ms = None
+    gather_ms, gather_check = None, None
     if args.gather and dist is not None:
         shard = importlib.import_module(g.PKG_NAME + ".shard")
         src = pcm if on_gpu_comm else pcm.cpu()
         sync(); dist.barrier(); tg = time.perf_counter()
-        shard.gather_pcm(src, src.shape[0] * world, dst=0)
+        full = shard.gather_pcm(src, src.shape[0] * world, dst=0)
         sync(); dist.barrier()
         gather_ms = (time.perf_counter() - tg) * 1e3
+        if args.gather_check:
+            import hashlib
+            mine = hashlib.sha256(pcm.cpu().numpy().tobytes()).hexdigest()
+            hashes = [None] * world
+            dist.all_gather_object(hashes, mine)
+            gather_check = dict(shards=hashes, device=[local, torch.cuda.current_device() if not dry else None],
+                                gathered=hashlib.sha256(full.cpu().numpy().tobytes()).hexdigest() if rank == 0 else None)
     if dist is not None:
         t = torch.tensor([elapsed, kern_ms], device="cuda" if on_gpu_comm else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -309,14 +318,23 @@ def main():
         if fmt == pkg.PCM_S16:      # int16 PCM out instead of f32: 2 bytes/sample less
             bytes_per_frame -= pkg.OUT_CH[cfg] * pkg.OUT_LEN[cfg] * 2
         achieved = bytes_per_frame * n / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per step: NOT measured in this run (the PMC passes need rocprofv3 around the process) but read
+        # from profiles/traffic.json, where tools/traffic.sh left it for this workload and PCM format (rocprofv3
+        # --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied).  An entry counts only if
+        # it was taken on the kernels that are running now (its kernel_sha = the hash of today's device
+        # sources); traffic_source says which entry, at which git head, or why there is none.
+        traffic, traffic_source = None, {"file": "profiles/traffic.json", "key": "%s_%s" % (workload, args.pcm)}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            # HBM bytes per frame measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate
-            # passes, gfx950 correction applied) on this workload; scaled to one step here
-            rec = json.load(open(tpath)).get("%s_%s" % (workload, args.pcm))
-            if rec:
-                traffic = rec["bytes_per_frame"] * n
+        rec = json.load(open(tpath)).get(traffic_source["key"]) if os.path.exists(tpath) else None
+        if rec is None:
+            traffic_source["status"] = "no entry"
+        elif rec.get("kernel_sha") != pkg.kernel_source_sha():
+            traffic_source.update(status="stale: measured on other kernel sources", head=rec.get("head"),
+                                  kernel_sha=rec.get("kernel_sha"), now=pkg.kernel_source_sha())
+        else:
+            traffic = rec["bytes_per_frame"] * n
+            traffic_source.update(status="ok", head=rec.get("head"), kernel_sha=rec["kernel_sha"],
+                                  bytes_per_frame=rec["bytes_per_frame"])
         out = {
             "metric": "HE-AAC frames/s (batched)", "value": value, "unit": "frames/s",
             "n_gpus": world, "per_gpu_value": value / world, "steps": args.steps, "warmup": args.warmup,
@@ -326,16 +344,24 @@ def main():
                        "bytes_per_frame": bytes_per_frame, "flops_per_frame": ALGO_FLOPS[workload],
                        "parallelism": "frames sharded by index, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": kern_ms,
                          # second ceiling: plain f32 add/mul, no FMA by construction
                          "gflops": ALGO_FLOPS[workload] * n / (kern_ms * 1e-3) / 1e9,
                          "gflops_peak_nofma": VALU_NOFMA_PEAK_GFLOPS},
         }
+        if not dry and cfg != pkg.CFG_LC_STEREO:
+            # how many bands of the X rows the HF / PS stage stored for the timed batch (the rest is +0 and neither
+            # written nor fetched): the headline leans on this share, so it is part of the workload's description
+            out["config"]["x_bands_stored"] = dev.x_bands_shares(n)
+        if pkg.LIB_OVERRIDDEN:
+            out["library"] = pkg.LIB_PATH          # a variant build (HEAAC_LIB_PATH), not the product library
         if dry:
             out["dry_run"] = True
         if gather_ms is not None:
             out["pcm_gather_ms"] = gather_ms
+        if gather_check is not None:
+            out["pcm_gather_check"] = gather_check
         if world == 1 and not args.no_cpu_baseline and not dry:
             out["cpu_baseline"] = cpu_baseline(pkg, synth, cfg)
         print(json.dumps(out))

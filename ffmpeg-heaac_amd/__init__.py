@@ -18,8 +18,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # HEAAC_LIB_PATH: measurement tooling (tools/abv.sh) points the binding at a variant build under ab/
-# without touching the product library; unset everywhere else.
-LIB_PATH = os.environ.get("HEAAC_LIB_PATH") or os.path.join(_HERE, "libheaac_amd.so")
+# without touching the product library; unset everywhere else.  Never silently: the override is announced on
+# stderr when the library is loaded, LIB_OVERRIDDEN says so to whoever reports numbers (bench.py prints it).
+PRODUCT_LIB_PATH = os.path.join(_HERE, "libheaac_amd.so")
+LIB_PATH = os.environ.get("HEAAC_LIB_PATH") or PRODUCT_LIB_PATH
+LIB_OVERRIDDEN = os.path.realpath(LIB_PATH) != os.path.realpath(PRODUCT_LIB_PATH)
 
 # ---- constants (include/heaac_dsp.h) ----
 ONLY_LONG_SEQUENCE, LONG_START_SEQUENCE, EIGHT_SHORT_SEQUENCE, LONG_STOP_SEQUENCE = 0, 1, 2, 3
@@ -164,6 +167,21 @@ def validate_frame(cfg, sbr, hdr, ps=None):
 _lib = None
 
 
+def kernel_source_sha():
+    """SHA-256 over the device sources and their headers (csrc/*.hip, csrc/*.h, include/heaac_dsp.h): a measurement
+    stored under profiles/ is tied to the kernels it was taken on (bench.py refuses a traffic figure whose stamp
+    differs)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "heaac_dsp.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def lib():
     """Load libheaac_amd.so; raise loudly if it has not been built."""
     global _lib
@@ -178,6 +196,10 @@ def lib():
             import torch  # noqa: F401
         except ImportError:
             pass
+        if LIB_OVERRIDDEN:
+            import sys
+            print("ffmpeg-heaac_amd: HEAAC_LIB_PATH is set -- using %s instead of the product library" % LIB_PATH,
+                  file=sys.stderr)
         _lib = C.CDLL(LIB_PATH)
         _lib.heaac_strerror.restype = C.c_char_p
         _lib.heaac_build_info.restype = C.c_char_p
@@ -255,6 +277,13 @@ class Device:
             self.close()
         except Exception:
             pass
+
+    def x_bands_shares(self, n):
+        """include/heaac_debug.h: the share of (frame, channel) X records of the last HE decode call that were
+        stored with 32 / 48 / 64 bands, as {"32": .., "48": .., "64": ..}."""
+        buf = np.zeros(2 * n, np.uint8)
+        _check(lib().heaac_debug_xbands(self._h, buf.ctypes.data_as(C.c_void_p), C.c_size_t(n)), "heaac_debug_xbands")
+        return {str(b): round(float((buf == b).mean()), 4) for b in (32, 48, 64)}
 
     # -- transforms --
     def imdct_half(self, which, x):

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "heaac_dsp.h"
+#include "heaac_debug.h"
 #include "tables.h"
 #include "kernels.h"
 
@@ -401,8 +402,7 @@ extern "C" int heaac_pcm_interleave_batch(HeaacDevice *dev, int channels, const 
     return heaac_launch_interleave(channels, planes, len, pcm_format, d_out, n, (hipStream_t)stream);
 }
 
-// Debug/test hook: device pointers of the stage workspace of the LAST chunk
-// (W[chunk][2][32][32][2], X[chunk][2][2][38][64]).  Not part of include/*.h.
+// include/heaac_debug.h: device pointers of workspace set 0
 extern "C" int heaac_debug_workspace(HeaacDevice *dev, float **d_W, float **d_X, size_t *chunk)
 {
     if (!dev) return HEAAC_ERR_ARG;
@@ -410,6 +410,14 @@ extern "C" int heaac_debug_workspace(HeaacDevice *dev, float **d_W, float **d_X,
     if (d_X) *d_X = (float *)dev->d_work + dev->chunk * WS_W_FLOATS;      /* set 0 */
     if (chunk) *chunk = dev->chunk;
     return HEAAC_OK;
+}
+
+extern "C" int heaac_debug_xbands(HeaacDevice *dev, unsigned char *host_out, size_t n_frames)
+{
+    if (!dev || !host_out || n_frames > dev->chunk) return HEAAC_ERR_ARG;
+    if (hipDeviceSynchronize() != hipSuccess) return HEAAC_ERR_HIP;
+    return hipMemcpy(host_out, dev->d_aux + HE_ZERO_BYTES, 2 * n_frames, hipMemcpyDeviceToHost) == hipSuccess
+               ? HEAAC_OK : HEAAC_ERR_HIP;
 }
 
 // internal: device table pointers for shim.hip

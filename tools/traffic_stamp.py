@@ -1,0 +1,24 @@
+"""Merge gpurun_out/traffic_new.json (tools/traffic.sh, measured on the GPU box) into profiles/traffic.json and stamp
+each merged entry with the git head it belongs to: an entry is accepted only if its kernel_sha equals the hash of the
+device sources in the working tree (so the head named is one whose kernels were measured).
+usage: python3 tools/traffic_stamp.py [round]"""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g
+sha = g.load_package().kernel_source_sha()
+head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+dirty = subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "ffmpeg-heaac_amd/csrc", "include"], text=True).strip()
+new = json.load(open(os.path.join(ROOT, "gpurun_out", "traffic_new.json")))
+path = os.path.join(ROOT, "profiles", "traffic.json")
+allrec = json.load(open(path)) if os.path.exists(path) else {}
+for key, rec in new.items():
+    if rec.get("kernel_sha") != sha:
+        print("skip %s: measured on kernel sources %s, the tree has %s" % (key, rec.get("kernel_sha"), sha))
+        continue
+    rec["head"] = head + ("+uncommitted kernel changes" if dirty else "")
+    if len(sys.argv) > 1:
+        rec["round"] = int(sys.argv[1])
+    allrec[key] = rec
+    print("merged %s: %d bytes per frame at %s" % (key, rec["bytes_per_frame"], rec["head"]))
+json.dump(allrec, open(path, "w"), indent=1)
