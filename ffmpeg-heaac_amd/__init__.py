@@ -97,7 +97,7 @@ TOOLS_FRAME_DT = np.dtype([
     ("ch", TOOLS_CH_DT, (2,)),
 ])
 assert TOOLS_ICS_DT.itemsize == 144 and TNS_DT.itemsize == 2668 and TOOLS_FRAME_DT.itemsize == 7132
-MAX_CCE, MAX_CCE_LINKS = 2, 4
+MAX_CCE, MAX_CCE_LINKS = 16, 4
 CC_BEFORE_TNS, CC_BETWEEN_TNS_AND_IMDCT, CC_AFTER_IMDCT = 0, 1, 3
 TOOLS_PRE, TOOLS_POST, TOOLS_ALL = 1, 2, 3
 CCE_LINK_DT = np.dtype([("target_ch", "u1"), ("pad", "u1", (3,)), ("gain", "<f4", (120,))])

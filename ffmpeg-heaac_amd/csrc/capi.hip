@@ -313,12 +313,17 @@ extern "C" int heaac_he_decode_batch_ex(HeaacDevice *dev, int cfg, int flags,
     // (event fork / join, so the call stays capturable into a hipGraph)
     const bool lanes = n > dev->chunk && dev->sets > 1;
     const int nl = lanes ? dev->sets : 1;
-    if (lanes) {
-        if (hipEventRecord(dev->fork, s) != hipSuccess) return HEAAC_ERR_HIP;
-        for (int k = 0; k < nl; k++)
-            if (hipStreamWaitEvent(dev->lane[k], dev->fork, 0) != hipSuccess) return HEAAC_ERR_HIP;
-    }
+    // (every exit behind he_claim goes through the join and he_release below: a failed fork must not leave the
+    // workspace claimed or lanes that were already forked unjoined)
     int rc = HEAAC_OK;
+    int forked = 0;
+    if (lanes) {
+        if (hipEventRecord(dev->fork, s) != hipSuccess) rc = HEAAC_ERR_HIP;
+        for (int k = 0; k < nl && rc == HEAAC_OK; k++) {
+            if (hipStreamWaitEvent(dev->lane[k], dev->fork, 0) != hipSuccess) rc = HEAAC_ERR_HIP;
+            else forked = k + 1;
+        }
+    }
     size_t c = 0;
     for (size_t f0 = 0; f0 < n && rc == HEAAC_OK; f0 += dev->chunk, c++) {
         const size_t nc = n - f0 < dev->chunk ? n - f0 : dev->chunk;
@@ -336,7 +341,7 @@ extern "C" int heaac_he_decode_batch_ex(HeaacDevice *dev, int cfg, int flags,
     }
     if (lanes) {
         // always rejoin, also after a failed launch (a capture must not be left forked)
-        for (int k = 0; k < nl; k++)
+        for (int k = 0; k < forked; k++)
             if (hipEventRecord(dev->join[k], dev->lane[k]) != hipSuccess ||
                 hipStreamWaitEvent(s, dev->join[k], 0) != hipSuccess)
                 rc = rc == HEAAC_OK ? HEAAC_ERR_HIP : rc;

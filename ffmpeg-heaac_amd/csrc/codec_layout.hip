@@ -375,6 +375,7 @@ int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void
     if (heaac_pcm_interleave_batch(d->dev, d->layout.channels, planes, len, HEAAC_PCM_S16_INTERLEAVED, d->d_pcm, 1, NULL) != HEAAC_OK)
         return -1;
     const int bytes = len * d->layout.channels * 2;
+    if (*data_size < bytes) return -1;                       // "Output buffer too small" (aacdec.c:2087-2092)
     if (hipMemcpy(data, d->d_pcm, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     *data_size = bytes;
     if (out) {

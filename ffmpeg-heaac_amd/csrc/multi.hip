@@ -124,6 +124,9 @@ extern "C" int heaac_multi_create(HeaacMulti **out, const int *devices, int n_de
     for (int g = 0; g < launched && rc == HEAAC_OK; g++) rc = m->slot[g].init_rc;
     // every device must reach the gather target and vice versa (no-op when already enabled or the same device)
     if (rc == HEAAC_OK) {
+        // (on the caller's thread: its current device is put back afterwards)
+        int caller_device = -1;
+        if (hipGetDevice(&caller_device) != hipSuccess) { (void)hipGetLastError(); caller_device = -1; }
         for (int a = 0; a < n_devices; a++)
             for (int b = 0; b < n_devices; b++) {
                 int can = 0;
@@ -135,6 +138,7 @@ extern "C" int heaac_multi_create(HeaacMulti **out, const int *devices, int n_de
                     }
                 }
             }
+        if (caller_device >= 0) (void)hipSetDevice(caller_device);
     }
     if (rc != HEAAC_OK) {
         m->n = launched;

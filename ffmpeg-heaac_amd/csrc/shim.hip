@@ -540,6 +540,7 @@ static int dec_frame_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p, vo
     }
     if (rc != HEAAC_OK) return -1;
     const int bytes = p->out_len * p->nout * 2;
+    if (*data_size < bytes) return -1;                       // "Output buffer too small" (aacdec.c:2087-2092)
     if (hipMemcpy(data, p->d_pcm, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     *data_size = bytes;
     // aacdec.c:2102-2107: bytes consumed, or the whole packet when only zero padding follows
@@ -646,6 +647,7 @@ static int dec_frame(HeaacCodecContext *avctx, void *data, int *data_size, Heaac
     if (rc != HEAAC_OK) return -1;
     // *data_size = samples * channels * sizeof(int16_t) (aacdec.c:2087-2094)
     const int bytes = p->out_len * p->nout * 2;
+    if (*data_size < bytes) return -1;                       // "Output buffer too small" (aacdec.c:2087-2092)
     if (hipMemcpy(data, p->d_pcm, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     *data_size = bytes;
     return (int)need;            // bytes consumed (aacdec.c:2102-2107)

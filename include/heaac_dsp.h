@@ -506,7 +506,7 @@ int heaac_spectral_tools_batch(HeaacDevice *dev, int channels, float *d_coeffs,
  * and IMDCT.  (The third point, AFTER_IMDCT, is heaac_couple_after_imdct_batch above.)
  * ------------------------------------------------------------------------ */
 enum { HEAAC_CC_BEFORE_TNS = 0, HEAAC_CC_BETWEEN_TNS_AND_IMDCT = 1, HEAAC_CC_AFTER_IMDCT = 3 };   /* aac.h:83-87 */
-#define HEAAC_MAX_CCE 2               /* coupling elements per access unit carried by the batched records */
+#define HEAAC_MAX_CCE 16              /* coupling elements per access unit carried by the batched records */
 #define HEAAC_MAX_CCE_LINKS 4         /* gain lists of one coupling element that land on the (one) target element */
 
 /* One gain list of a coupling element applied to one channel of the target element: coup->gain[index][] with the

@@ -275,7 +275,8 @@ int heaac_aac_parse_frame_layout(const HeaacAacConfig *cfg, HeaacAacLayout *layo
  *                                            unit left it out
  *   cce->coeffs [HEAAC_MAX_CCE][1024], cce->ics [HEAAC_MAX_CCE], cce->tools [HEAAC_MAX_CCE] (channel 0)
  * The coupling channels' window history is st[0].cce_window_sequence / cce_use_kb_window.  info->n_cce = coupling
- * elements found.  A coupling element beyond the layout's first HEAAC_MAX_CCE, or with more than
+ * elements found (HEAAC_MAX_CCE = 16: one slot per instance tag, every coupling element a layout can name).  A
+ * coupling element with more than
  * HEAAC_MAX_CCE_LINKS gain lists on one output element: HEAAC_PARSE_ERR_UNSUPPORTED. */
 int heaac_aac_parse_frame_layout_ex(const HeaacAacConfig *cfg, HeaacAacLayout *layout, HeaacAacStream *st,
                                     const uint8_t *au, int size,

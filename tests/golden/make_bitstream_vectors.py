@@ -39,6 +39,8 @@ COUPLED_STREAMS = {
     "lc_pce_5_1_coupled_48k": (2, 3, [(SCE, 0), (CPE, 0), (CPE, 1), (LFE, 0)], [3, 9], [0, 1, 3], 6, 821),
     "main_pce_pair_coupled_48k": (1, 3, [(CPE, 2)], [6], [0, 1, 3], 6, 822),
     "hev1_pce_three_coupled_24k": (2, 6, [(SCE, 0), (CPE, 0), (LFE, 1)], [4, 11], [0, 1, 3], 6, 823),   # SBR: si = 6
+    # four coupling elements on one pair (round 4: HEAAC_MAX_CCE covers every instance tag; the reference has no limit)
+    "lc_pce_pair_four_coupled_48k": (2, 3, [(CPE, 1)], [0, 5, 9, 15], [0, 1, 3], 5, 824),
 }
 
 

@@ -537,15 +537,16 @@ def test_coupling_elements_of_a_program_config_layout(pkg):
                     assert int(rec["link"][n]["target_ch"]) == tch
                     assert np.array_equal(rec["link"][n]["gain"].view(np.uint32), gl.view(np.uint32))
     assert points_seen == {0, 1, 3} and linked > 20
-    # without the coupling records the element is outside the entry; the third coupling element of the layout too;
-    # one the program did not name is not allocated
+    # without the coupling records the element is outside the entry; the third coupling element of the layout is taken
+    # like the first two (HEAAC_MAX_CCE = 16 since round 4: every tag the syntax has); one the program did not name is
+    # not allocated
     def one(tag, with_cce):
         bw = W.BitWriter()
         write_elem(bw, rng, si, aot, SCE, 4)
         TW.write_cce(bw, rng, si, aot, tag, [(0, 4, 2)], 0)
         bw.put(7, 3)
         return pkg.aac_parse_frame_layout(cfg, l0.copy(), st.copy(), bw.bytes(), with_cce=with_cce)[0]
-    assert one(3, True) == 0 and one(3, False) == -3 and one(12, True) == -3 and one(5, True) == -1 and one(5, False) == -1
+    assert one(3, True) == 0 and one(3, False) == -3 and one(12, True) == 0 and one(5, True) == -1 and one(5, False) == -1
     # an SBR payload behind a coupling element is that element's own (decode_extension_payload hands it to che_prev,
     # :2059; read_sbr_data takes TYPE_CCE as a single channel, aacsbr.c:986): reported in cce_elem, or outside the entry
     bw = W.BitWriter()

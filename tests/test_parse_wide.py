@@ -260,11 +260,13 @@ def test_program_config_elements_are_read_past_and_mono_spectra_pack(pkg):
         # the same unit through the two-channel layout gives the same spectrum in channel 0
         r2, got2 = pkg.aac_parse_frame_ex(cfg, np.zeros(1, pkg.AAC_STREAM_DT), au, coeff_channels=2)
         assert r2 == 0 and np.array_equal(got2["coeffs"][0].view(np.uint32), got["coeffs"][0].view(np.uint32))
-    # a pair cannot be packed into one channel; a third coupling element, a second output element are outside the slice
+    # a pair cannot be packed into one channel; a second output element is outside the slice
     au, _ = build_au(rng, si, aot, True, [])
     assert pkg.aac_parse_frame_ex(TP._cfg(pkg, aot, si, 2), np.zeros(1, pkg.AAC_STREAM_DT), au, coeff_channels=1)[0] == -4
-    au, _ = build_au(rng, si, aot, False, [(1, [(0, 0, 2)], 0, False), (2, [(0, 0, 2)], 1, False), (3, [(0, 0, 2)], 1, True)])
-    assert pkg.aac_parse_frame_ex(cfg, np.zeros(1, pkg.AAC_STREAM_DT), au)[0] == -3
+    # three coupling elements (and up to one per instance tag): taken since round 4
+    au, exp3 = build_au(rng, si, aot, False, [(1, [(0, 0, 2)], 0, False), (2, [(0, 0, 2)], 1, False), (3, [(0, 0, 2)], 1, True)])
+    r3, got3 = pkg.aac_parse_frame_ex(cfg, np.zeros(1, pkg.AAC_STREAM_DT), au)
+    check(pkg, r3, got3, exp3, False, si)
     bw = W.BitWriter()
     write_target(bw, rng, si, aot, False); write_target(bw, rng, si, aot, False); bw.put(7, 3)
     assert pkg.aac_parse_frame_ex(cfg, np.zeros(1, pkg.AAC_STREAM_DT), bw.bytes())[0] == -3
