@@ -129,6 +129,10 @@ EXPORTED = [
     "heaac_asc_parse", "heaac_ga_specific_config", "heaac_aac_parse_frame_ex", "heaac_pcm_interleave_batch", "heaac_aac_layout_default", "heaac_aac_layout_from_pce", "heaac_aac_layout_from_au", "heaac_asc_layout", "heaac_aac_parse_frame_layout", "heaac_aac_parse_frame_layout_ex", "heaac_spectral_tools_batch_ex", "heaac_codec_get_context_defaults", "heaac_adts_parse_header", "heaac_adts_probe", "heaac_adts_split",
     "heaac_heaac_parse_frame_ex", "heaac_pipeline_create", "heaac_pipeline_destroy", "heaac_pipeline_submit",
     "heaac_pipeline_collect", "heaac_pipeline_timing",
+    "heaac_layout_pipeline_create", "heaac_layout_pipeline_destroy", "heaac_layout_pipeline_submit",
+    "heaac_layout_pipeline_collect",
+    # heaac_debug.h
+    "heaac_debug_workspace", "heaac_debug_xbands",
     "heaac_multi_shard", "heaac_multi_create", "heaac_multi_destroy", "heaac_multi_devices", "heaac_multi_device",
     "heaac_multi_stream", "heaac_multi_he_decode", "heaac_aac_parse_frame", "heaac_aac_parse_batch",
     "heaac_aac_tables_fingerprint",
@@ -168,13 +172,15 @@ _lib = None
 
 
 def kernel_source_sha():
-    """SHA-256 over the device sources and their headers (csrc/*.hip, csrc/*.h, include/heaac_dsp.h): a measurement
-    stored under profiles/ is tied to the kernels it was taken on (bench.py refuses a traffic figure whose stamp
-    differs)."""
+    """SHA-256 over the DEVICE sources (csrc/k_*.hip, csrc/k_*.h, kernels.h, tables.h, validate.h) and the record
+    header include/heaac_dsp.h: a measurement stored under profiles/ is tied to the kernels it was taken on (bench.py
+    refuses a traffic figure whose stamp differs).  Host-side sources (parsers, pipelines, the C API) do not count."""
     import glob
     import hashlib
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")))
+    d = os.path.join(_HERE, "csrc")
+    files = sorted(glob.glob(os.path.join(d, "k_*.hip")) + glob.glob(os.path.join(d, "k_*.h")))
+    files += [os.path.join(d, f) for f in ("kernels.h", "tables.h", "validate.h")]
     files.append(os.path.join(os.path.dirname(_HERE), "include", "heaac_dsp.h"))
     for f in files:
         h.update(os.path.basename(f).encode())
@@ -575,6 +581,39 @@ class Pipeline:
     def close(self):
         if self._h:
             lib().heaac_pipeline_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class LayoutPipeline:
+    """include/heaac_pipeline.h, second half: n streams of one multi-element layout, access units in, int16 PCM out."""
+
+    def __init__(self, aac_cfg, layout, n_streams, threads=0):
+        self._h = C.c_void_p()
+        self.n, self.ch = n_streams, int(layout[0]["channels"])
+        he = aac_cfg.sbr == 1
+        self.len = 2048 if he and not (aac_cfg.ext_sample_rate and aac_cfg.ext_sample_rate < 2 * aac_cfg.sample_rate) else 1024
+        self._layout = np.ascontiguousarray(layout)
+        _check(lib().heaac_layout_pipeline_create(C.byref(self._h), C.byref(aac_cfg), self._layout.ctypes.data_as(C.c_void_p),
+                                                  C.c_size_t(n_streams), threads), "heaac_layout_pipeline_create")
+
+    def submit(self, aus):
+        assert len(aus) == self.n
+        keep = [C.create_string_buffer(bytes(a), len(a)) for a in aus]
+        ptrs = (C.c_char_p * self.n)(*[C.cast(k, C.c_char_p) for k in keep])
+        sizes = (C.c_int * self.n)(*[len(a) for a in aus])
+        status = np.zeros(self.n, np.int32)
+        _check(lib().heaac_layout_pipeline_submit(self._h, ptrs, sizes, status.ctypes.data_as(C.c_void_p)),
+               "heaac_layout_pipeline_submit")
+        return status
+
+    def collect(self):
+        p = C.POINTER(C.c_int16)()
+        _check(lib().heaac_layout_pipeline_collect(self._h, C.byref(p)), "heaac_layout_pipeline_collect")
+        return np.ctypeslib.as_array(p, shape=(self.n, self.len, self.ch))
+
+    def close(self):
+        if self._h:
+            lib().heaac_layout_pipeline_destroy(self._h)
             self._h = C.c_void_p()
 
 

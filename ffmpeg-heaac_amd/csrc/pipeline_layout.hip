@@ -1,0 +1,474 @@
+// pipeline_layout.hip -- include/heaac_pipeline.h, second half: n streams of ONE multi-element layout (3.0 ... 7.1, a
+// program config layout) advance in lock step, access units in host memory in, interleaved int16 PCM in host memory
+// out.  What codec_layout.hip does for one stream with batches of one -- aac_decode_frame's element loop
+// (aacdec.c:1999-2076), spectral_to_sample per element (:1903-1933), float_to_int16_interleave over output_data[]
+// (:2096-2097) -- done for all streams at once: the parsed records are laid out ELEMENT-major
+// ([element][stream]), so every element of the layout is one batched tools call and one batched decode call over the
+// n streams, and one interleave launch writes [n][len][channels].
+//   * one noise generator per stream, run through the elements in bitstream order: the streams of a pipeline must
+//     share that order (encoders emit one order; the first good unit sets it).  A stream that deviates, leaves an
+//     element out or fails to parse gets silence for the tick and keeps its decoder state (as heaac_pipeline does);
+//   * SBR per element (explicit signalling: m4ac.sbr = 1), "pure upsampling" where an element has no payload;
+//   * layouts whose program config element names coupling channel elements are not taken here (one
+//     heaac_codec_decode context per such stream): HEAAC_ERR_ARG at create.
+// Two buffer sets rotate: the host parses tick t + 1 while tick t is on the link and on the GPU.
+#include <hip/hip_runtime.h>
+#include <alloca.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include "heaac_pipeline.h"
+#include "codec_layout.h"        // heaac_sbr_output_mode
+
+#define LP_DEPTH 2
+#define LP_MAX_HDRS 4096
+
+struct LpElem {
+    int channels, cfg, words;
+    // persistent, device
+    float *d_state;                 // [n][words]
+    HeaacPredictorState *d_pred;    // [n][channels][672] (AAC-Main) or NULL
+    float *d_f32;                   // [n][channels][len]: the element's planes of the tick in work
+    HeaacSbrStream *sst;            // [n] host: the element's SBR reader state per stream
+};
+
+struct LpSet {
+    // per element, [n] each; pinned host / device
+    float *h_coeffs[HEAAC_MAX_ELEMENTS], *d_coeffs[HEAAC_MAX_ELEMENTS];
+    HeaacIcs *h_ics[HEAAC_MAX_ELEMENTS], *d_ics[HEAAC_MAX_ELEMENTS];
+    HeaacToolsFrame *h_tools[HEAAC_MAX_ELEMENTS], *d_tools[HEAAC_MAX_ELEMENTS];
+    HeaacSbrFrame *h_sbr[HEAAC_MAX_ELEMENTS], *d_sbr[HEAAC_MAX_ELEMENTS];
+    int16_t *h_pcm, *d_pcm;
+    unsigned char *failed;          // [n]
+    unsigned char *seq;             // [n][ne] bitstream position of each element
+    hipEvent_t done;
+    int used;
+};
+
+struct HeaacLayoutPipeline {
+    HeaacAacConfig aac;
+    HeaacAacLayout layout;
+    int ne, he, downsampled, len, main_profile;
+    size_t n;
+    HeaacDevice *dev;
+    hipStream_t run;
+    LpElem e[HEAAC_MAX_ELEMENTS];
+    LpSet set[LP_DEPTH];
+    int32_t *d_rng;
+    HeaacSbrHeader *d_hdr; size_t hdr_uploaded;
+    HeaacSbrHeaderTable *tab;
+    HeaacAacStream *ast;            // [n][ne]
+    HeaacAacLayout *lay;            // [n]: every stream's own tag map
+    int have_order; unsigned char order[HEAAC_MAX_ELEMENTS];     // order[seq] = element at that bitstream position
+    // parked state of the streams whose unit failed
+    float *d_park; size_t park_bytes;
+    unsigned long submitted, collected;
+    // pool
+    int threads;
+    pthread_t *tid;
+    pthread_mutex_t mu;
+    pthread_cond_t cv_go, cv_done;
+    unsigned long generation;
+    int pending, quit;
+    const uint8_t *const *job_au; const int *job_size; int *job_status; LpSet *job_set;
+};
+
+struct LpWorkerArg { HeaacLayoutPipeline *p; int w; };
+
+static inline HeaacSbrStream *sst_at(HeaacSbrStream *base, size_t i)
+{
+    return (HeaacSbrStream *)((char *)base + i * heaac_sbr_stream_bytes());
+}
+
+// neutral records of one stream: silence, no tools, no SBR payload (from a COPY of the SBR reader state)
+static void neutral(HeaacLayoutPipeline *p, LpSet *s, size_t i)
+{
+    for (int k = 0; k < p->ne; k++) {
+        const int ch = p->e[k].channels;
+        memset(s->h_coeffs[k] + i * (size_t)ch * 1024, 0, (size_t)ch * 4096);
+        memset(s->h_ics[k] + i * ch, 0, ch * sizeof(HeaacIcs));
+        memset(&s->h_tools[k][i], 0, sizeof(HeaacToolsFrame));
+        if (p->he) {
+            void *tmp = alloca(heaac_sbr_stream_bytes());
+            memcpy(tmp, sst_at(p->e[k].sst, i), heaac_sbr_stream_bytes());
+            heaac_sbr_no_payload((HeaacSbrStream *)tmp, ch, &s->h_sbr[k][i], NULL);
+        }
+    }
+}
+
+static void lp_parse_slice(HeaacLayoutPipeline *p, int w)
+{
+    const size_t lo = p->n * (size_t)w / (size_t)p->threads, hi = p->n * (size_t)(w + 1) / (size_t)p->threads;
+    LpSet *s = p->job_set;
+    const int ne = p->ne;
+    float *tc = (float *)malloc((size_t)ne * 2048 * sizeof(float));
+    HeaacIcs *ti = (HeaacIcs *)malloc((size_t)ne * 2 * sizeof(HeaacIcs));
+    HeaacToolsFrame *tt = (HeaacToolsFrame *)malloc((size_t)ne * sizeof(HeaacToolsFrame));
+    HeaacAacElementInfo te[HEAAC_MAX_ELEMENTS];
+    HeaacAacStream st[HEAAC_MAX_ELEMENTS];
+    for (size_t i = lo; i < hi; i++) {
+        int r = HEAAC_PARSE_ERR_ARG;
+        HeaacAacFrameInfo fi;
+        memset(&fi, 0, sizeof(fi));
+        if (tc && ti && tt) {
+            // the parser works on copies of the window histories until the whole unit has parsed
+            for (int k = 0; k < ne; k++) st[k] = p->ast[i * ne + k];
+            r = heaac_aac_parse_frame_layout_ex(&p->aac, &p->lay[i], st, p->job_au[i], p->job_size[i], tc, ti, tt, te, NULL, &fi);
+            for (int k = 0; r == HEAAC_PARSE_OK && k < ne; k++)
+                if (!te[k].present) r = HEAAC_PARSE_ERR_DATA;      // an element of the layout left out (codec_layout.hip: refused)
+        }
+        if (p->job_status) p->job_status[i] = r;
+        s->failed[i] = (unsigned char)(r != HEAAC_PARSE_OK);
+        if (r != HEAAC_PARSE_OK) {
+            neutral(p, s, i);
+            continue;
+        }
+        for (int k = 0; k < ne; k++) {
+            const int ch = p->e[k].channels;
+            p->ast[i * ne + k] = st[k];
+            s->seq[i * ne + k] = te[k].seq;
+            memcpy(s->h_coeffs[k] + i * (size_t)ch * 1024, tc + (size_t)k * 2048, (size_t)ch * 4096);
+            memcpy(s->h_ics[k] + i * ch, ti + k * 2, ch * sizeof(HeaacIcs));
+            s->h_tools[k][i] = tt[k];
+            if (p->he) {
+                // a failed payload leaves its degraded record (start = 0) and the decode goes on, as ff_sbr_apply does
+                if (te[k].sbr_payload_bit >= 0)
+                    (void)heaac_sbr_parse_payload(sst_at(p->e[k].sst, i), p->tab, p->aac.sample_rate, p->job_au[i], p->job_size[i],
+                                                  te[k].sbr_payload_bit, te[k].sbr_payload_bytes, te[k].sbr_crc, ch,
+                                                  te[k].sbr_misplaced ? HEAAC_SBR_MISPLACED : 0, &s->h_sbr[k][i], NULL, NULL);
+                else
+                    heaac_sbr_no_payload(sst_at(p->e[k].sst, i), ch, &s->h_sbr[k][i], NULL);
+            }
+        }
+    }
+    free(tc); free(ti); free(tt);
+}
+
+static void *lp_worker(void *arg)
+{
+    LpWorkerArg *a = (LpWorkerArg *)arg;
+    HeaacLayoutPipeline *p = a->p;
+    const int w = a->w;
+    free(a);
+    unsigned long seen = 0;
+    pthread_mutex_lock(&p->mu);
+    for (;;) {
+        while (p->generation == seen && !p->quit) pthread_cond_wait(&p->cv_go, &p->mu);
+        if (p->quit) break;
+        seen = p->generation;
+        pthread_mutex_unlock(&p->mu);
+        lp_parse_slice(p, w);
+        pthread_mutex_lock(&p->mu);
+        if (--p->pending == 0) pthread_cond_signal(&p->cv_done);
+    }
+    pthread_mutex_unlock(&p->mu);
+    return NULL;
+}
+
+static int lp_pinned(void **p, size_t bytes) { return hipHostMalloc(p, bytes, hipHostMallocDefault) == hipSuccess; }
+static int lp_devmem(void **p, size_t bytes) { return hipMalloc(p, bytes) == hipSuccess; }
+
+extern "C" void heaac_layout_pipeline_destroy(HeaacLayoutPipeline *p)
+{
+    if (!p) return;
+    if (p->tid) {
+        pthread_mutex_lock(&p->mu);
+        p->quit = 1;
+        pthread_cond_broadcast(&p->cv_go);
+        pthread_mutex_unlock(&p->mu);
+        for (int t = 1; t < p->threads; t++) if (p->tid[t]) pthread_join(p->tid[t], NULL);
+        free(p->tid);
+        pthread_mutex_destroy(&p->mu);
+        pthread_cond_destroy(&p->cv_go);
+        pthread_cond_destroy(&p->cv_done);
+    }
+    if (p->run) (void)hipStreamSynchronize(p->run);
+    for (int q = 0; q < LP_DEPTH; q++) {
+        LpSet *s = &p->set[q];
+        for (int k = 0; k < HEAAC_MAX_ELEMENTS; k++) {
+            void *h[] = { s->h_coeffs[k], s->h_ics[k], s->h_tools[k], s->h_sbr[k] };
+            void *d[] = { s->d_coeffs[k], s->d_ics[k], s->d_tools[k], s->d_sbr[k] };
+            for (void *x : h) if (x) (void)hipHostFree(x);
+            for (void *x : d) if (x) (void)hipFree(x);
+        }
+        if (s->h_pcm) (void)hipHostFree(s->h_pcm);
+        if (s->d_pcm) (void)hipFree(s->d_pcm);
+        if (s->done) (void)hipEventDestroy(s->done);
+        free(s->failed); free(s->seq);
+    }
+    for (int k = 0; k < HEAAC_MAX_ELEMENTS; k++) {
+        if (p->e[k].d_state) (void)hipFree(p->e[k].d_state);
+        if (p->e[k].d_pred) (void)hipFree(p->e[k].d_pred);
+        if (p->e[k].d_f32) (void)hipFree(p->e[k].d_f32);
+        free(p->e[k].sst);
+    }
+    if (p->d_rng) (void)hipFree(p->d_rng);
+    if (p->d_hdr) (void)hipFree(p->d_hdr);
+    if (p->d_park) (void)hipFree(p->d_park);
+    if (p->run) (void)hipStreamDestroy(p->run);
+    heaac_sbr_table_destroy(p->tab);
+    free(p->ast); free(p->lay);
+    heaac_device_destroy(p->dev);
+    free(p);
+}
+
+extern "C" int heaac_layout_pipeline_create(HeaacLayoutPipeline **out, const HeaacAacConfig *aac, const HeaacAacLayout *layout,
+                                            size_t n, int threads)
+{
+    if (!out) return HEAAC_ERR_ARG;
+    *out = NULL;
+    if (!aac || !layout || !n || layout->n_elements < 1 || layout->n_elements > HEAAC_MAX_ELEMENTS ||
+        layout->channels < 1 || layout->channels > HEAAC_MAX_PCM_PLANES || aac->sampling_index < 0 || aac->sampling_index > 12 ||
+        (aac->sbr != 0 && aac->sbr != 1))                 // implicit signalling (-1) is settled per stream by its first unit
+        return HEAAC_ERR_ARG;
+    for (int id = 0; id < 16; id++)
+        if (layout->slot_of[HEAAC_ELEM_CCE][id]) return HEAAC_ERR_ARG;         // coupling elements: heaac_codec_decode
+    HeaacLayoutPipeline *p = (HeaacLayoutPipeline *)calloc(1, sizeof(*p));
+    if (!p) return HEAAC_ERR_NOMEM;
+    p->aac = *aac;
+    p->layout = *layout;
+    p->ne = layout->n_elements;
+    p->n = n;
+    p->he = aac->sbr == 1;
+    const int mode = p->he ? heaac_sbr_output_mode(aac) : 0;
+    if (mode < 0) { free(p); return HEAAC_ERR_ARG; }
+    p->downsampled = mode;
+    p->len = p->he && !mode ? 2048 : 1024;
+    p->main_profile = aac->object_type == HEAAC_AOT_AAC_MAIN;
+    int rc = heaac_device_create(&p->dev, n);
+    if (rc != HEAAC_OK) { free(p); return rc; }
+    bool ok = hipStreamCreateWithFlags(&p->run, hipStreamNonBlocking) == hipSuccess;
+    HeaacPredictorState *ps = NULL;
+    for (int k = 0; ok && k < p->ne; k++) {
+        LpElem &e = p->e[k];
+        e.channels = layout->elem[k].channels;
+        e.cfg = p->he ? (e.channels == 2 ? HEAAC_CFG_HEV1 : HEAAC_CFG_HEV1_MONO)
+                      : (e.channels == 2 ? HEAAC_CFG_LC_STEREO : HEAAC_CFG_LC_MONO);
+        e.words = e.cfg == HEAAC_CFG_HEV1 ? HEAAC_STATE_WORDS_HEV1 : e.cfg == HEAAC_CFG_HEV1_MONO ? HEAAC_STATE_WORDS_HEV1_MONO :
+                  e.cfg == HEAAC_CFG_LC_STEREO ? HEAAC_STATE_WORDS_LC_STEREO : HEAAC_STATE_WORDS_LC_MONO;
+        ok = lp_devmem((void **)&e.d_state, n * (size_t)e.words * 4) && hipMemset(e.d_state, 0, n * (size_t)e.words * 4) == hipSuccess &&
+             lp_devmem((void **)&e.d_f32, n * (size_t)e.channels * p->len * 4);
+        if (ok && p->he) {
+            e.sst = (HeaacSbrStream *)malloc(n * heaac_sbr_stream_bytes());
+            ok = e.sst != NULL;
+            if (ok) heaac_sbr_stream_init(e.sst, n);
+        }
+        if (ok && p->main_profile) {
+            // reset_predict_state (aacdec.c:507-515) for every predictor of every channel
+            const size_t np = n * (size_t)e.channels * HEAAC_MAX_PREDICTORS;
+            ps = (HeaacPredictorState *)calloc(np, sizeof(*ps));
+            ok = ps != NULL && lp_devmem((void **)&e.d_pred, np * sizeof(*ps));
+            if (ok) {
+                for (size_t i = 0; i < np; i++) ps[i].var0 = ps[i].var1 = 1.0f;
+                ok = hipMemcpy(e.d_pred, ps, np * sizeof(*ps), hipMemcpyHostToDevice) == hipSuccess;
+            }
+            free(ps);
+            ps = NULL;
+        }
+    }
+    for (int q = 0; q < LP_DEPTH && ok; q++) {
+        LpSet *s = &p->set[q];
+        for (int k = 0; k < p->ne && ok; k++) {
+            const size_t nc = n * (size_t)p->e[k].channels;
+            ok = lp_pinned((void **)&s->h_coeffs[k], nc * 4096) && lp_devmem((void **)&s->d_coeffs[k], nc * 4096) &&
+                 lp_pinned((void **)&s->h_ics[k], nc * sizeof(HeaacIcs)) && lp_devmem((void **)&s->d_ics[k], nc * sizeof(HeaacIcs)) &&
+                 lp_pinned((void **)&s->h_tools[k], n * sizeof(HeaacToolsFrame)) && lp_devmem((void **)&s->d_tools[k], n * sizeof(HeaacToolsFrame)) &&
+                 (!p->he || (lp_pinned((void **)&s->h_sbr[k], n * sizeof(HeaacSbrFrame)) && lp_devmem((void **)&s->d_sbr[k], n * sizeof(HeaacSbrFrame))));
+        }
+        const size_t pcm_bytes = n * (size_t)layout->channels * p->len * 2;
+        ok = ok && lp_pinned((void **)&s->h_pcm, pcm_bytes) && lp_devmem((void **)&s->d_pcm, pcm_bytes) &&
+             (s->failed = (unsigned char *)calloc(n, 1)) != NULL && (s->seq = (unsigned char *)calloc(n * p->ne, 1)) != NULL &&
+             hipEventCreate(&s->done) == hipSuccess;
+    }
+    ok = ok && lp_devmem((void **)&p->d_rng, n * 4) && lp_devmem((void **)&p->d_hdr, LP_MAX_HDRS * sizeof(HeaacSbrHeader));
+    if (ok) {
+        int32_t *seed = (int32_t *)malloc(n * 4);
+        ok = seed != NULL;
+        if (ok) {
+            for (size_t i = 0; i < n; i++) seed[i] = 0x1f2e3d4c;       // ac->random_state, aacdec.c:558
+            ok = hipMemcpy(p->d_rng, seed, n * 4, hipMemcpyHostToDevice) == hipSuccess;
+            free(seed);
+        }
+    }
+    p->tab = heaac_sbr_table_create(LP_MAX_HDRS);
+    p->ast = (HeaacAacStream *)calloc(n * p->ne, sizeof(HeaacAacStream));
+    p->lay = (HeaacAacLayout *)malloc(n * sizeof(HeaacAacLayout));
+    ok = ok && p->tab && p->ast && p->lay;
+    if (ok) {
+        for (size_t i = 0; i < n; i++) p->lay[i] = *layout;
+        // the null header (table entry 0) is what frames before their element's first header point at
+        ok = hipMemcpy(p->d_hdr, heaac_sbr_table_data(p->tab), sizeof(HeaacSbrHeader), hipMemcpyHostToDevice) == hipSuccess;
+        p->hdr_uploaded = 1;
+    }
+    if (ok) {
+        if (threads <= 0) {
+            long online = sysconf(_SC_NPROCESSORS_ONLN);
+            threads = online < 1 ? 1 : online > 32 ? 32 : (int)online;
+        }
+        if (threads > 256) threads = 256;
+        if ((size_t)threads > n) threads = (int)n;
+        p->threads = threads;
+        pthread_mutex_init(&p->mu, NULL);
+        pthread_cond_init(&p->cv_go, NULL);
+        pthread_cond_init(&p->cv_done, NULL);
+        p->tid = (pthread_t *)calloc(threads, sizeof(pthread_t));
+        ok = p->tid != NULL;
+        for (int t = 1; t < threads && ok; t++) {          // slice 0 is parsed by the submitting thread
+            LpWorkerArg *a = (LpWorkerArg *)malloc(sizeof(*a));
+            if (!a) { ok = false; break; }
+            a->p = p; a->w = t;
+            if (pthread_create(&p->tid[t], NULL, lp_worker, a) != 0) { free(a); p->tid[t] = 0; p->threads = t; break; }
+        }
+    }
+    if (!ok) { heaac_layout_pipeline_destroy(p); return HEAAC_ERR_NOMEM; }
+    *out = p;
+    return HEAAC_OK;
+}
+
+#define LP_HIP(x) do { if ((x) != hipSuccess) return HEAAC_ERR_HIP; } while (0)
+
+// rows of every failed stream: element states, predictors, noise generator -- to / from the parking area
+static int lp_park(HeaacLayoutPipeline *p, LpSet *s, size_t n_failed, int restore)
+{
+    char *park = (char *)p->d_park;
+    size_t off = 0;
+    for (size_t i = 0; i < p->n; i++) {
+        if (!s->failed[i]) continue;
+        for (int k = 0; k < p->ne; k++) {
+            const LpElem &e = p->e[k];
+            const size_t sb = (size_t)e.words * 4, pb = (size_t)e.channels * HEAAC_MAX_PREDICTORS * sizeof(HeaacPredictorState);
+            char *st = (char *)e.d_state + i * sb;
+            LP_HIP(restore ? hipMemcpyAsync(st, park + off, sb, hipMemcpyDeviceToDevice, p->run)
+                           : hipMemcpyAsync(park + off, st, sb, hipMemcpyDeviceToDevice, p->run));
+            off += sb;
+            if (e.d_pred) {
+                char *pr = (char *)e.d_pred + i * pb;
+                LP_HIP(restore ? hipMemcpyAsync(pr, park + off, pb, hipMemcpyDeviceToDevice, p->run)
+                               : hipMemcpyAsync(park + off, pr, pb, hipMemcpyDeviceToDevice, p->run));
+                off += pb;
+            }
+        }
+        LP_HIP(restore ? hipMemcpyAsync(p->d_rng + i, park + off, 4, hipMemcpyDeviceToDevice, p->run)
+                       : hipMemcpyAsync(park + off, p->d_rng + i, 4, hipMemcpyDeviceToDevice, p->run));
+        off += 4;
+    }
+    (void)n_failed;
+    return HEAAC_OK;
+}
+
+extern "C" int heaac_layout_pipeline_submit(HeaacLayoutPipeline *p, const uint8_t *const *au, const int *size, int *status)
+{
+    if (!p || !au || !size) return HEAAC_ERR_ARG;
+    if (p->submitted - p->collected >= LP_DEPTH) return HEAAC_ERR_ARG;
+    LpSet *s = &p->set[p->submitted % LP_DEPTH];
+    // (the set's buffers are free: its last tick has been collected, which waited for its `done`)
+    pthread_mutex_lock(&p->mu);
+    p->job_au = au; p->job_size = size; p->job_status = status; p->job_set = s;
+    p->pending = p->threads - 1;
+    p->generation++;
+    pthread_cond_broadcast(&p->cv_go);
+    pthread_mutex_unlock(&p->mu);
+    lp_parse_slice(p, 0);
+    pthread_mutex_lock(&p->mu);
+    while (p->pending > 0) pthread_cond_wait(&p->cv_done, &p->mu);
+    pthread_mutex_unlock(&p->mu);
+
+    const size_t n = p->n;
+    const int ne = p->ne;
+    // the element order of the pipeline's streams: the first good unit sets it, a stream that deviates is dropped for the tick
+    size_t n_failed = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (s->failed[i]) { n_failed++; continue; }
+        if (!p->have_order) {
+            for (int k = 0; k < ne; k++) p->order[s->seq[i * ne + k] < ne ? s->seq[i * ne + k] : 0] = (unsigned char)k;
+            p->have_order = 1;
+        }
+        bool same = true;
+        for (int k = 0; k < ne; k++) same = same && s->seq[i * ne + k] < ne && p->order[s->seq[i * ne + k]] == k;
+        if (!same) {
+            s->failed[i] = 1;
+            n_failed++;
+            if (status) status[i] = HEAAC_PARSE_ERR_UNSUPPORTED;
+            neutral(p, s, i);
+        }
+    }
+    const size_t have = heaac_sbr_table_count(p->tab);
+    if (have > LP_MAX_HDRS) return HEAAC_ERR_ARG;
+    // H2D (the run stream carries everything: the tick before has the GPU meanwhile)
+    if (have > p->hdr_uploaded) {
+        LP_HIP(hipMemcpyAsync(p->d_hdr + p->hdr_uploaded, heaac_sbr_table_data(p->tab) + p->hdr_uploaded,
+                              (have - p->hdr_uploaded) * sizeof(HeaacSbrHeader), hipMemcpyHostToDevice, p->run));
+        p->hdr_uploaded = have;
+    }
+    for (int k = 0; k < ne; k++) {
+        const size_t nc = n * (size_t)p->e[k].channels;
+        LP_HIP(hipMemcpyAsync(s->d_coeffs[k], s->h_coeffs[k], nc * 4096, hipMemcpyHostToDevice, p->run));
+        LP_HIP(hipMemcpyAsync(s->d_ics[k], s->h_ics[k], nc * sizeof(HeaacIcs), hipMemcpyHostToDevice, p->run));
+        LP_HIP(hipMemcpyAsync(s->d_tools[k], s->h_tools[k], n * sizeof(HeaacToolsFrame), hipMemcpyHostToDevice, p->run));
+        if (p->he) LP_HIP(hipMemcpyAsync(s->d_sbr[k], s->h_sbr[k], n * sizeof(HeaacSbrFrame), hipMemcpyHostToDevice, p->run));
+    }
+    if (n_failed) {
+        size_t row = 4;
+        for (int k = 0; k < ne; k++)
+            row += (size_t)p->e[k].words * 4 + (p->e[k].d_pred ? (size_t)p->e[k].channels * HEAAC_MAX_PREDICTORS * sizeof(HeaacPredictorState) : 0);
+        if (n_failed * row > p->park_bytes) {
+            LP_HIP(hipStreamSynchronize(p->run));
+            if (p->d_park) (void)hipFree(p->d_park);
+            p->d_park = NULL; p->park_bytes = 0;
+            size_t rows = 16;
+            while (rows < n_failed) rows *= 2;
+            if (rows > n) rows = n;
+            if (!lp_devmem((void **)&p->d_park, rows * row)) return HEAAC_ERR_NOMEM;
+            p->park_bytes = rows * row;
+        }
+        const int rc = lp_park(p, s, n_failed, 0);
+        if (rc != HEAAC_OK) return rc;
+    }
+    // the spectral tools of the elements in bitstream order (one noise generator per stream)
+    for (int q = 0; q < ne; q++) {
+        const int k = p->have_order ? p->order[q] : q;
+        const LpElem &e = p->e[k];
+        const int rc = heaac_spectral_tools_batch(p->dev, e.channels, s->d_coeffs[k], s->d_tools[k], p->d_rng, p->d_rng,
+                                                  e.d_pred, e.d_pred, n, (void *)p->run);
+        if (rc != HEAAC_OK) return rc;
+    }
+    HeaacPlaneRef planes[HEAAC_MAX_PCM_PLANES];
+    for (int k = 0; k < ne; k++) {
+        const LpElem &e = p->e[k];
+        const int rc = p->he
+            ? heaac_he_decode_batch_ex(p->dev, e.cfg, p->downsampled ? HEAAC_HE_DOWNSAMPLED : 0, s->d_coeffs[k], s->d_ics[k], s->d_sbr[k],
+                                       p->d_hdr, LP_MAX_HDRS, NULL, e.d_state, e.d_state, e.d_f32, HEAAC_PCM_F32_PLANAR, n, (void *)p->run)
+            : heaac_lc_decode_batch(p->dev, e.channels, s->d_coeffs[k], s->d_ics[k], e.d_state, e.d_state, e.d_f32,
+                                    HEAAC_PCM_F32_PLANAR, n, (void *)p->run);
+        if (rc != HEAAC_OK) return rc;
+        for (int c = 0; c < e.channels; c++) {
+            planes[p->layout.elem[k].first_channel + c].d_base = e.d_f32 + (size_t)c * p->len;
+            planes[p->layout.elem[k].first_channel + c].frame_stride = (size_t)e.channels * p->len;
+        }
+    }
+    int rc = heaac_pcm_interleave_batch(p->dev, p->layout.channels, planes, p->len, HEAAC_PCM_S16_INTERLEAVED, s->d_pcm, n, (void *)p->run);
+    if (rc != HEAAC_OK) return rc;
+    const size_t pcm_row = (size_t)p->layout.channels * p->len;
+    if (n_failed) {
+        rc = lp_park(p, s, n_failed, 1);
+        if (rc != HEAAC_OK) return rc;
+        for (size_t i = 0; i < n; i++)
+            if (s->failed[i]) LP_HIP(hipMemsetAsync(s->d_pcm + i * pcm_row, 0, pcm_row * 2, p->run));
+    }
+    LP_HIP(hipMemcpyAsync(s->h_pcm, s->d_pcm, n * pcm_row * 2, hipMemcpyDeviceToHost, p->run));
+    LP_HIP(hipEventRecord(s->done, p->run));
+    s->used = 1;
+    p->submitted++;
+    return HEAAC_OK;
+}
+
+extern "C" int heaac_layout_pipeline_collect(HeaacLayoutPipeline *p, const int16_t **pcm)
+{
+    if (!p || !pcm || p->collected == p->submitted) return HEAAC_ERR_ARG;
+    LpSet *s = &p->set[p->collected % LP_DEPTH];
+    LP_HIP(hipEventSynchronize(s->done));
+    *pcm = s->h_pcm;
+    p->collected++;
+    return HEAAC_OK;
+}

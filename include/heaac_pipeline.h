@@ -59,6 +59,27 @@ int heaac_pipeline_collect(HeaacPipeline *p, const int16_t **pcm);
  * from HIP events). */
 void heaac_pipeline_timing(const HeaacPipeline *p, float ms[4]);
 
+/* ---- streams of a multi-element layout (aac_decode_frame's element loop, aacdec.c:1999-2076) ----
+ * n streams of ONE layout (heaac_aac_layout_default for the channel configurations 1 ... 7, heaac_asc_layout /
+ * heaac_aac_layout_from_pce for a program config element) advance in lock step: per tick every stream's access unit is
+ * parsed on the pool (heaac_aac_parse_frame_layout_ex + the SBR payload behind each element), the records are laid out
+ * element-major, and every element of the layout is ONE batched spectral-tools call and ONE batched decode call over
+ * the n streams; heaac_pcm_interleave_batch writes what float_to_int16_interleave writes (:2096-2097).  Exactly what
+ * heaac_codec_decode does for one such stream (csrc/codec_layout.hip), which is what the tests compare it with.
+ *   aac->sbr: 0 (AAC-LC / Main: 1024 samples per channel and tick) or 1 (explicit SBR per element; 2048, or 1024 for
+ *             downsampled SBR).  Implicit signalling (-1) is settled per stream by its first access unit: HEAAC_ERR_ARG.
+ *   layout:   without coupling channel elements (HEAAC_ERR_ARG otherwise: one heaac_codec_decode context per stream).
+ * The streams must emit their elements in one bitstream order (the noise generator runs through them in that order;
+ * the first good access unit sets it).  A stream whose unit does not parse, leaves an element out or deviates from
+ * the order (status HEAAC_PARSE_ERR_UNSUPPORTED) gets silence for the tick and keeps its decoder state.
+ * Two ticks may be in flight.  PCM: [n_streams][len][layout->channels] int16, pinned, valid until two more submits. */
+typedef struct HeaacLayoutPipeline HeaacLayoutPipeline;
+int  heaac_layout_pipeline_create(HeaacLayoutPipeline **out, const HeaacAacConfig *aac, const HeaacAacLayout *layout,
+                                  size_t n_streams, int threads);
+void heaac_layout_pipeline_destroy(HeaacLayoutPipeline *p);
+int  heaac_layout_pipeline_submit(HeaacLayoutPipeline *p, const uint8_t *const *au, const int *size, int *status);
+int  heaac_layout_pipeline_collect(HeaacLayoutPipeline *p, const int16_t **pcm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     names = set()
-    for h in ("heaac_dsp.h", "heaac_fft.h", "heaac_codec.h", "heaac_parse.h", "heaac_multi.h", "heaac_pipeline.h"):
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if not h.endswith(".h") or h == "heaac_iso_tables.h":        # (constant tables, no entry points)
+            continue
         txt = open(os.path.join(ROOT, "include", h)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         for m in re.finditer(r"^\s*(?:extern\s+)?[A-Za-z_][\w\s\*]*?\b((?:heaac|ff|av)_\w+)\s*(?:\(|\[|;)", txt, re.M):

@@ -1,0 +1,132 @@
+"""include/heaac_pipeline.h, second half: heaac_layout_pipeline_* -- n streams of one multi-element layout through the
+batched records (VERDICT r03 "missing" #2: aac_decode_frame's element loop, aacdec.c:1999-2076, had existed only behind
+one heaac_codec_decode context per stream).  Every stream is ALSO decoded by a codec context of its own on the same
+bytes (the path tests/test_layout_gpu.py pins to the oracle): the pipeline's interleaved int16 PCM must equal it
+stream for stream and tick for tick -- 5.1 AAC-LC, 5.0 AAC-Main (predictor state per element and stream), 5.1 HE-AAC
+with explicit SBR per element.  A damaged unit gives its stream silence and leaves it as it was."""
+import copy
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import test_layout_gpu as LG
+
+pytestmark = pytest.mark.gpu
+
+SCE, CPE, CCE, LFE = 0, 1, 2, 3
+
+
+def _stream_units(pkg, rng, mode, ticks):
+    """The access units of one stream (raw data blocks), written as tests/test_layout_gpu.py writes them."""
+    import sbr_bitwriter as SW
+    import test_parse_layout as TL
+    cc, elems, he, how = LG.MODES[mode]
+    aot = 1 if mode.startswith("main") else 2
+    si = 6 if he else 3
+    writers = {k: SW.SbrStreamWriter(pkg, 2 if t == CPE else 1) for k, (t, _) in enumerate(elems)}
+    units = []
+    for t in range(ticks):
+        payloads = None
+        if he:
+            payloads = []
+            for k, (typ, _) in enumerate(elems):
+                if typ == LFE:
+                    payloads.append(None)
+                    continue
+                w = writers[k]
+                while True:
+                    keep = copy.deepcopy((w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling))
+                    bits, _ = w.frame(rng, new_header=(t == 3 and k == 1), respec=(t == 3 and k == 1))
+                    if (4 + len(bits) + 7) // 8 <= 269:
+                        break
+                    w.ch, w.ps, w.header, w.hdr_rec, w.kx_m, w.coupling = keep
+                payloads.append(bits)
+        au, _ = TL.build(rng, si, aot, elems, extras=t & 1, payloads=payloads)
+        units.append(au)
+    return units, aot, si, cc, he
+
+
+@pytest.mark.parametrize("mode", ["lc_5_1", "main_5_0", "he_5_1"])
+def test_layout_pipeline_equals_one_codec_context_per_stream(pkg, dev, mode):
+    import test_parse as TP
+    from test_shim_gpu import HeaacCodecContext, HeaacPacket
+    lib = pkg.lib()
+    n, ticks = 6, 5
+    rng = np.random.default_rng(sum(map(ord, mode)) + 9)
+    streams = [_stream_units(pkg, rng, mode, ticks) for _ in range(n)]
+    _, aot, si, cc, he = streams[0]
+    asc = LG._asc(aot, si, cc, he=he)
+    r, m4, layout = pkg.asc_layout(asc)
+    assert r == 0
+    if not he:
+        assert m4.sbr == -1          # a plain AAC-LC configuration leaves implicit SBR open; these streams carry none
+        m4.sbr = 0
+    nch = int(layout[0]["channels"])
+    length = 2048 if he else 1024
+    # one damaged unit: its stream gets silence for that tick and goes on as if it had never seen it
+    bad_tick, bad = 2, 4
+    units = [[streams[i][0][t] for i in range(n)] for t in range(ticks)]
+    fed = [list(u) for u in units]
+    fed[bad_tick][bad] = units[bad_tick][bad][:6] + bytes(8)
+
+    # the reference run: a codec context per stream
+    codec = C.c_void_p.in_dll(lib, "heaac_aac_decoder")
+    want = np.zeros((ticks, n, length, nch), np.int16)
+    out = (C.c_int16 * (192000 // 2))()
+    for i in range(n):
+        ctx = HeaacCodecContext(cfg=-1, extradata=asc, extradata_size=len(asc))
+        assert lib.heaac_codec_open(C.byref(ctx), C.c_void_p(C.addressof(codec))) == 0
+        for t in range(ticks):
+            if t == bad_tick and i == bad:
+                continue                                   # (silence; the stream's state untouched)
+            b = units[t][i]
+            buf = C.create_string_buffer(b, len(b))
+            pkt = HeaacPacket(C.cast(buf, C.c_void_p), len(b))
+            size = C.c_int(192000)
+            assert lib.heaac_codec_decode(C.byref(ctx), out, C.byref(size), C.byref(pkt)) == len(b), (i, t)
+            assert size.value == length * nch * 2
+            want[t, i] = np.frombuffer(out, np.int16, size.value // 2).reshape(length, nch)
+        assert lib.heaac_codec_close(C.byref(ctx)) == 0
+
+    pl = pkg.LayoutPipeline(m4, layout, n, threads=3)
+    got = []
+    for t in range(ticks):
+        st = pl.submit(fed[t])
+        if t == bad_tick:
+            assert st[bad] < 0 and all(st[i] == 0 for i in range(n) if i != bad)
+        else:
+            assert (st == 0).all(), (t, st)
+        if t >= 1:
+            got.append(pl.collect().copy())
+    got.append(pl.collect().copy())
+    with pytest.raises(pkg.HeaacError):
+        pl.collect()
+    for t in range(ticks):
+        assert got[t].shape == (n, length, nch)
+        for i in range(n):
+            assert np.array_equal(got[t][i], want[t, i]), ("tick %d stream %d" % (t, i), np.argwhere(got[t][i] != want[t, i])[:3])
+    assert not got[bad_tick][bad].any() and int(np.abs(got[ticks - 1][bad].astype(int)).max()) > 20
+    pl.close()
+
+
+def test_layout_pipeline_refuses_what_it_does_not_take(pkg, dev):
+    import test_parse as TP
+    r, layout = pkg.aac_layout_default(6)
+    assert r == 0
+    m4 = TP._cfg(pkg, 2, 3, 6)
+    m4.sbr = -1                                                # implicit signalling: settled per stream
+    with pytest.raises(pkg.HeaacError):
+        pkg.LayoutPipeline(m4, layout, 4)
+    m4.sbr = 0
+    l2 = layout.copy()
+    l2[0]["slot_of"][2][5] = 1                                 # a coupling channel element in the layout
+    with pytest.raises(pkg.HeaacError):
+        pkg.LayoutPipeline(m4, l2, 4)
+    pl = pkg.LayoutPipeline(m4, layout, 4)
+    for _ in range(2):
+        pl.submit([bytes(16)] * 4)                             # (garbage units: every stream fails, silence)
+    with pytest.raises(pkg.HeaacError):
+        pl.submit([bytes(16)] * 4)                             # a third tick in flight
+    assert not pl.collect().any()
+    pl.close()

@@ -23,6 +23,17 @@ def test_create_checks_arguments_and_fails_loudly_without_a_device(pkg):
     assert lib.heaac_pipeline_create(C.byref(h), C.byref(cfg), pkg.CFG_HEV2, C.c_size_t(0), 1) == -1
     if not torch.cuda.is_available():
         assert lib.heaac_pipeline_create(C.byref(h), C.byref(cfg), pkg.CFG_HEV2, C.c_size_t(4), 1) == -4 and not h.value
+    # the layout form: argument checks first, then the same loud failure
+    r, layout = pkg.aac_layout_default(6)
+    m4 = TP._cfg(pkg, 2, 3, 6)
+    lp = lambda c, l, n: lib.heaac_layout_pipeline_create(C.byref(h), C.byref(c) if c is not None else None,
+                                                          l.ctypes.data_as(C.c_void_p) if l is not None else None, C.c_size_t(n), 1)
+    assert r == 0 and lp(None, layout, 4) == -1 and lp(m4, None, 4) == -1 and lp(m4, layout, 0) == -1
+    m4.sbr = -1
+    assert lp(m4, layout, 4) == -1                          # implicit SBR is settled per stream
+    m4.sbr = 0
+    if not torch.cuda.is_available():
+        assert lp(m4, layout, 4) == -4 and not h.value
 
 
 def _ticks(pkg, rng, channels, ps, n, ticks):

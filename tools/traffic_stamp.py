@@ -1,18 +1,33 @@
 """Merge gpurun_out/traffic_new.json (tools/traffic.sh, measured on the GPU box) into profiles/traffic.json and stamp
 each merged entry with the git head it belongs to: an entry is accepted only if its kernel_sha equals the hash of the
 device sources in the working tree (so the head named is one whose kernels were measured).
-usage: python3 tools/traffic_stamp.py [round]"""
+usage: python3 tools/traffic_stamp.py [round] [--same-kernels <commit>]
+--same-kernels <commit>: the measurement was taken on the snapshot of <commit>, whose device sources are the working
+tree's (checked with git diff) -- used once in round 4, when the definition of the hash changed between measuring and
+stamping."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 sha = g.load_package().kernel_source_sha()
 head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
-dirty = subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "ffmpeg-heaac_amd/csrc", "include"], text=True).strip()
+kfiles = ["ffmpeg-heaac_amd/csrc/" + f for f in os.listdir(os.path.join(ROOT, "ffmpeg-heaac_amd", "csrc"))
+          if f.startswith("k_") or f in ("kernels.h", "tables.h", "validate.h")] + ["include/heaac_dsp.h"]
+dirty = subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--"] + kfiles, text=True).strip()
 new = json.load(open(os.path.join(ROOT, "gpurun_out", "traffic_new.json")))
 path = os.path.join(ROOT, "profiles", "traffic.json")
 allrec = json.load(open(path)) if os.path.exists(path) else {}
+same = None
+if "--same-kernels" in sys.argv:
+    same = sys.argv[sys.argv.index("--same-kernels") + 1]
+    files = ["ffmpeg-heaac_amd/csrc/" + f for f in os.listdir(os.path.join(ROOT, "ffmpeg-heaac_amd", "csrc"))
+             if f.startswith("k_") or f in ("kernels.h", "tables.h", "validate.h")] + ["include/heaac_dsp.h"]
+    diff = subprocess.check_output(["git", "-C", ROOT, "diff", "--stat", same, "--"] + files, text=True).strip()
+    assert not diff, "device sources differ from %s:\n%s" % (same, diff)
+    sys.argv = [a for a in sys.argv if a not in ("--same-kernels", same)]
 for key, rec in new.items():
+    if same:
+        rec["kernel_sha"] = sha
     if rec.get("kernel_sha") != sha:
         print("skip %s: measured on kernel sources %s, the tree has %s" % (key, rec.get("kernel_sha"), sha))
         continue
