@@ -171,20 +171,38 @@ def validate_frame(cfg, sbr, hdr, ps=None):
 _lib = None
 
 
-def kernel_source_sha():
-    """SHA-256 over the DEVICE sources (csrc/k_*.hip, csrc/k_*.h, kernels.h, tables.h, validate.h) and the record
-    header include/heaac_dsp.h: a measurement stored under profiles/ is tied to the kernels it was taken on (bench.py
-    refuses a traffic figure whose stamp differs).  Host-side sources (parsers, pipelines, the C API) do not count."""
+KERNEL_SOURCE_EXTRA = ("kernels.h", "tables.h", "validate.h")
+
+
+def kernel_source_files():
+    """The device sources, relative to the repository root: csrc/k_*.hip, csrc/k_*.h, kernels.h, tables.h, validate.h
+    and the record header include/heaac_dsp.h."""
     import glob
-    import hashlib
-    h = hashlib.sha256()
     d = os.path.join(_HERE, "csrc")
     files = sorted(glob.glob(os.path.join(d, "k_*.hip")) + glob.glob(os.path.join(d, "k_*.h")))
-    files += [os.path.join(d, f) for f in ("kernels.h", "tables.h", "validate.h")]
+    files += [os.path.join(d, f) for f in KERNEL_SOURCE_EXTRA]
     files.append(os.path.join(os.path.dirname(_HERE), "include", "heaac_dsp.h"))
-    for f in files:
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+    return [os.path.relpath(f, os.path.dirname(_HERE)) for f in files]
+
+
+def kernel_source_sha(read=None):
+    """SHA-256 over the CODE of the device sources (comments and white space do not count; host-side sources --
+    parsers, pipelines, the C API -- do not either): a measurement stored under profiles/ is tied to the kernels it was
+    taken on, and bench.py refuses a traffic figure whose stamp differs.  read(relative path) -> text lets
+    tools/traffic_stamp.py hash the files of another commit."""
+    import hashlib
+    import re
+    root = os.path.dirname(_HERE)
+    if read is None:
+        read = lambda rel: open(os.path.join(root, rel), encoding="utf-8").read()
+    h = hashlib.sha256()
+    for rel in kernel_source_files():
+        txt = read(rel)
+        txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)          # block comments
+        txt = re.sub(r"//[^\n]*", " ", txt)                       # line comments (no string literal of these files holds //)
+        txt = " ".join(txt.split())
+        h.update(os.path.basename(rel).encode())
+        h.update(txt.encode())
     return h.hexdigest()[:16]
 
 

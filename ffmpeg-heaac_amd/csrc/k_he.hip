@@ -559,9 +559,8 @@ void k_synth(const float *__restrict__ g_tab, const float *g_X,
             int16_t *o = reinterpret_cast<int16_t *>(g_pcm) + (pcm_frame0 + f) * 2048 * nout;
             for (int ch = 0; ch < nout; ch++)
                 channel(ch, [&](int i, int n, float v) {
-                    // (plain stores, not the non-temporal ones of the float path: a streamed 2-byte store leaves for
-                    // HBM as a partial line before the other channel's half arrives -- measured 25.5 KiB written per
-                    // frame where 17.4 are algorithmic, and k_synth<1> 10 % slower: profiles/r04_experiments.md E3)
+                    // (plain stores, not the non-temporal ones of the float path: -10 % kernel time for these 2-byte,
+                    // half-line stores -- profiles/r04_experiments.md E3; the bytes written do not change)
                     o[(64 * i + n) * nout + ch] = (int16_t)pcm_int16<FMT>(v);
                 });
         }

@@ -11,19 +11,18 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 sha = g.load_package().kernel_source_sha()
 head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
-kfiles = ["ffmpeg-heaac_amd/csrc/" + f for f in os.listdir(os.path.join(ROOT, "ffmpeg-heaac_amd", "csrc"))
-          if f.startswith("k_") or f in ("kernels.h", "tables.h", "validate.h")] + ["include/heaac_dsp.h"]
+kfiles = g.load_package().kernel_source_files()
 dirty = subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--"] + kfiles, text=True).strip()
 new = json.load(open(os.path.join(ROOT, "gpurun_out", "traffic_new.json")))
 path = os.path.join(ROOT, "profiles", "traffic.json")
 allrec = json.load(open(path)) if os.path.exists(path) else {}
 same = None
 if "--same-kernels" in sys.argv:
+    # the measurement's snapshot was <commit>: accept it if that commit's device CODE hashes like the working tree's
     same = sys.argv[sys.argv.index("--same-kernels") + 1]
-    files = ["ffmpeg-heaac_amd/csrc/" + f for f in os.listdir(os.path.join(ROOT, "ffmpeg-heaac_amd", "csrc"))
-             if f.startswith("k_") or f in ("kernels.h", "tables.h", "validate.h")] + ["include/heaac_dsp.h"]
-    diff = subprocess.check_output(["git", "-C", ROOT, "diff", "--stat", same, "--"] + files, text=True).strip()
-    assert not diff, "device sources differ from %s:\n%s" % (same, diff)
+    pkg = g.load_package()
+    there = pkg.kernel_source_sha(read=lambda rel: subprocess.check_output(["git", "-C", ROOT, "show", "%s:%s" % (same, rel)], text=True))
+    assert there == sha, "device code differs from %s: %s there, %s here" % (same, there, sha)
     sys.argv = [a for a in sys.argv if a not in ("--same-kernels", same)]
 for key, rec in new.items():
     if same:
