@@ -485,9 +485,17 @@ __device__ __forceinline__ void hf_channel(const HfWave &w, const float *g_noise
             const int e = t / n_lim, kk = t - e * n_lim;
             const int ma = h.f_tablelim[kk] - kx, mb = h.f_tablelim[kk + 1] - kx;
             float sum0 = 0.0f, sum1 = 0.0f;
-            for (int mm = ma; mm < mb; mm++) {
-                sum0 += w.sumA[e][mm];
-                sum1 += w.sumB[e][mm];
+            // (four terms' reads in flight per trip; a term past the band adds +0.0f to a sum of non-negative energies,
+            // which changes no bit of it, so the order of the reference's additions is kept)
+            for (int mm = ma; mm < mb; mm += 4) {
+                float ta[4], tb[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { ta[j] = w.sumA[e][mm + j]; tb[j] = w.sumB[e][mm + j]; }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    sum0 += mm + j < mb ? ta[j] : 0.0f;
+                    sum1 += mm + j < mb ? tb[j] : 0.0f;
+                }
             }
             float gain_max = limgain * sqrtf((1.1920928955078125e-7f + sum0) / (1.1920928955078125e-7f + sum1));
             gain_max = FFMIN_(100000.0f, gain_max);
@@ -513,9 +521,17 @@ __device__ __forceinline__ void hf_channel(const HfWave &w, const float *g_noise
             const int e = t / n_lim, kk = t - e * n_lim;
             const int ma = h.f_tablelim[kk] - kx, mb = h.f_tablelim[kk + 1] - kx;
             float sum0 = 0.0f, sum1 = 0.0f;
-            for (int mm = ma; mm < mb; mm++) {
-                sum0 += w.sumA[e][mm];
-                sum1 += w.sumB[e][mm];
+            // (four terms' reads in flight per trip; a term past the band adds +0.0f to a sum of non-negative energies,
+            // which changes no bit of it, so the order of the reference's additions is kept)
+            for (int mm = ma; mm < mb; mm += 4) {
+                float ta[4], tb[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { ta[j] = w.sumA[e][mm + j]; tb[j] = w.sumB[e][mm + j]; }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    sum0 += mm + j < mb ? ta[j] : 0.0f;
+                    sum1 += mm + j < mb ? tb[j] : 0.0f;
+                }
             }
             float gain_boost = sqrtf((1.1920928955078125e-7f + sum0) / (1.1920928955078125e-7f + sum1));
             // FFMIN(1.584893192, gain_boost) is evaluated in double (:1597)
