@@ -518,7 +518,8 @@ AAC_STREAM_DT = np.dtype([("window_sequence", "u1", (2,)), ("use_kb_window", "u1
                           ("cce_window_sequence", "u1", (16,)), ("cce_use_kb_window", "u1", (16,))])
 AAC_INFO_DT = np.dtype([("channels", "<i4"), ("bits_consumed", "<i4"), ("sbr_payload_bit", "<i4"),
                         ("sbr_payload_bytes", "<i4"), ("sbr_crc", "<i4"), ("elem_id", "<i4"), ("n_cce", "<i4"),
-                        ("sbr_misplaced", "<i4")])
+                        ("sbr_misplaced", "<i4"), ("refused", "<i4")])
+REFUSED_AS_REFERENCE, REFUSED_RUN_TOOLS = 1, 2
 
 
 def asc_parse(buf):

@@ -167,11 +167,31 @@ typedef struct {
     uint8_t window_sequence[2], use_kb_window[2];
 } WinInfo;
 
+/* How far the reference's element decoders had got when an access unit is refused: decoder state they have moved by
+ * then stays moved (the window history of decode_ics_info, the noise generator of decode_spectrum_and_dequant, the
+ * predictors of apply_prediction), although the unit gives no output.  `as_reference` is set where the refusal is
+ * one the reference makes at the same bit of the unit; the checks of this parser alone (a read past the end that the
+ * reference's unchecked reader would run through, the layouts it does not take) leave it clear. */
+typedef struct {
+    uint8_t ics[2];         /* per channel: 0 window history untouched, 1 moved on to this unit's, 2 cleared */
+    uint8_t decoded[2];     /* decode_ics has returned 0 for the channel */
+    uint8_t predicted[2];   /* apply_prediction has run on it */
+    uint8_t as_reference;
+    uint8_t ref_overread;   /* ... and it is one of the reference's own end-of-unit checks */
+    int noise_stop[2];      /* channel not decoded: bands [0, noise_stop) have been through the spectrum loop */
+} Progress;
+#define REF_FAIL(pg, code) ((pg)->as_reference = 1, (code))
+#define REF_OVERREAD(pg) ((pg)->as_reference = (pg)->ref_overread = 1, HEAAC_PARSE_ERR_OVERREAD)
+
 /* decode_ics_info + decode_prediction (aacdec.c:622-742) */
-static int read_ics_info(const HeaacAacConfig *cfg, Bits *b, HeaacToolsIcs *ics, HeaacPrediction *pred, WinInfo *w)
+static int read_ics_info(const HeaacAacConfig *cfg, Bits *b, HeaacToolsIcs *ics, HeaacPrediction *pred, WinInfo *w,
+                         Progress *pg, int ch)
 {
     const int si = cfg->sampling_index;
-    if (bit1(b)) return HEAAC_PARSE_ERR_DATA;          /* reserved bit */
+    /* every refusal in here is the reference's, and each of them clears the whole IndividualChannelStream
+     * (memset, aacdec.c:650, 687, 692, 696, 705): the window history with it */
+    pg->ics[ch] = 2;
+    if (bit1(b)) return REF_FAIL(pg, HEAAC_PARSE_ERR_DATA);            /* reserved bit */
     w->window_sequence[1] = w->window_sequence[0];
     w->window_sequence[0] = (uint8_t)bits(b, 2);
     w->use_kb_window[1] = w->use_kb_window[0];
@@ -207,23 +227,25 @@ static int read_ics_info(const HeaacAacConfig *cfg, Bits *b, HeaacToolsIcs *ics,
                 if (bit1(b)) {
                     pred->predictor_reset_group = (uint8_t)bits(b, 5);
                     if (pred->predictor_reset_group == 0 || pred->predictor_reset_group > 30)
-                        return HEAAC_PARSE_ERR_DATA;
+                        return REF_FAIL(pg, HEAAC_PARSE_ERR_DATA);
                 }
                 const int lim = ics->max_sfb < pred->pred_sfb_max ? ics->max_sfb : pred->pred_sfb_max;
                 for (int sfb = 0; sfb < lim; sfb++) pred->prediction_used[sfb] = (uint8_t)bit1(b);
             } else if (cfg->object_type == HEAAC_AOT_AAC_LC) {
-                return HEAAC_PARSE_ERR_DATA;           /* prediction is not allowed in AAC-LC */
+                return REF_FAIL(pg, HEAAC_PARSE_ERR_DATA);             /* prediction is not allowed in AAC-LC */
             } else {
-                return HEAAC_PARSE_ERR_UNSUPPORTED;    /* LTP */
+                return REF_FAIL(pg, HEAAC_PARSE_ERR_UNSUPPORTED);      /* LTP */
             }
         }
     }
-    if (ics->max_sfb > ics->num_swb) return HEAAC_PARSE_ERR_DATA;
+    if (ics->max_sfb > ics->num_swb) return REF_FAIL(pg, HEAAC_PARSE_ERR_DATA);
+    pg->ics[ch] = 1;
     return HEAAC_PARSE_OK;
 }
 
 /* decode_band_types (:755-801) */
-static int read_band_types(Bits *b, const HeaacToolsIcs *ics, int eight, uint8_t band_type[128], uint8_t run_end[128])
+static int read_band_types(Bits *b, const HeaacToolsIcs *ics, int eight, uint8_t band_type[128], uint8_t run_end[128],
+                           Progress *pg)
 {
     const int nb = eight ? 3 : 5;
     int idx = 0;
@@ -232,14 +254,16 @@ static int read_band_types(Bits *b, const HeaacToolsIcs *ics, int eight, uint8_t
         while (k < ics->max_sfb) {
             int sect_end = k, incr;
             const int bt = (int)bits(b, 4);
-            if (bt == 12) return HEAAC_PARSE_ERR_DATA;
+            if (bt == 12) return REF_FAIL(pg, HEAAC_PARSE_ERR_DATA);
+            /* past the end the reference reads the zeros of its input padding, leaves the loop and fails its
+             * get_bits_left() < 0 check (:778-781): the same refusal, taken here without the walk */
             while ((incr = (int)bits(b, nb)) == (1 << nb) - 1) {
                 sect_end += incr;
-                if (b->over) return HEAAC_PARSE_ERR_OVERREAD;
+                if (b->over) return REF_OVERREAD(pg);
             }
             sect_end += incr;
-            if (b->over) return HEAAC_PARSE_ERR_OVERREAD;
-            if (sect_end > ics->max_sfb) return HEAAC_PARSE_ERR_DATA;
+            if (b->over) return REF_OVERREAD(pg);
+            if (sect_end > ics->max_sfb) return REF_FAIL(pg, HEAAC_PARSE_ERR_DATA);
             for (; k < sect_end; k++) {
                 band_type[idx] = (uint8_t)bt;
                 run_end[idx++] = (uint8_t)sect_end;
@@ -251,7 +275,7 @@ static int read_band_types(Bits *b, const HeaacToolsIcs *ics, int eight, uint8_t
 
 /* decode_scalefactors (:815-873) on the C path: sf_offset = 0 (+12 for eight short) */
 static int read_scalefactors(Bits *b, const HeaacToolsIcs *ics, int eight, unsigned global_gain,
-                             const uint8_t band_type[128], const uint8_t run_end[128], float sf[128])
+                             const uint8_t band_type[128], const uint8_t run_end[128], float sf[128], Progress *pg)
 {
     const int sf_offset = eight ? 12 : 0;
     int offset[3] = { (int)global_gain, (int)global_gain - 90, 100 };
@@ -267,7 +291,7 @@ static int read_scalefactors(Bits *b, const HeaacToolsIcs *ics, int eight, unsig
                     const int s = tree_read(&g_sf_tree, b);
                     if (s < 0) return HEAAC_PARSE_ERR_DATA;
                     offset[2] += s - 60;
-                    if ((unsigned)offset[2] > 255U) return HEAAC_PARSE_ERR_DATA;
+                    if ((unsigned)offset[2] > 255U) return REF_FAIL(pg, HEAAC_PARSE_ERR_DATA);
                     sf[idx] = g_pow2sf[-offset[2] + 300];
                 }
             } else if (bt == HEAAC_NOISE_BT) {
@@ -279,7 +303,7 @@ static int read_scalefactors(Bits *b, const HeaacToolsIcs *ics, int eight, unsig
                         if (s < 0) return HEAAC_PARSE_ERR_DATA;
                         offset[1] += s - 60;
                     }
-                    if ((unsigned)offset[1] > 255U) return HEAAC_PARSE_ERR_DATA;
+                    if ((unsigned)offset[1] > 255U) return REF_FAIL(pg, HEAAC_PARSE_ERR_DATA);
                     sf[idx] = -g_pow2sf[offset[1] + sf_offset + 100];
                 }
             } else {
@@ -287,7 +311,7 @@ static int read_scalefactors(Bits *b, const HeaacToolsIcs *ics, int eight, unsig
                     const int s = tree_read(&g_sf_tree, b);
                     if (s < 0) return HEAAC_PARSE_ERR_DATA;
                     offset[0] += s - 60;
-                    if ((unsigned)offset[0] > 255U) return HEAAC_PARSE_ERR_DATA;
+                    if ((unsigned)offset[0] > 255U) return REF_FAIL(pg, HEAAC_PARSE_ERR_DATA);
                     sf[idx] = -g_pow2sf[offset[0] + sf_offset];
                 }
             }
@@ -297,24 +321,24 @@ static int read_scalefactors(Bits *b, const HeaacToolsIcs *ics, int eight, unsig
 }
 
 /* decode_pulses (:878-900) */
-static int read_pulses(Bits *b, const HeaacToolsIcs *ics, Pulse *p)
+static int read_pulses(Bits *b, const HeaacToolsIcs *ics, Pulse *p, Progress *pg)
 {
     p->num_pulse = (int)bits(b, 2) + 1;
     const int swb = (int)bits(b, 6);
-    if (swb >= ics->num_swb) return HEAAC_PARSE_ERR_DATA;
+    if (swb >= ics->num_swb) return REF_FAIL(pg, HEAAC_PARSE_ERR_DATA);
     p->pos[0] = ics->swb_offset[swb] + (int)bits(b, 5);
-    if (p->pos[0] > 1023) return HEAAC_PARSE_ERR_DATA;
+    if (p->pos[0] > 1023) return REF_FAIL(pg, HEAAC_PARSE_ERR_DATA);
     p->amp[0] = (int)bits(b, 4);
     for (int i = 1; i < p->num_pulse; i++) {
         p->pos[i] = (int)bits(b, 5) + p->pos[i - 1];
-        if (p->pos[i] > 1023) return HEAAC_PARSE_ERR_DATA;
+        if (p->pos[i] > 1023) return REF_FAIL(pg, HEAAC_PARSE_ERR_DATA);
         p->amp[i] = (int)bits(b, 4);
     }
     return HEAAC_PARSE_OK;
 }
 
 /* decode_tns (:907-945) */
-static int read_tns(const HeaacAacConfig *cfg, Bits *b, const HeaacToolsIcs *ics, int eight, HeaacTns *tns)
+static int read_tns(const HeaacAacConfig *cfg, Bits *b, const HeaacToolsIcs *ics, int eight, HeaacTns *tns, Progress *pg)
 {
     const int max_order = eight ? 7 : cfg->object_type == HEAAC_AOT_AAC_MAIN ? 20 : 12;
     for (int w = 0; w < ics->num_windows; w++) {
@@ -324,7 +348,7 @@ static int read_tns(const HeaacAacConfig *cfg, Bits *b, const HeaacToolsIcs *ics
         for (int f = 0; f < tns->n_filt[w]; f++) {
             tns->length[w][f] = (uint8_t)bits(b, 6 - 2 * eight);
             tns->order[w][f] = (uint8_t)bits(b, 5 - 2 * eight);
-            if (tns->order[w][f] > max_order) { tns->order[w][f] = 0; return HEAAC_PARSE_ERR_DATA; }
+            if (tns->order[w][f] > max_order) { tns->order[w][f] = 0; return REF_FAIL(pg, HEAAC_PARSE_ERR_DATA); }
             if (tns->order[w][f]) {
                 tns->direction[w][f] = (uint8_t)bit1(b);
                 const int compress = (int)bit1(b);
@@ -361,7 +385,7 @@ static inline float pulse_add(float line, int amp, float sf)
 
 /* decode_spectrum_and_dequant (:988-1245).  NOISE_BT bands are zeroed (the GPU fills them). */
 static int read_spectrum(Bits *b, const HeaacToolsIcs *ics, const uint8_t band_type[128], const float sf[128],
-                         int pulse_present, const Pulse *pulse, float coef[1024])
+                         int pulse_present, const Pulse *pulse, float coef[1024], Progress *pg, int ch)
 {
     const int c = 1024 / ics->num_windows;
     const uint16_t *off = ics->swb_offset;
@@ -375,6 +399,7 @@ static int read_spectrum(Bits *b, const HeaacToolsIcs *ics, const uint8_t band_t
             const int bt = band_type[idx];
             float *cfo = coef + off[i];
             const int len = off[i + 1] - off[i];
+            pg->noise_stop[ch] = idx;                  /* the noise bands in front of this one have drawn their numbers */
             if (bt == 0 || bt >= HEAAC_NOISE_BT) {
                 for (int w = 0; w < g_len; w++) memset(cfo + 128 * w, 0, len * sizeof(float));
                 continue;
@@ -432,7 +457,7 @@ static int read_spectrum(Bits *b, const HeaacToolsIcs *ics, const uint8_t band_t
                                     /* escape_sequence: N ones, a zero, then N + 4 bits (:1174-1197) */
                                     int n = 0;
                                     while (bit1(b)) {
-                                        if (++n > 8) return HEAAC_PARSE_ERR_DATA;
+                                        if (++n > 8) return REF_FAIL(pg, HEAAC_PARSE_ERR_DATA);   /* "ESC overflow", :1187-1190 */
                                     }
                                     v = (1u << (n + 4)) + bits(b, n + 4);
                                 }
@@ -460,30 +485,36 @@ static int read_spectrum(Bits *b, const HeaacToolsIcs *ics, const uint8_t band_t
 }
 
 /* decode_ics (:1334-1388) without apply_prediction (a GPU stage) */
-static int read_ics(const HeaacAacConfig *cfg, Bits *b, int common_window, HeaacToolsChannel *ch, WinInfo *w, float coef[1024])
+static int read_ics(const HeaacAacConfig *cfg, Bits *b, int common_window, HeaacToolsChannel *ch, WinInfo *w, float coef[1024],
+                    Progress *pg, int c)
 {
     Pulse pulse;
     pulse.num_pulse = 0;
     const unsigned global_gain = bits(b, 8);
     int r;
-    if (!common_window && (r = read_ics_info(cfg, b, &ch->ics, &ch->pred, w)) < 0)
+    if (!common_window && (r = read_ics_info(cfg, b, &ch->ics, &ch->pred, w, pg, c)) < 0)
         return r;
     const int eight = w->window_sequence[0] == HEAAC_EIGHT_SHORT_SEQUENCE;
     uint8_t run_end[128];
     memset(ch->band_type, 0, sizeof(ch->band_type));
     memset(ch->sf, 0, sizeof(ch->sf));
     memset(&ch->tns, 0, sizeof(ch->tns));
-    if ((r = read_band_types(b, &ch->ics, eight, ch->band_type, run_end)) < 0) return r;
-    if ((r = read_scalefactors(b, &ch->ics, eight, global_gain, ch->band_type, run_end, ch->sf)) < 0) return r;
+    if ((r = read_band_types(b, &ch->ics, eight, ch->band_type, run_end, pg)) < 0) return r;
+    if ((r = read_scalefactors(b, &ch->ics, eight, global_gain, ch->band_type, run_end, ch->sf, pg)) < 0) return r;
     const int pulse_present = (int)bit1(b);
     if (pulse_present) {
-        if (eight) return HEAAC_PARSE_ERR_DATA;        /* pulse tool not allowed in eight short sequence */
-        if ((r = read_pulses(b, &ch->ics, &pulse)) < 0) return r;
+        if (eight) return REF_FAIL(pg, HEAAC_PARSE_ERR_DATA);          /* pulse tool not allowed in eight short sequence */
+        if ((r = read_pulses(b, &ch->ics, &pulse, pg)) < 0) return r;
     }
     ch->tns.present = (uint8_t)bit1(b);
-    if (ch->tns.present && (r = read_tns(cfg, b, &ch->ics, eight, &ch->tns)) < 0) return r;
-    if (bit1(b)) return HEAAC_PARSE_ERR_UNSUPPORTED;   /* gain control (SSR) */
-    return read_spectrum(b, &ch->ics, ch->band_type, ch->sf, pulse_present, &pulse, coef);
+    if (ch->tns.present && (r = read_tns(cfg, b, &ch->ics, eight, &ch->tns, pg)) < 0) return r;
+    if (bit1(b)) return REF_FAIL(pg, HEAAC_PARSE_ERR_UNSUPPORTED);     /* gain control (SSR) */
+    pg->noise_stop[c] = 0;
+    if ((r = read_spectrum(b, &ch->ics, ch->band_type, ch->sf, pulse_present, &pulse, coef, pg, c)) < 0) return r;
+    pg->decoded[c] = 1;
+    /* apply_prediction inside decode_ics (:1381-1382) */
+    if (cfg->object_type == HEAAC_AOT_AAC_MAIN && !common_window) pg->predicted[c] = 1;
+    return HEAAC_PARSE_OK;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -494,29 +525,33 @@ enum { EXT_DYNAMIC_RANGE = 0xb, EXT_SBR_DATA = 0xd, EXT_SBR_DATA_CRC = 0xe };
 
 /* channel_pair_element behind its instance tag (decode_cpe, :1453-1492) without the spectral tools (GPU stages);
  * w[2] = the two channels' window history, coeffs [2][1024] */
-static int read_cpe(const HeaacAacConfig *cfg, Bits *b, HeaacToolsFrame *tools, WinInfo *w, float *coeffs)
+static int read_cpe(const HeaacAacConfig *cfg, Bits *b, HeaacToolsFrame *tools, WinInfo *w, float *coeffs, Progress *pg)
 {
     int r;
     const int common = (int)bit1(b);
     tools->common_window = (uint8_t)common;
     if (common) {
-        if ((r = read_ics_info(cfg, b, &tools->ch[0].ics, &tools->ch[0].pred, &w[0])) < 0) return r;
+        if ((r = read_ics_info(cfg, b, &tools->ch[0].ics, &tools->ch[0].pred, &w[0], pg, 0)) < 0) return r;
         /* channel 1 takes channel 0's ics, keeping its own previous window shape (:1462-1464) */
         const uint8_t kb_prev1 = w[1].use_kb_window[0];
         w[1] = w[0];
         w[1].use_kb_window[1] = kb_prev1;
+        pg->ics[1] = 1;
         tools->ch[1].ics = tools->ch[0].ics;
         tools->ch[1].pred = tools->ch[0].pred;
         tools->ms_present = (uint8_t)bits(b, 2);
-        if (tools->ms_present == 3) return HEAAC_PARSE_ERR_DATA;
+        if (tools->ms_present == 3) return REF_FAIL(pg, HEAAC_PARSE_ERR_DATA);
         const int nb = tools->ch[0].ics.num_window_groups * tools->ch[0].ics.max_sfb;
         if (tools->ms_present == 1)
             for (int i = 0; i < nb; i++) tools->ms_mask[i] = (uint8_t)bit1(b);
         else if (tools->ms_present == 2)
             memset(tools->ms_mask, 1, nb);
     }
-    if ((r = read_ics(cfg, b, common, &tools->ch[0], &w[0], coeffs)) < 0) return r;
-    return read_ics(cfg, b, common, &tools->ch[1], &w[1], coeffs + 1024);
+    if ((r = read_ics(cfg, b, common, &tools->ch[0], &w[0], coeffs, pg, 0)) < 0) return r;
+    if ((r = read_ics(cfg, b, common, &tools->ch[1], &w[1], coeffs + 1024, pg, 1)) < 0) return r;
+    /* apply_prediction at the end of decode_cpe (:1486-1489) */
+    if (common && cfg->object_type == HEAAC_AOT_AAC_MAIN) pg->predicted[0] = pg->predicted[1] = 1;
+    return HEAAC_PARSE_OK;
 }
 
 /* data_stream_element behind its tag (skip_data_stream_element, :602-620) */
@@ -692,7 +727,9 @@ static int read_cce(const HeaacAacConfig *cfg, Bits *b, int elem_id, HeaacCceFra
     CceListCoding k;
     k.sign_coded = (int)bit1(b);
     k.base = (float)pow(2., pow(2., (int)bits(b, 2) - 3));
-    int r = read_ics(cfg, b, 0, ch, w, coef);
+    Progress pg;                                       /* a refusal inside a coupling element is not followed up */
+    memset(&pg, 0, sizeof(pg));
+    int r = read_ics(cfg, b, 0, ch, w, coef, &pg, 0);
     if (r < 0) return r;
     out->ics = ch->ics;
     memcpy(out->band_type, ch->band_type, sizeof(out->band_type));
@@ -743,20 +780,14 @@ int heaac_aac_parse_frame(const HeaacAacConfig *cfg, HeaacAacStream *st,
     return heaac_aac_parse_frame_ex(cfg, st, au, size, 2, coeffs, ics, tools, NULL, info);
 }
 
-int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
-                             const uint8_t *au, int size, int coeff_channels,
-                             float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
-                             const HeaacCceOut *cce, HeaacAacFrameInfo *info)
+/* The walk over one access unit of a one-element stream; `b`, `w`, `pg`, `n_cce_seen` are the caller's so that it
+ * can tell, after a refusal, how far the walk had got. */
+static int frame_walk(const HeaacAacConfig *cfg, HeaacAacStream *st, const uint8_t *au, int size, int coeff_channels,
+                      float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools, const HeaacCceOut *cce,
+                      HeaacAacFrameInfo *info, Bits *b, WinInfo w[2], Progress *pg, int *n_cce_seen)
 {
-    if (!cfg || !st || !au || size <= 0 || !coeffs || !ics || !tools ||
-        cfg->sampling_index < 0 || cfg->sampling_index > 12 || coeff_channels < 1 || coeff_channels > 2 ||
-        (cce && (!cce->cce || !cce->coeffs || !cce->ics || !cce->tools)))
-        return HEAAC_PARSE_ERR_ARG;
-    pthread_once(&g_once, tables_init);
-    if (g_tables_bad) return HEAAC_PARSE_ERR_ARG;
-    Bits b;
-    bits_init(&b, au, size);
-    if (peek(&b, 12) == 0xfff) {
+    bits_init(b, au, size);
+    if (peek(b, 12) == 0xfff) {
         /* an ADTS header in front of the raw data block (aacdec.c:1988-1997) */
         HeaacAdtsHeader h;
         const int hs = heaac_adts_parse_header(&h, au, size);
@@ -766,16 +797,15 @@ int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
          * that contradicts it would be dequantised against the wrong band tables, so it is refused instead. */
         if (h.num_aac_frames != 1) return HEAAC_PARSE_ERR_UNSUPPORTED;
         if (h.sampling_index != cfg->sampling_index || h.object_type != cfg->object_type) return HEAAC_PARSE_ERR_DATA;
-        b.pos = hs * 8;
+        b->pos = hs * 8;
     }
-    WinInfo w[2], wc[HEAAC_MAX_CCE];
+    WinInfo wc[HEAAC_MAX_CCE];
     for (int c = 0; c < 2; c++) {
         w[c].window_sequence[0] = st->window_sequence[c];
         w[c].use_kb_window[0] = st->use_kb_window[c];
         w[c].window_sequence[1] = w[c].use_kb_window[1] = 0;
     }
-    memset(tools, 0, sizeof(*tools));
-    HeaacAacFrameInfo fi = { 0, 0, -1, 0, 0, 0, 0, 0 };
+    HeaacAacFrameInfo fi = { 0, 0, -1, 0, 0, 0, 0, 0, 0 };
     int last_che = 0, prev_type = TYPE_END;            /* 1 + type of the channel element last seen; the element in front */
     /* The coupling elements name their targets by (type, tag): the output element of this slice is the one SCE /
      * CPE of the configuration (set_default_channel_config: tag 0), known before the walk starts. */
@@ -783,19 +813,19 @@ int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
     int cce_tag[HEAAC_MAX_CCE], n_cce = 0;
     if (cce) memset(cce->cce, 0, HEAAC_MAX_CCE * sizeof(HeaacCceFrame));
     int elem, r;
-    while ((elem = (int)bits(&b, 3)) != TYPE_END) {
-        int elem_id = (int)bits(&b, 4);
+    while ((elem = (int)bits(b, 3)) != TYPE_END) {
+        int elem_id = (int)bits(b, 4);
         switch (elem) {
         case TYPE_SCE:
             if (fi.channels) return HEAAC_PARSE_ERR_UNSUPPORTED;
-            if ((r = read_ics(cfg, &b, 0, &tools->ch[0], &w[0], coeffs)) < 0) return r;
+            if ((r = read_ics(cfg, b, 0, &tools->ch[0], &w[0], coeffs, pg, 0)) < 0) return r;
             fi.channels = 1;
             fi.elem_id = elem_id;
             break;
         case TYPE_CPE: {
             if (fi.channels) return HEAAC_PARSE_ERR_UNSUPPORTED;
             if (coeff_channels < 2) return HEAAC_PARSE_ERR_ARG;
-            if ((r = read_cpe(cfg, &b, tools, w, coeffs)) < 0) return r;
+            if ((r = read_cpe(cfg, b, tools, w, coeffs, pg)) < 0) return r;
             fi.channels = 2;
             fi.elem_id = elem_id;
             break;
@@ -816,6 +846,7 @@ int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
             }
             cce_tag[slot] = elem_id;
             n_cce++;
+            *n_cce_seen = n_cce;
             /* the coupling channel's window history: by instance tag, as the reference keeps it (che[TYPE_CCE][tag]) --
              * slots move with the tags an access unit happens to carry and the order they arrive in */
             wc[slot].window_sequence[0] = st->cce_window_sequence[elem_id];
@@ -823,7 +854,7 @@ int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
             wc[slot].window_sequence[1] = wc[slot].use_kb_window[1] = 0;
             memset(&cce->tools[slot], 0, sizeof(HeaacToolsFrame));
             CceLists ls;
-            r = read_cce(cfg, &b, elem_id, &cce->cce[slot], &ls, &cce->tools[slot].ch[0], &wc[slot],
+            r = read_cce(cfg, b, elem_id, &cce->cce[slot], &ls, &cce->tools[slot].ch[0], &wc[slot],
                          cce->coeffs + slot * 1024);
             if (r < 0) return r;
             if ((r = cce_resolve(&ls, target_type, 0, &cce->cce[slot])) < 0) return r;
@@ -832,21 +863,23 @@ int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
             break;
         }
         case TYPE_LFE:
-            return HEAAC_PARSE_ERR_UNSUPPORTED;        /* no LFE in a one- or two-channel layout */
+            /* no LFE in a one- or two-channel layout: get_che finds no element for it ("channel element %d.%d is not
+             * allocated", :2011-2015) */
+            return REF_FAIL(pg, HEAAC_PARSE_ERR_UNSUPPORTED);
         case TYPE_DSE: {
-            if ((r = skip_dse(&b)) < 0) return r;
+            if ((r = skip_dse(b)) < 0) return r;
             break;
         }
         case TYPE_PCE:
-            if ((r = skip_pce(&b)) < 0) return r;
+            if ((r = skip_pce(b)) < 0) return r;
             break;
         case TYPE_FIL: {
-            if (elem_id == 15) elem_id += (int)bits(&b, 8) - 1;
-            if (bits_left(&b) < 8 * elem_id) return HEAAC_PARSE_ERR_OVERREAD;
+            if (elem_id == 15) elem_id += (int)bits(b, 8) - 1;
+            if (bits_left(b) < 8 * elem_id) return REF_OVERREAD(pg);                  /* :2053-2056 */
             /* an SBR payload is located here and parsed by sbr_parse.c.  decode_extension_payload hands it to the
              * channel element last seen, together with the type of the element directly in front (:2059) */
             int at, bytes = 0, crc = 0;
-            read_fil(&b, elem_id, &at, &bytes, &crc);
+            read_fil(b, elem_id, &at, &bytes, &crc);
             if (at >= 0) {
                 if (!last_che) return HEAAC_PARSE_ERR_DATA;            /* "SBR was found before the first channel element" */
                 if (last_che == TYPE_CCE + 1) return HEAAC_PARSE_ERR_UNSUPPORTED;   /* the coupling element's own SBR */
@@ -863,8 +896,8 @@ int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
         }
         if (elem < TYPE_DSE) last_che = elem + 1;
         prev_type = elem;
-        if (b.over) return HEAAC_PARSE_ERR_OVERREAD;
-        if (bits_left(&b) < 3) return HEAAC_PARSE_ERR_OVERREAD;
+        if (b->over) return HEAAC_PARSE_ERR_OVERREAD;
+        if (bits_left(b) < 3) return REF_OVERREAD(pg);                             /* :2072-2075 */
     }
     if (!fi.channels) return HEAAC_PARSE_ERR_DATA;
     if (fi.elem_id != 0 && n_cce) {
@@ -889,9 +922,115 @@ int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
         st->cce_use_kb_window[cce_tag[k]] = wc[k].use_kb_window[0];
     }
     fi.n_cce = n_cce;
-    fi.bits_consumed = b.pos;
+    fi.bits_consumed = b->pos;
     if (info) *info = fi;
     return HEAAC_PARSE_OK;
+}
+
+/* A channel record that only draws `draws` numbers from the noise generator (bands of at most 96 lines, the widest
+ * the band tables have) and leaves the predictors alone: one long window, so that no reset applies. */
+static void noise_only_channel(HeaacToolsChannel *ch, float *coef, int draws)
+{
+    memset(ch, 0, sizeof(*ch));
+    if (coef) memset(coef, 0, 1024 * sizeof(float));
+    ch->ics.num_windows = ch->ics.num_window_groups = ch->ics.group_len[0] = 1;
+    int nb = 0, at = 0;
+    while (draws > 0) {
+        const int len = draws < 96 ? draws : 96;
+        ch->ics.swb_offset[nb] = (uint16_t)at;
+        ch->band_type[nb] = HEAAC_NOISE_BT;
+        ch->sf[nb] = 1.0f;
+        at += len;
+        draws -= len;
+        nb++;
+    }
+    ch->ics.swb_offset[nb] = (uint16_t)at;
+    ch->ics.max_sfb = ch->ics.num_swb = (uint8_t)nb;
+}
+
+/* The noise bands among the first `stop` bands of a channel, in lines (= numbers drawn, :1016-1029) */
+static int noise_draws(const HeaacToolsChannel *ch, int stop)
+{
+    int idx = 0, draws = 0;
+    for (int g = 0; g < ch->ics.num_window_groups; g++)
+        for (int i = 0; i < ch->ics.max_sfb; i++, idx++)
+            if (idx < stop && ch->band_type[idx] == HEAAC_NOISE_BT)
+                draws += ch->ics.group_len[g] * (ch->ics.swb_offset[i + 1] - ch->ics.swb_offset[i]);
+    return draws;
+}
+
+/* A refused access unit gives no samples, but what the reference's element decoders did before they gave up is not
+ * undone (aac_decode_frame returns from the middle of its element loop, :2069-2070): the window history that
+ * decode_ics_info moved on or cleared, the numbers decode_spectrum_and_dequant drew for the noise bands it had passed,
+ * the predictors apply_prediction stepped for a channel it completed.  Where the refusal is the reference's own,
+ * `st` takes the same history here, and `tools` / `coeffs` are rewritten into records that make the spectral tools
+ * draw and predict exactly that much (HEAAC_REFUSED_RUN_TOOLS); their coefficients are of no further use. */
+static void unit_refused(const HeaacAacConfig *cfg, HeaacAacStream *st, const Bits *b, const WinInfo w[2],
+                         const Progress *pg, int n_cce, int coeff_channels, float *coeffs, HeaacToolsFrame *tools,
+                         HeaacAacFrameInfo *info)
+{
+    HeaacAacFrameInfo fi = { 0, 0, -1, 0, 0, 0, 0, 0, 0 };
+    if (pg->as_reference && (!b->over || pg->ref_overread) && !n_cce) {
+        fi.refused = HEAAC_REFUSED_AS_REFERENCE;
+        for (int c = 0; c < 2; c++) {
+            if (pg->ics[c] == 1) {
+                st->window_sequence[c] = w[c].window_sequence[0];
+                st->use_kb_window[c] = w[c].use_kb_window[0];
+            } else if (pg->ics[c] == 2) {
+                st->window_sequence[c] = st->use_kb_window[c] = 0;
+            }
+        }
+        const int main_profile = cfg->object_type == HEAAC_AOT_AAC_MAIN;
+        const int complete = pg->decoded[0] && (pg->ics[1] == 0 || pg->decoded[1]) &&
+                             (!main_profile || (pg->predicted[0] && (pg->ics[1] == 0 || pg->predicted[1])));
+        int work = 0;
+        if (complete) {
+            /* the element was decoded to its end (the refusal came behind it): its records stand as they are */
+            work = main_profile || noise_draws(&tools->ch[0], 128) || (pg->ics[1] && noise_draws(&tools->ch[1], 128));
+        } else {
+            tools->common_window = tools->ms_present = 0;
+            memset(tools->ms_mask, 0, sizeof(tools->ms_mask));
+            for (int c = 0; c < 2; c++) {
+                HeaacToolsChannel *ch = &tools->ch[c];
+                float *coef = c < coeff_channels ? coeffs + c * 1024 : NULL;
+                if (pg->decoded[c] && (!main_profile || pg->predicted[c])) {
+                    work |= main_profile || noise_draws(ch, 128);
+                    memset(&ch->tns, 0, sizeof(ch->tns));
+                } else {
+                    /* a channel that stopped inside its spectrum, or one whose prediction was still to come at the
+                     * end of the pair: only its noise bands have left a trace */
+                    const int draws = pg->ics[c] == 1 ? noise_draws(ch, pg->decoded[c] ? 128 : pg->noise_stop[c]) : 0;
+                    noise_only_channel(ch, coef, draws);
+                    work |= draws;
+                }
+            }
+        }
+        if (work) fi.refused |= HEAAC_REFUSED_RUN_TOOLS;
+    }
+    if (info) *info = fi;
+}
+
+int heaac_aac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st,
+                             const uint8_t *au, int size, int coeff_channels,
+                             float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
+                             const HeaacCceOut *cce, HeaacAacFrameInfo *info)
+{
+    if (!cfg || !st || !au || size <= 0 || !coeffs || !ics || !tools ||
+        cfg->sampling_index < 0 || cfg->sampling_index > 12 || coeff_channels < 1 || coeff_channels > 2 ||
+        (cce && (!cce->cce || !cce->coeffs || !cce->ics || !cce->tools)))
+        return HEAAC_PARSE_ERR_ARG;
+    pthread_once(&g_once, tables_init);
+    if (g_tables_bad) return HEAAC_PARSE_ERR_ARG;
+    Bits b;
+    WinInfo w[2];
+    Progress pg;
+    int n_cce = 0;
+    memset(&pg, 0, sizeof(pg));
+    memset(w, 0, sizeof(w));
+    memset(tools, 0, sizeof(*tools));
+    const int r = frame_walk(cfg, st, au, size, coeff_channels, coeffs, ics, tools, cce, info, &b, w, &pg, &n_cce);
+    if (r < 0) unit_refused(cfg, st, &b, w, &pg, n_cce, coeff_channels, coeffs, tools, info);
+    return r;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -1134,8 +1273,10 @@ int heaac_aac_parse_frame_layout_ex(const HeaacAacConfig *cfg, HeaacAacLayout *l
             HeaacToolsFrame *t = &tools[slot];
             memset(t, 0, sizeof(*t));
             float *co = coeffs + (size_t)slot * 2048;
-            if (type == TYPE_CPE) r = read_cpe(cfg, &b, t, w[slot], co);
-            else r = read_ics(cfg, &b, 0, &t->ch[0], &w[slot][0], co);
+            Progress pg;                               /* refusals are not followed up in the layouts (heaac_parse.h) */
+            memset(&pg, 0, sizeof(pg));
+            if (type == TYPE_CPE) r = read_cpe(cfg, &b, t, w[slot], co, &pg);
+            else r = read_ics(cfg, &b, 0, &t->ch[0], &w[slot][0], co, &pg, 0);
             if (r < 0) return r;
             elem[slot].present = 1;
             elem[slot].type = (uint8_t)type;

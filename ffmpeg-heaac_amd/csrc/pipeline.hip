@@ -31,7 +31,8 @@ struct Set {
     hipEvent_t in_start, in_done, run_done, out_done;
     int used;                       // a tick has gone through this set
     float parse_ms;
-    unsigned char *failed;          // [n] 1: the stream's access unit of this tick did not parse (core element)
+    unsigned char *failed;          // [n] the stream's access unit of this tick did not parse (core element): 1, or 2 where
+                                    // the spectral tools still have to move its noise generator / predictors
 };
 
 struct HeaacPipeline {
@@ -86,12 +87,18 @@ static void parse_slice(HeaacPipeline *p, int w)
         // no SBR payload -- and submit() parks its state rows around the launches: the stream is left as it was before
         // the unit and its PCM of this tick is zero.  (What was half written by the failed parse, and the SBR / PS
         // records of the tick that used this buffer set last, must not reach the kernels.)
+        // One thing does move, as in the reference: where its element decoders had drawn noise or stepped predictors
+        // before they refused the unit, the parser has left tools records that do exactly that much
+        // (HEAAC_REFUSED_RUN_TOOLS, heaac_parse.h) -- they run, and only the decoder's state rows are parked.
         const int core_failed = r < 0 && fi.channels == 0;
-        s->failed[i] = (unsigned char)core_failed;
+        const int run_tools = core_failed && (fi.refused & HEAAC_REFUSED_RUN_TOOLS);
+        s->failed[i] = (unsigned char)(core_failed ? 1 + run_tools : 0);
         if (core_failed) {
-            memset(s->h_coeffs + i * (size_t)p->ncore * 1024, 0, (size_t)p->ncore * 4096);
             memset(s->h_ics + i * p->ncore, 0, p->ncore * sizeof(HeaacIcs));
-            memset(&s->h_tools[i], 0, sizeof(HeaacToolsFrame));
+            if (!run_tools) {
+                memset(s->h_coeffs + i * (size_t)p->ncore * 1024, 0, (size_t)p->ncore * 4096);
+                memset(&s->h_tools[i], 0, sizeof(HeaacToolsFrame));
+            }
             if (p->he) {
                 // the record of "no payload" from a COPY of the stream's SBR state (the call moves kx / m along)
                 void *tmp = alloca(heaac_sbr_stream_bytes());
@@ -356,7 +363,7 @@ extern "C" int heaac_pipeline_submit(HeaacPipeline *p, const uint8_t *const *au,
     if (s->used) HIP_OK(hipStreamWaitEvent(p->run, s->out_done, 0));
     // streams whose unit failed: park their state rows (state, noise generator, predictors) before the launches ...
     size_t n_failed = 0;
-    for (size_t i = 0; i < n; i++) n_failed += s->failed[i];
+    for (size_t i = 0; i < n; i++) n_failed += s->failed[i] != 0;
     const size_t pred_row = (size_t)p->ncore * HEAAC_MAX_PREDICTORS;
     if (n_failed > p->park_rows) {
         // (grown outside the streams' order: nothing of the old area is in flight once `run` has drained)
@@ -378,6 +385,7 @@ extern "C" int heaac_pipeline_submit(HeaacPipeline *p, const uint8_t *const *au,
         for (size_t i = 0; i < n; i++) {
             if (!s->failed[i]) continue;
             HIP_OK(hipMemcpyAsync(p->d_park_state + j * p->words, p->d_state + i * p->words, p->words * 4, hipMemcpyDeviceToDevice, p->run));
+            if (s->failed[i] == 2) { j++; continue; }       // the tools' side of the stream moves on
             HIP_OK(hipMemcpyAsync(p->d_park_rng + j, p->d_rng + i, 4, hipMemcpyDeviceToDevice, p->run));
             if (p->d_pred)
                 HIP_OK(hipMemcpyAsync(p->d_park_pred + j * pred_row, p->d_pred + i * pred_row, pred_row * sizeof(HeaacPredictorState),
@@ -401,11 +409,12 @@ extern "C" int heaac_pipeline_submit(HeaacPipeline *p, const uint8_t *const *au,
         for (size_t i = 0; i < n; i++) {
             if (!s->failed[i]) continue;
             HIP_OK(hipMemcpyAsync(p->d_state + i * p->words, p->d_park_state + j * p->words, p->words * 4, hipMemcpyDeviceToDevice, p->run));
+            HIP_OK(hipMemsetAsync(s->d_pcm + i * pcm_row, 0, pcm_row * 2, p->run));
+            if (s->failed[i] == 2) { j++; continue; }
             HIP_OK(hipMemcpyAsync(p->d_rng + i, p->d_park_rng + j, 4, hipMemcpyDeviceToDevice, p->run));
             if (p->d_pred)
                 HIP_OK(hipMemcpyAsync(p->d_pred + i * pred_row, p->d_park_pred + j * pred_row, pred_row * sizeof(HeaacPredictorState),
                                       hipMemcpyDeviceToDevice, p->run));
-            HIP_OK(hipMemsetAsync(s->d_pcm + i * pcm_row, 0, pcm_row * 2, p->run));
             j++;
         }
     }

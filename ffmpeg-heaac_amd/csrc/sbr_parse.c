@@ -886,8 +886,8 @@ int heaac_heaac_parse_frame_ex(const HeaacAacConfig *cfg, HeaacAacStream *st, He
     if (info) *info = fi;
     if (!cfg || !sst || !tab || !sbr) return HEAAC_PARSE_ERR_ARG;
     const int r = heaac_aac_parse_frame_ex(cfg, st, au, size, coeff_channels, coeffs, ics, tools, NULL, &fi);
-    if (r) return r;                                   /* info->channels = 0: the core element failed */
-    if (info) *info = fi;
+    if (info) *info = fi;                              /* refused: channels = 0 and the HEAAC_REFUSED_* flags */
+    if (r) return r;
     const int allow_ps = (cfg->ps != 0 && fi.channels == 1 && ps != NULL ? HEAAC_SBR_ALLOW_PS : 0) |
                          (fi.sbr_misplaced ? HEAAC_SBR_MISPLACED : 0);
     if (fi.sbr_payload_bit < 0 || cfg->sbr == 0) {

@@ -493,6 +493,19 @@ static int dec_frame_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p, vo
     // A coupling channel element lands here too: in a channel configuration 1 / 2 stream get_che has no place for it
     // ("channel element 2.%d is not allocated", aacdec.c:132-177, :2006-2010) -- only a program config element
     // allocates coupling elements, and those streams take the layout path above.
+    if (r < 0 && fi.channels == 0 && (fi.refused & HEAAC_REFUSED_RUN_TOOLS) && p->configured) {
+        // No samples, but the reference's element decoders had drawn noise / stepped predictors before they refused
+        // the unit (heaac_parse.h, HEAAC_REFUSED_*): the records the parser left do exactly that much to the stream's
+        // generator and predictors; the coefficients they leave are dropped, the decoder's state stays.
+        const int ch = p->ncore;
+        const int main_profile = p->m4ac.object_type == HEAAC_AOT_AAC_MAIN;
+        if (hipMemcpy(p->d_coeffs, p->h_coeffs, (size_t)ch * 4096, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(p->d_tools, p->h_tools, sizeof(HeaacToolsFrame), hipMemcpyHostToDevice) == hipSuccess &&
+            heaac_spectral_tools_batch(p->dev, ch, p->d_coeffs, p->d_tools, p->d_rng, p->d_rng,
+                                       main_profile ? p->d_pred : NULL, main_profile ? p->d_pred : NULL, 1, NULL) == HEAAC_OK)
+            (void)hipDeviceSynchronize();
+        return -1;
+    }
     if (r == HEAAC_PARSE_ERR_UNSUPPORTED) return -1;
     if (r == HEAAC_PARSE_ERR_ARG) return -1;
     if (r < 0 && fi.channels == 0) return -1;          // the core element failed (aacdec.c:2046-2049)

@@ -132,7 +132,28 @@ typedef struct HeaacAacFrameInfo {
                                      reference hands its SBR reader the type of the element in between, which reads a
                                      header if there is one and then switches the element's SBR off (aacdec.c:2059,
                                      aacsbr.c:996-1000).  Pass HEAAC_SBR_MISPLACED to heaac_sbr_parse_payload. */
+    int refused;                  /* after a negative return of heaac_aac_parse_frame(_ex) / heaac_heaac_parse_frame(_ex):
+                                     HEAAC_REFUSED_* (the other fields are then 0, sbr_payload_bit -1) */
 } HeaacAacFrameInfo;
+
+/* A refused access unit gives no samples, but the reference does not undo what its element decoders had done by
+ * then (aac_decode_frame leaves its element loop at the first error, aacdec.c:2069-2070):
+ *   - decode_ics_info has moved the channel's window history on to the refused unit's, or cleared it where the
+ *     refusal is its own (memset of the IndividualChannelStream, :650, 687-705);
+ *   - decode_spectrum_and_dequant has drawn the numbers of the noise bands it passed (:1016-1029);
+ *   - apply_prediction has stepped the AAC-Main predictors of a channel that was completed (:1381, 1486-1489).
+ * HEAAC_REFUSED_AS_REFERENCE: the refusal is one the reference makes at the same bit of the unit (a reserved value,
+ * a range check, one of its three end-of-unit checks) and `st` now holds the window history its decoder is left
+ * with.  Clear for the refusals that are this parser's alone -- a read past the end of the unit where the reference
+ * reads on unchecked, element combinations it is not built for, any unit with a coupling element, the layout
+ * parsers: `st` is then untouched, as if the unit had not been there.
+ * HEAAC_REFUSED_RUN_TOOLS (only with the former): `tools` and `coeffs` have been rewritten into records under which
+ * heaac_spectral_tools_batch draws from the stream's noise generator and steps its predictors exactly as far as the
+ * reference had; run it on them as for a good unit (both channels of a pair) and discard the coefficients.
+ * The SBR / PS side of a refused unit is not followed up: an extension payload in front of the refusal, which the
+ * reference has read by then, is not read here. */
+#define HEAAC_REFUSED_AS_REFERENCE 1
+#define HEAAC_REFUSED_RUN_TOOLS    2
 
 /* What heaac_aac_parse_frame_ex adds for access units that carry coupling channel elements: per slot (ascending
  * instance tag, HEAAC_MAX_CCE slots) the element's coupling record with its gain lists resolved against the target

@@ -45,9 +45,10 @@ void heaac_pipeline_destroy(HeaacPipeline *p);
  * only).  Parses on the pool, then enqueues upload, decode and download and returns without waiting for them.
  * status (may be NULL) receives each stream's parse result (heaac_heaac_parse_frame's).  A stream whose access unit
  * does not parse (its core element: a negative status with no channels read; an SBR payload that fails only turns
- * SBR off for the unit, as in the reference) gets SILENCE for this tick and keeps its decoder state -- parser state,
- * DSP state record, noise generator, predictors -- as it was before the unit, whether or not status is given (the
- * reference returns an error and writes no samples, aacdec.c:2065-2068).  At most
+ * SBR off for the unit, as in the reference) gets SILENCE for this tick and keeps its DSP state record, whether or not
+ * status is given (the reference returns an error and writes no samples, aacdec.c:2065-2070).  Window history, noise
+ * generator and predictors are left as the reference's decoder leaves its own where the refusal is the reference's
+ * (HEAAC_REFUSED_AS_REFERENCE, heaac_parse.h), and as they were before the unit otherwise.  At most
  * HEAAC_PIPELINE_DEPTH ticks may be in flight: one more submit before a collect returns HEAAC_ERR_ARG. */
 int heaac_pipeline_submit(HeaacPipeline *p, const uint8_t *const *au, const int *size, int *status);
 

@@ -152,7 +152,7 @@ def test_pipeline_equals_the_calls_made_one_after_the_other(pkg, dev, cfgname):
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfgname", ["CFG_HEV2", "CFG_LC_STEREO"])
 def test_a_damaged_access_unit_gives_silence_and_leaves_its_stream_as_it_was(pkg, dev, cfgname):
-    """one unit of one stream does not parse (a reserved window grouping / truncated core element).  That
+    """one unit of one stream does not parse.  That
     stream's PCM of the tick is zero, and from the next tick on it decodes exactly as a stream that never saw the
     damaged unit; every other stream is untouched.  With and without a status array."""
     import torch
@@ -168,7 +168,10 @@ def test_a_damaged_access_unit_gives_silence_and_leaves_its_stream_as_it_was(pkg
         m4 = TP._cfg(pkg, 1, 3, 2)                                   # AAC-Main: the predictors are state too
     good = [list(a) for a in aus]
     for i in bad:
-        aus[bad_tick][i] = aus[bad_tick][i][:5] + bytes(8)           # the core element ends inside its side info
+        # a unit this parser alone refuses (a coupling element in a one-element stream): nothing of the stream moves.
+        # (Where the refusal is the reference's own, the stream is left where ITS decoder would be:
+        # tests/test_refused_units.py.)
+        aus[bad_tick][i] = bytes([0x40, 0]) + bytes(8)
     results = []
     for with_status in (True, False):
         pl = pkg.Pipeline(m4, cfg, n, threads=2)

@@ -1,0 +1,219 @@
+"""What a refused access unit leaves behind (include/heaac_parse.h, HEAAC_REFUSED_*): the reference returns from the
+middle of its element loop and undoes nothing (aacdec.c:2069-2070), so the window history, the noise generator and
+the AAC-Main predictors of the stream have moved as far as its element decoders had got.  tests/refused_units.py
+writes such units with a model of that state derived from what was written.  CPU: the parser's verdict, the history
+it leaves in the stream and the records it hands the spectral tools.  GPU: streams through the pipeline and through
+the codec surface carry on, after the refused unit, exactly like the call-by-call path driven by the model."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import refused_units as R
+import test_parse as TP
+
+SI = 3
+
+
+def _history(st, c):
+    return int(st["window_sequence"][0, c]), int(st["use_kb_window"][0, c])
+
+
+def _record_draws(t):
+    """Numbers a tools channel record draws: the lines of its noise bands."""
+    ics, total, idx = t["ics"], 0, 0
+    for g in range(int(ics["num_window_groups"])):
+        for i in range(int(ics["max_sfb"])):
+            if int(t["band_type"][idx]) == 13:
+                total += int(ics["group_len"][g]) * (int(ics["swb_offset"][i + 1]) - int(ics["swb_offset"][i]))
+            idx += 1
+    return total
+
+
+def _units(kinds, writer, aot, seed, per_kind=6):
+    rng = np.random.default_rng(seed)
+    return [(k,) + writer(rng, SI, aot, k) for k in kinds for _ in range(per_kind)]
+
+
+@pytest.mark.parametrize("aot", [2, 1])
+@pytest.mark.parametrize("cpe", [False, True])
+def test_the_parser_leaves_the_stream_where_the_reference_decoder_would_be(pkg, cpe, aot):
+    cfg = TP._cfg(pkg, aot, SI, 2 if cpe else 1)
+    seen = set()
+    for kind, bad, good, model in _units(R.KINDS_CPE if cpe else R.KINDS_SCE, R.cpe_unit if cpe else R.sce_unit, aot, 77 + cpe + 2 * aot):
+        st = np.zeros(1, pkg.AAC_STREAM_DT)
+        st["window_sequence"][0] = (3, 1); st["use_kb_window"][0] = (1, 1)
+        before = [_history(st, 0), _history(st, 1)]
+        r, out = pkg.aac_parse_frame_ex(cfg, st[0:1], bad, with_cce=False)
+        info = out["info"][0]
+        assert r < 0 and info["channels"] == 0 and info["sbr_payload_bit"] == -1, kind
+        if kind == "ours_only":
+            assert info["refused"] == 0 and [_history(st, 0), _history(st, 1)] == before
+            continue
+        assert info["refused"] & pkg.REFUSED_AS_REFERENCE, kind
+        for c in range(2):
+            want = model["history"][c] if c < len(model["history"]) and model["history"][c] is not None else before[c]
+            assert _history(st, c) == want, (kind, c)
+        seen.add(kind)
+        t = out["tools"][0]
+        run = bool(info["refused"] & pkg.REFUSED_RUN_TOOLS)
+        assert run == bool(model["draws"] or model["predicted"]), kind
+        if not run:
+            continue
+        assert sum(_record_draws(t["ch"][c]) for c in range(2 if cpe else 1)) == model["draws"], kind
+        for c in range(2 if cpe else 1):
+            pr, ics = t["ch"][c]["pred"], t["ch"][c]["ics"]
+            if aot == 1 and c not in model["predicted"]:
+                # nothing the prediction stage could do to this channel: no line below the limit, no reset
+                assert ics["num_windows"] == 1 and pr["pred_sfb_max"] == 0 and pr["predictor_reset_group"] == 0, kind
+        if model["predicted"]:
+            # the completed channels' records are the undamaged twin's, spectrum included
+            st2 = np.zeros(1, pkg.AAC_STREAM_DT)
+            r2, twin = pkg.aac_parse_frame_ex(cfg, st2[0:1], good, with_cce=False)
+            assert r2 == 0
+            for c in model["predicted"]:
+                a, b = t["ch"][c], twin["tools"][0]["ch"][c]
+                for f in ("ics", "band_type", "sf", "pred"):
+                    assert a[f].tobytes() == b[f].tobytes(), (kind, c, f)
+                assert np.array_equal(out["coeffs"][c].view(np.uint32), twin["coeffs"][c].view(np.uint32)), (kind, c)
+    assert seen == set(R.KINDS_CPE if cpe else R.KINDS_SCE) - {"ours_only"}
+
+
+def test_the_he_parser_passes_the_verdict_on(pkg):
+    """heaac_heaac_parse_frame_ex: channels = 0 and the flags of the core parser."""
+    import test_sbr_parse as TS
+    rng = np.random.default_rng(5)
+    bad, _, model = R.sce_unit(rng, SI, 2, "esc_overflow")
+    m4 = TS._he_cfg(pkg, 1, True)
+    m4.sampling_index, m4.sample_rate = SI, 48000
+    st, sst, tab = np.zeros(1, pkg.AAC_STREAM_DT), pkg.sbr_streams(1), pkg.SbrHeaderTable(8)
+    p = pkg.heaac_parse_batch(m4, st, sst, tab, [bad], with_ps=True)
+    assert p["status"][0] < 0 and p["info"]["channels"][0] == 0
+    assert p["info"]["refused"][0] == pkg.REFUSED_AS_REFERENCE | pkg.REFUSED_RUN_TOOLS
+    assert _history(st, 0) == model["history"][0] and _record_draws(p["tools"][0]["ch"][0]) == model["draws"] > 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GPU: streams carry on behind a refused unit as the model says
+# ------------------------------------------------------------------------------------------------------------------
+def _expected_run(pkg, oracle, cfg, ch, aot, ticks_good, bad_tick, models):
+    """The oracle over the good units, the refused tick replaced per stream by its model: no samples and the
+    decoder's overlap state kept; the window history set; the generator stepped `draws` times; the predictors of the
+    completed channels stepped by the oracle's tools on the undamaged twin's records."""
+    n = len(ticks_good[0])
+    st = np.zeros(n, pkg.AAC_STREAM_DT)
+    state = np.zeros((n, 512 * ch), np.float32)
+    rs = np.full(n, 0x1f2e3d4c, np.int32)
+    pred = np.tile(np.array([0, 0, 1, 1, 0, 0], np.float32), (n, ch, pkg.MAX_PREDICTORS, 1)) if aot == 1 else None
+    out = []
+    for t, aus in enumerate(ticks_good):
+        before = st.copy()
+        q = pkg.aac_parse_batch(cfg, st, aus, threads=1)
+        assert q["failed"] == 0
+        coeffs = np.ascontiguousarray(q["coeffs"][:, :ch])
+        tools = q["tools"].copy()
+        rs_before = rs.copy()
+        if t == bad_tick:
+            for i, m in models.items():
+                st[i] = before[i]
+                for c, h in enumerate(m["history"]):
+                    if h is not None:
+                        st["window_sequence"][i, c], st["use_kb_window"][i, c] = h
+                # the tools see the twin's records for the channels that were predicted and nothing for the others
+                for c in range(2):
+                    if c not in m["predicted"]:
+                        tools["ch"][i, c] = np.zeros((), tools.dtype["ch"].base)
+                tools["common_window"][i] = tools["ms_present"][i] = 0
+                tools["ch"]["tns"]["present"][i] = 0
+        if aot == 1:
+            ref_c, rs, pred = oracle.spectral_tools_batch(ch, coeffs, tools, rng=rs, pred=pred)
+        else:
+            ref_c, rs = oracle.spectral_tools_batch(ch, coeffs, tools, rng=rs)
+        if t == bad_tick:
+            for i, m in models.items():
+                stepped = R.lcg(rs_before[i], m["draws"])
+                # (a predicted channel's numbers were drawn by its own records: the same count)
+                assert not m["predicted"] or rs[i] == stepped, (i, m)
+                rs[i] = stepped
+        ics = np.ascontiguousarray(q["ics"][:, :ch])
+        pcm, new_state = oracle.lc_decode_batch(ch, ref_c, ics, state, oracle.PCM_S16)
+        pcm = pcm.copy()
+        if t == bad_tick:
+            for i in models:
+                new_state[i] = state[i]
+                pcm[i] = 0
+        state = new_state
+        out.append(pcm)
+    return out
+
+
+def _streams(pkg, cpe, aot, seed, ticks=5, bad_tick=2, rounds=2):
+    rng = np.random.default_rng(seed)
+    kinds = R.KINDS_CPE if cpe else R.KINDS_SCE
+    writer = R.cpe_unit if cpe else R.sce_unit
+    n = rounds * len(kinds) + 3
+    good = [[TP._write_au(rng, SI, aot, cpe, extras=False, quiet=True)[0] for _ in range(n)] for _ in range(ticks)]
+    fed = [list(a) for a in good]
+    models = {}
+    for j, kind in enumerate(kinds * rounds):
+        i = j + 1
+        bad, twin, model = writer(rng, SI, aot, kind)
+        fed[bad_tick][i] = bad
+        good[bad_tick][i] = twin
+        models[i] = model
+    return good, fed, models, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aot", [2, 1])
+@pytest.mark.parametrize("cpe", [False, True])
+def test_streams_carry_on_behind_a_refused_unit_as_the_reference_decoder_would(pkg, oracle, dev, cpe, aot):
+    """Through the pipeline: a batch in which every kind of refused unit hits some stream at one tick."""
+    ch, bad_tick = 2 if cpe else 1, 2
+    cfg = TP._cfg(pkg, aot, SI, ch)
+    good, fed, models, n = _streams(pkg, cpe, aot, 31 + cpe + 2 * aot, bad_tick=bad_tick)
+    want = _expected_run(pkg, oracle, cfg, ch, aot, good, bad_tick, models)
+    pl = pkg.Pipeline(cfg, pkg.CFG_LC_STEREO if cpe else pkg.CFG_LC_MONO, n, threads=2)
+    for t in range(len(fed)):
+        status = pl.submit(fed[t])
+        got = pl.collect().copy()
+        assert [i for i in range(n) if status[i] < 0] == (sorted(models) if t == bad_tick else []), t
+        assert np.array_equal(got, want[t]), (t, [i for i in range(n) if not np.array_equal(got[i], want[t][i])])
+    pl.close()
+    assert all(any(want[t][i].any() for t in range(bad_tick + 1, len(fed))) for i in models)
+    # the model matters: a stream that simply skipped the unit would sound different afterwards
+    skipped = _expected_run(pkg, oracle, cfg, ch, aot, good, bad_tick,
+                            {i: dict(history=[None, None], draws=0, predicted=[]) for i in models})
+    differ = [i for i in models if any(not np.array_equal(skipped[t][i], want[t][i]) for t in range(bad_tick + 1, len(fed)))]
+    assert len(differ) >= len(models) // 2, differ
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aot", [2, 1])
+@pytest.mark.parametrize("cpe", [False, True])
+def test_the_codec_surface_carries_on_behind_a_refused_unit(pkg, oracle, dev, cpe, aot):
+    """heaac_codec_decode, one stream per kind: -1 and no samples for the refused unit, then on as the model says."""
+    from test_shim_gpu import HeaacCodecContext, HeaacPacket
+    lib = pkg.lib()
+    ch, bad_tick = 2 if cpe else 1, 2
+    cfg = TP._cfg(pkg, aot, SI, ch)
+    good, fed, models, n = _streams(pkg, cpe, aot, 57 + cpe + 2 * aot, bad_tick=bad_tick, rounds=1)
+    want = _expected_run(pkg, oracle, cfg, ch, aot, good, bad_tick, models)
+    asc = bytes([(aot << 3) | (SI >> 1), ((SI & 1) << 7) | (ch << 3)])
+    codec = C.c_void_p.in_dll(lib, "heaac_aac_decoder")
+    out = (C.c_int16 * (192000 // 2))()
+    for i in range(n):
+        ctx = HeaacCodecContext(cfg=-1, extradata=asc, extradata_size=len(asc))
+        assert lib.heaac_codec_open(C.byref(ctx), C.c_void_p(C.addressof(codec))) == 0
+        for t in range(len(fed)):
+            buf = C.create_string_buffer(fed[t][i], len(fed[t][i]))
+            pkt = HeaacPacket(C.cast(buf, C.c_void_p), len(fed[t][i]))
+            size = C.c_int(192000)
+            used = lib.heaac_codec_decode(C.byref(ctx), out, C.byref(size), C.byref(pkt))
+            if t == bad_tick and i in models:
+                assert used < 0, (i, t)
+                continue
+            assert used == len(fed[t][i]) and size.value == 1024 * ch * 2, (i, t, used)
+            got = np.frombuffer(out, np.int16, 1024 * ch).reshape(1024, ch)
+            assert np.array_equal(got, want[t][i]), (i, t)
+        assert lib.heaac_codec_close(C.byref(ctx)) == 0
