@@ -24,6 +24,27 @@ static uint32_t rnd(void) { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; retur
 
 typedef struct { uint32_t kind, len; uint8_t *data; } Seed;
 
+/* What the spectral-tools kernel takes on trust from a channel record (k_tools.hip indexes by these): groups and
+ * windows that tile the frame, bands inside it, no noise band wider than the 96 lines its generator table spans. */
+static int tools_channel_bad(const HeaacToolsChannel *c, int allow_empty)
+{
+    const HeaacToolsIcs *ic = &c->ics;
+    if (allow_empty && ic->num_window_groups == 0 && ic->max_sfb == 0 && ic->num_windows == 0) return 0;
+    if ((ic->num_windows != 1 && ic->num_windows != 8) || ic->num_window_groups < 1 || ic->num_window_groups > 8) return 1;
+    if (ic->max_sfb > ic->num_swb || ic->num_swb > 63 || ic->num_window_groups * ic->max_sfb > 120) return 2;
+    int wins = 0;
+    for (int g = 0; g < ic->num_window_groups; g++) wins += ic->group_len[g];
+    if (wins != ic->num_windows) return 3;
+    for (int i = 0; i < ic->max_sfb; i++) if (ic->swb_offset[i] >= ic->swb_offset[i + 1]) return 4;
+    if (ic->swb_offset[ic->max_sfb] > (ic->num_windows == 8 ? 128 : 1024)) return 5;
+    int idx = 0;
+    for (int g = 0; g < ic->num_window_groups; g++)
+        for (int i = 0; i < ic->max_sfb; i++, idx++)
+            if (c->band_type[idx] == HEAAC_NOISE_BT && ic->swb_offset[i + 1] - ic->swb_offset[i] > 96) return 6;
+    if (c->pred.pred_sfb_max > ic->num_swb && ic->num_windows == 1 && c->pred.pred_sfb_max > 41) return 7;
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 3) { printf("usage: fuzz_parse seeds.bin iterations\n"); return 2; }
@@ -87,7 +108,7 @@ int main(int argc, char **argv)
     HeaacIcs lics[HEAAC_MAX_ELEMENTS][2];
     HeaacToolsFrame *ltools = malloc(HEAAC_MAX_ELEMENTS * sizeof(*ltools));
     HeaacAacElementInfo lelem[HEAAC_MAX_ELEMENTS];
-    long layouts_ok = 0, layout_units = 0, layout_bad = 0, coupled_units = 0, coupled_links = 0;
+    long tools_runs = 0, layouts_ok = 0, layout_units = 0, layout_bad = 0, coupled_units = 0, coupled_links = 0;
     HeaacCceFrame *lcce = malloc(HEAAC_MAX_ELEMENTS * HEAAC_MAX_CCE * sizeof(*lcce));
     HeaacAacElementInfo lcce_elem[HEAAC_MAX_CCE];
     const HeaacCceOut lco = { lcce, cce_coeffs, cce_ics, cce_tools, lcce_elem };
@@ -242,6 +263,16 @@ int main(int argc, char **argv)
                                               &sbr, k == 2 ? &ps : NULL, &info);
         free(au);
         if (r >= 0) ok++; else err++;
+        /* records the spectral tools will run on: a parsed unit's, and what a refused unit leaves for them */
+        if (info.channels || (info.refused & HEAAC_REFUSED_RUN_TOOLS)) {
+            const int nch = info.channels ? info.channels : cfg[k].chan_config;
+            tools_runs += !info.channels;
+            for (int c = 0; c < nch; c++) {
+                const int v = tools_channel_bad(&tools->ch[c], !info.channels);
+                if (v) { bad_records++; if (bad_records < 5) printf("iteration %ld: status %d, tools record breaks rule %d\n", it, r, v); }
+            }
+        }
+        if (!info.channels && (info.refused & ~3)) bad_records++;
         if (info.channels) {                                                   /* the core element parsed: records were written */
             int v = heaac_check_sbr_frame(&sbr, heaac_sbr_table_data(tab), heaac_sbr_table_count(tab), info.channels);
             if (!v && k == 2) v = heaac_check_ps_frame(&ps);
@@ -252,6 +283,7 @@ int main(int argc, char **argv)
     }
     printf("iterations %ld: parsed %ld, refused %ld, frames with start = 1: %ld, headers %zu, invalid records %ld\n",
            iters, ok, err, started, heaac_sbr_table_count(tab), bad_records);
+    printf("refused units that leave work for the spectral tools %ld\n", tools_runs);
     printf("coupling elements parsed %ld, ADTS frames delivered %ld, ADTS walks that did not tile %ld\n", coupled, adts_frames, adts_bad);
     printf("5.1 units parsed %ld, program config layouts accepted %ld, out of range %ld\n", layout_units, layouts_ok, layout_bad);
     printf("coupled layout units parsed %ld, gain lists landed %ld\n", coupled_units, coupled_links);

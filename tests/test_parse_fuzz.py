@@ -57,6 +57,8 @@ def test_parsers_survive_damaged_access_units():
     m = re.search(r"parsed (\d+), refused (\d+), frames with start = 1: (\d+)", p.stdout)
     # the run is not vacuous: many frames parse, many are refused, SBR streams keep (re)starting
     assert int(m.group(1)) > 60000 and int(m.group(2)) > 60000 and int(m.group(3)) > 10000, m.group(0)
+    m = re.search(r"refused units that leave work for the spectral tools (\d+)", p.stdout)
+    assert int(m.group(1)) > 1000, m.group(0)
     m = re.search(r"coupling elements parsed (\d+), ADTS frames delivered (\d+)", p.stdout)
     assert int(m.group(1)) > 5000 and int(m.group(2)) > 10000, m.group(0)
     m = re.search(r"5.1 units parsed (\d+), program config layouts accepted (\d+), out of range (\d+)", p.stdout)
