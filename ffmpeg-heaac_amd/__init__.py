@@ -130,7 +130,7 @@ EXPORTED = [
     "heaac_heaac_parse_frame_ex", "heaac_pipeline_create", "heaac_pipeline_destroy", "heaac_pipeline_submit",
     "heaac_pipeline_collect", "heaac_pipeline_timing",
     "heaac_layout_pipeline_create", "heaac_layout_pipeline_destroy", "heaac_layout_pipeline_submit",
-    "heaac_layout_pipeline_collect",
+    "heaac_layout_pipeline_collect", "heaac_layout_pipeline_channels",
     # heaac_debug.h
     "heaac_debug_workspace", "heaac_debug_xbands",
     "heaac_multi_shard", "heaac_multi_create", "heaac_multi_destroy", "heaac_multi_devices", "heaac_multi_device",
@@ -614,6 +614,7 @@ class LayoutPipeline:
         self._layout = np.ascontiguousarray(layout)
         _check(lib().heaac_layout_pipeline_create(C.byref(self._h), C.byref(aac_cfg), self._layout.ctypes.data_as(C.c_void_p),
                                                   C.c_size_t(n_streams), threads), "heaac_layout_pipeline_create")
+        self.ch = int(lib().heaac_layout_pipeline_channels(self._h))
 
     def submit(self, aus):
         assert len(aus) == self.n

@@ -19,6 +19,8 @@ int heaac_sbr_output_mode(const HeaacAacConfig *m);
 
 HeaacLayoutDec *heaac_layout_dec_create(HeaacDevice *dev, const HeaacAacConfig *m4ac, const HeaacAacLayout *layout);
 void heaac_layout_dec_destroy(HeaacLayoutDec *d);
+// avctx->channels: the layout's channels, plus one for every SCE that carries Parametric Stereo (aacdec.c:203-206)
+int heaac_layout_dec_channels(const HeaacLayoutDec *d);
 // One access unit -> interleaved int16 in `data` (host).  Returns the bytes consumed (aacdec.c:2102-2107) or -1.
 int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void *data, int *data_size,
                            HeaacLayoutOut *out);

@@ -24,15 +24,19 @@
 
 #define LAY_MAX_HDRS 64
 #define CCE_STATE_WORDS HEAAC_STATE_WORDS_HEV1_MONO
+#define LAY_STATE_WORDS (HEAAC_STATE_WORDS_HEV2 > HEAAC_STATE_WORDS_HEV1 ? HEAAC_STATE_WORDS_HEV2 : HEAAC_STATE_WORDS_HEV1)
 
 struct LayElem {
     int cfg_lc, cfg_he, channels;
+    int out_channels, first_out;  // planes the element gives and where they stand among the stream's; 2 for an SCE
+                                  // that carries Parametric Stereo (che_configure, aacdec.c:203-206)
+    HeaacPsFrame *d_ps;           // ... and its record
     HeaacAacStream ast;
     HeaacSbrStream sst;
     float *d_coeffs;              // [2][1024]
     HeaacIcs *d_ics;              // [2]
     HeaacToolsFrame *d_tools;
-    float *d_state;               // HEAAC_STATE_WORDS_HEV1 (the largest of the four configurations)
+    float *d_state;               // LAY_STATE_WORDS (the largest of the configurations)
     HeaacPredictorState *d_pred;  // [2][672]
     HeaacSbrFrame *d_sbr;
     float *d_f32;                 // [2][2048]
@@ -63,6 +67,7 @@ struct HeaacLayoutDec {
     HeaacDevice *dev;
     HeaacAacConfig m4ac;
     HeaacAacLayout layout;
+    int out_channels;             // avctx->channels: the layout's, plus one per SCE with Parametric Stereo
     int locked;                   // the first access unit has settled implicit SBR (output_configured == OC_LOCKED)
     int n;
     LayElem e[HEAAC_MAX_ELEMENTS];
@@ -130,6 +135,7 @@ void heaac_layout_dec_destroy(HeaacLayoutDec *d)
         if (e.d_pred) (void)hipFree(e.d_pred);
         if (e.d_sbr) (void)hipFree(e.d_sbr);
         if (e.d_f32) (void)hipFree(e.d_f32);
+        if (e.d_ps) (void)hipFree(e.d_ps);
     }
     if (d->d_hdr) (void)hipFree(d->d_hdr);
     if (d->d_rng) (void)hipFree(d->d_rng);
@@ -141,17 +147,30 @@ void heaac_layout_dec_destroy(HeaacLayoutDec *d)
     free(d);
 }
 
+int heaac_layout_dec_channels(const HeaacLayoutDec *d) { return d ? d->out_channels : 0; }
+
 HeaacLayoutDec *heaac_layout_dec_create(HeaacDevice *dev, const HeaacAacConfig *m4ac, const HeaacAacLayout *layout)
 {
     if (!dev || !m4ac || !layout || layout->n_elements < 1 || layout->n_elements > HEAAC_MAX_ELEMENTS ||
         layout->channels < 1 || layout->channels > HEAAC_MAX_PCM_PLANES)
         return NULL;
+    // Explicitly signalled SBR with the Parametric Stereo question left open (ps = -1: only a program-config layout
+    // leaves it open, mpeg4audio.c:137-139) is ps = 1 to decode_audio_specific_config (aacdec.c:476-477), and
+    // che_configure then gives EVERY single channel element of the layout a second output channel (:203-206):
+    // ff_sbr_apply runs ff_ps_apply on it once PS data has arrived and copies the left channel until then
+    // (aacsbr.c:1751-1758).  An LFE stays one channel (its type is not TYPE_SCE).
+    const int ps_sce = m4ac->sbr == 1 && m4ac->ps == 1;
+    int outs = 0;
+    for (int i = 0; i < layout->n_elements; i++)
+        outs += ps_sce && layout->elem[i].type == HEAAC_ELEM_SCE ? 2 : layout->elem[i].channels;
+    if (outs > HEAAC_MAX_PCM_PLANES) return NULL;
     HeaacLayoutDec *d = (HeaacLayoutDec *)calloc(1, sizeof(*d));
     if (!d) return NULL;
     d->dev = dev;
     d->m4ac = *m4ac;
     d->layout = *layout;
     d->n = layout->n_elements;
+    d->out_channels = outs;
     d->tab = heaac_sbr_table_create(LAY_MAX_HDRS);
     d->h_coeffs = (float *)calloc((size_t)d->n * 2048, sizeof(float));
     d->h_tools = (HeaacToolsFrame *)calloc(d->n, sizeof(HeaacToolsFrame));
@@ -163,15 +182,19 @@ HeaacLayoutDec *heaac_layout_dec_create(HeaacDevice *dev, const HeaacAacConfig *
         e.channels = layout->elem[i].channels;
         e.cfg_lc = e.channels == 2 ? HEAAC_CFG_LC_STEREO : HEAAC_CFG_LC_MONO;
         e.cfg_he = e.channels == 2 ? HEAAC_CFG_HEV1 : HEAAC_CFG_HEV1_MONO;
+        e.out_channels = e.channels;
+        if (ps_sce && layout->elem[i].type == HEAAC_ELEM_SCE) { e.cfg_he = HEAAC_CFG_HEV2; e.out_channels = 2; }
+        e.first_out = i ? d->e[i - 1].first_out + d->e[i - 1].out_channels : 0;
         heaac_sbr_stream_init(&e.sst, 1);
         ok = hipMalloc((void **)&e.d_coeffs, 2 * 1024 * 4) == hipSuccess &&
              hipMalloc((void **)&e.d_ics, 2 * sizeof(HeaacIcs)) == hipSuccess &&
              hipMalloc((void **)&e.d_tools, sizeof(HeaacToolsFrame)) == hipSuccess &&
-             hipMalloc((void **)&e.d_state, HEAAC_STATE_WORDS_HEV1 * 4) == hipSuccess &&
+             hipMalloc((void **)&e.d_state, LAY_STATE_WORDS * 4) == hipSuccess &&
+             hipMalloc((void **)&e.d_ps, sizeof(HeaacPsFrame)) == hipSuccess &&
              hipMalloc((void **)&e.d_pred, 2 * HEAAC_MAX_PREDICTORS * sizeof(*ps)) == hipSuccess &&
              hipMalloc((void **)&e.d_sbr, sizeof(HeaacSbrFrame)) == hipSuccess &&
              hipMalloc((void **)&e.d_f32, 2 * 2048 * 4) == hipSuccess &&
-             hipMemset(e.d_state, 0, HEAAC_STATE_WORDS_HEV1 * 4) == hipSuccess &&
+             hipMemset(e.d_state, 0, LAY_STATE_WORDS * 4) == hipSuccess &&
              hipMemcpy(e.d_pred, ps, 2 * HEAAC_MAX_PREDICTORS * sizeof(*ps), hipMemcpyHostToDevice) == hipSuccess;
     }
     for (int id = 0; ok && id < 16; id++)
@@ -181,7 +204,7 @@ HeaacLayoutDec *heaac_layout_dec_create(HeaacDevice *dev, const HeaacAacConfig *
     for (int i = 0; i < LAY_MAX_HDRS; i++) d->hdr[i].kx = 32;          // kx' = 32, m = 0 (aacsbr.c:130)
     ok = ok && hipMalloc((void **)&d->d_hdr, sizeof(d->hdr)) == hipSuccess &&
          hipMalloc((void **)&d->d_rng, 4) == hipSuccess &&
-         hipMalloc((void **)&d->d_pcm, (size_t)layout->channels * 2048 * 2) == hipSuccess &&
+         hipMalloc((void **)&d->d_pcm, (size_t)outs * 2048 * 2) == hipSuccess &&
          hipMemcpy(d->d_hdr, d->hdr, sizeof(d->hdr), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(d->d_rng, &seed, 4, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { heaac_layout_dec_destroy(d); return NULL; }
@@ -335,20 +358,25 @@ int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void
                                        HEAAC_PCM_F32_PLANAR, 1, NULL);
         } else {
             HeaacSbrFrame sbr;
+            HeaacPsFrame ps;
+            const bool with_ps = e.cfg_he == HEAAC_CFG_HEV2;
             const HeaacAacElementInfo &ei = d->h_elem[i];
             if (ei.sbr_payload_bit >= 0) {
                 // a failed payload leaves its degraded record (start = 0) and the decode goes on, as ff_sbr_apply does
                 (void)heaac_sbr_parse_payload(&e.sst, d->tab, d->m4ac.sample_rate, buf, size, ei.sbr_payload_bit,
-                                              ei.sbr_payload_bytes, ei.sbr_crc, e.channels, ei.sbr_misplaced ? HEAAC_SBR_MISPLACED : 0,
-                                              &sbr, NULL, NULL);
+                                              ei.sbr_payload_bytes, ei.sbr_crc, e.channels,
+                                              (ei.sbr_misplaced ? HEAAC_SBR_MISPLACED : 0) | (with_ps ? HEAAC_SBR_ALLOW_PS : 0),
+                                              &sbr, with_ps ? &ps : NULL, NULL);
             } else {
-                heaac_sbr_no_payload(&e.sst, e.channels, &sbr, NULL);
+                heaac_sbr_no_payload(&e.sst, e.channels, &sbr, with_ps ? &ps : NULL);
             }
             if (sync_headers()) return -1;
-            if (heaac_validate_frame(e.cfg_he, &sbr, d->hdr, LAY_MAX_HDRS, NULL)) return -1;
+            if (heaac_validate_frame(e.cfg_he, &sbr, d->hdr, LAY_MAX_HDRS, with_ps ? &ps : NULL)) return -1;
             if (hipMemcpy(e.d_sbr, &sbr, sizeof(sbr), hipMemcpyHostToDevice) != hipSuccess) return -1;
+            if (with_ps && hipMemcpy(e.d_ps, &ps, sizeof(ps), hipMemcpyHostToDevice) != hipSuccess) return -1;
             rc = heaac_he_decode_batch_ex(d->dev, e.cfg_he, mode ? HEAAC_HE_DOWNSAMPLED : 0, e.d_coeffs, e.d_ics, e.d_sbr, d->d_hdr,
-                                          LAY_MAX_HDRS, NULL, e.d_state, e.d_state, e.d_f32, HEAAC_PCM_F32_PLANAR, 1, NULL);
+                                          LAY_MAX_HDRS, with_ps ? e.d_ps : NULL, e.d_state, e.d_state, e.d_f32, HEAAC_PCM_F32_PLANAR,
+                                          1, NULL);
         }
         if (rc != HEAAC_OK) return -1;
         // every AFTER_IMDCT element in tag order, every gain list it lands on this element (apply_channel_coupling
@@ -367,19 +395,20 @@ int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void
                     return -1;
             }
         }
-        for (int c = 0; c < e.channels; c++) {
-            planes[d->layout.elem[i].first_channel + c].d_base = e.d_f32 + (size_t)c * len;
-            planes[d->layout.elem[i].first_channel + c].frame_stride = (size_t)e.channels * len;
+        const int np = he ? e.out_channels : e.channels;
+        for (int c = 0; c < np; c++) {
+            planes[e.first_out + c].d_base = e.d_f32 + (size_t)c * len;
+            planes[e.first_out + c].frame_stride = (size_t)np * len;
         }
     }
-    if (heaac_pcm_interleave_batch(d->dev, d->layout.channels, planes, len, HEAAC_PCM_S16_INTERLEAVED, d->d_pcm, 1, NULL) != HEAAC_OK)
+    if (heaac_pcm_interleave_batch(d->dev, d->out_channels, planes, len, HEAAC_PCM_S16_INTERLEAVED, d->d_pcm, 1, NULL) != HEAAC_OK)
         return -1;
-    const int bytes = len * d->layout.channels * 2;
+    const int bytes = len * d->out_channels * 2;
     if (*data_size < bytes) return -1;                       // "Output buffer too small" (aacdec.c:2087-2092)
     if (hipMemcpy(data, d->d_pcm, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     *data_size = bytes;
     if (out) {
-        out->channels = d->layout.channels;
+        out->channels = d->out_channels;
         out->channel_layout = d->layout.channel_layout;
         out->frame_size = len;
         out->sample_rate = he && !mode ? 2 * d->m4ac.sample_rate : d->m4ac.sample_rate;

@@ -26,6 +26,7 @@
 
 struct LpElem {
     int channels, cfg, words;
+    int out, first_out;             // planes the element gives (2 for an SCE with Parametric Stereo) and where they stand
     // persistent, device
     float *d_state;                 // [n][words]
     HeaacPredictorState *d_pred;    // [n][channels][672] (AAC-Main) or NULL
@@ -39,6 +40,7 @@ struct LpSet {
     HeaacIcs *h_ics[HEAAC_MAX_ELEMENTS], *d_ics[HEAAC_MAX_ELEMENTS];
     HeaacToolsFrame *h_tools[HEAAC_MAX_ELEMENTS], *d_tools[HEAAC_MAX_ELEMENTS];
     HeaacSbrFrame *h_sbr[HEAAC_MAX_ELEMENTS], *d_sbr[HEAAC_MAX_ELEMENTS];
+    HeaacPsFrame *h_ps[HEAAC_MAX_ELEMENTS], *d_ps[HEAAC_MAX_ELEMENTS];     // single channel elements with Parametric Stereo only
     int16_t *h_pcm, *d_pcm;
     unsigned char *failed;          // [n]
     unsigned char *seq;             // [n][ne] bitstream position of each element
@@ -50,6 +52,7 @@ struct HeaacLayoutPipeline {
     HeaacAacConfig aac;
     HeaacAacLayout layout;
     int ne, he, downsampled, len, main_profile;
+    int out_channels;               // the layout's channels, plus one per SCE with Parametric Stereo
     size_t n;
     HeaacDevice *dev;
     hipStream_t run;
@@ -92,7 +95,7 @@ static void neutral(HeaacLayoutPipeline *p, LpSet *s, size_t i)
         if (p->he) {
             void *tmp = alloca(heaac_sbr_stream_bytes());
             memcpy(tmp, sst_at(p->e[k].sst, i), heaac_sbr_stream_bytes());
-            heaac_sbr_no_payload((HeaacSbrStream *)tmp, ch, &s->h_sbr[k][i], NULL);
+            heaac_sbr_no_payload((HeaacSbrStream *)tmp, ch, &s->h_sbr[k][i], s->h_ps[k] ? &s->h_ps[k][i] : NULL);
         }
     }
 }
@@ -133,12 +136,14 @@ static void lp_parse_slice(HeaacLayoutPipeline *p, int w)
             s->h_tools[k][i] = tt[k];
             if (p->he) {
                 // a failed payload leaves its degraded record (start = 0) and the decode goes on, as ff_sbr_apply does
+                HeaacPsFrame *ps = s->h_ps[k] ? &s->h_ps[k][i] : NULL;
                 if (te[k].sbr_payload_bit >= 0)
                     (void)heaac_sbr_parse_payload(sst_at(p->e[k].sst, i), p->tab, p->aac.sample_rate, p->job_au[i], p->job_size[i],
                                                   te[k].sbr_payload_bit, te[k].sbr_payload_bytes, te[k].sbr_crc, ch,
-                                                  te[k].sbr_misplaced ? HEAAC_SBR_MISPLACED : 0, &s->h_sbr[k][i], NULL, NULL);
+                                                  (te[k].sbr_misplaced ? HEAAC_SBR_MISPLACED : 0) | (ps ? HEAAC_SBR_ALLOW_PS : 0),
+                                                  &s->h_sbr[k][i], ps, NULL);
                 else
-                    heaac_sbr_no_payload(sst_at(p->e[k].sst, i), ch, &s->h_sbr[k][i], NULL);
+                    heaac_sbr_no_payload(sst_at(p->e[k].sst, i), ch, &s->h_sbr[k][i], ps);
             }
         }
     }
@@ -187,8 +192,8 @@ extern "C" void heaac_layout_pipeline_destroy(HeaacLayoutPipeline *p)
     for (int q = 0; q < LP_DEPTH; q++) {
         LpSet *s = &p->set[q];
         for (int k = 0; k < HEAAC_MAX_ELEMENTS; k++) {
-            void *h[] = { s->h_coeffs[k], s->h_ics[k], s->h_tools[k], s->h_sbr[k] };
-            void *d[] = { s->d_coeffs[k], s->d_ics[k], s->d_tools[k], s->d_sbr[k] };
+            void *h[] = { s->h_coeffs[k], s->h_ics[k], s->h_tools[k], s->h_sbr[k], s->h_ps[k] };
+            void *d[] = { s->d_coeffs[k], s->d_ics[k], s->d_tools[k], s->d_sbr[k], s->d_ps[k] };
             for (void *x : h) if (x) (void)hipHostFree(x);
             for (void *x : d) if (x) (void)hipFree(x);
         }
@@ -224,6 +229,12 @@ extern "C" int heaac_layout_pipeline_create(HeaacLayoutPipeline **out, const Hea
         return HEAAC_ERR_ARG;
     for (int id = 0; id < 16; id++)
         if (layout->slot_of[HEAAC_ELEM_CCE][id]) return HEAAC_ERR_ARG;         // coupling elements: heaac_codec_decode
+    {
+        int outs = 0;
+        for (int k = 0; k < layout->n_elements; k++)
+            outs += aac->sbr == 1 && aac->ps != 0 && layout->elem[k].type == HEAAC_ELEM_SCE ? 2 : layout->elem[k].channels;
+        if (outs > HEAAC_MAX_PCM_PLANES) return HEAAC_ERR_ARG;
+    }
     HeaacLayoutPipeline *p = (HeaacLayoutPipeline *)calloc(1, sizeof(*p));
     if (!p) return HEAAC_ERR_NOMEM;
     p->aac = *aac;
@@ -240,15 +251,23 @@ extern "C" int heaac_layout_pipeline_create(HeaacLayoutPipeline **out, const Hea
     if (rc != HEAAC_OK) { free(p); return rc; }
     bool ok = hipStreamCreateWithFlags(&p->run, hipStreamNonBlocking) == hipSuccess;
     HeaacPredictorState *ps = NULL;
+    // explicit SBR with Parametric Stereo on (or left open, which decode_audio_specific_config reads as on,
+    // aacdec.c:476-477): every single channel element gives two channels (che_configure :203-206; codec_layout.hip)
+    const bool ps_sce = aac->sbr == 1 && aac->ps != 0;
     for (int k = 0; ok && k < p->ne; k++) {
         LpElem &e = p->e[k];
         e.channels = layout->elem[k].channels;
         e.cfg = p->he ? (e.channels == 2 ? HEAAC_CFG_HEV1 : HEAAC_CFG_HEV1_MONO)
                       : (e.channels == 2 ? HEAAC_CFG_LC_STEREO : HEAAC_CFG_LC_MONO);
+        e.out = e.channels;
+        if (ps_sce && layout->elem[k].type == HEAAC_ELEM_SCE) { e.cfg = HEAAC_CFG_HEV2; e.out = 2; }
+        e.first_out = k ? p->e[k - 1].first_out + p->e[k - 1].out : 0;
+        p->out_channels = e.first_out + e.out;
         e.words = e.cfg == HEAAC_CFG_HEV1 ? HEAAC_STATE_WORDS_HEV1 : e.cfg == HEAAC_CFG_HEV1_MONO ? HEAAC_STATE_WORDS_HEV1_MONO :
+                  e.cfg == HEAAC_CFG_HEV2 ? HEAAC_STATE_WORDS_HEV2 :
                   e.cfg == HEAAC_CFG_LC_STEREO ? HEAAC_STATE_WORDS_LC_STEREO : HEAAC_STATE_WORDS_LC_MONO;
         ok = lp_devmem((void **)&e.d_state, n * (size_t)e.words * 4) && hipMemset(e.d_state, 0, n * (size_t)e.words * 4) == hipSuccess &&
-             lp_devmem((void **)&e.d_f32, n * (size_t)e.channels * p->len * 4);
+             lp_devmem((void **)&e.d_f32, n * (size_t)e.out * p->len * 4);
         if (ok && p->he) {
             e.sst = (HeaacSbrStream *)malloc(n * heaac_sbr_stream_bytes());
             ok = e.sst != NULL;
@@ -274,9 +293,11 @@ extern "C" int heaac_layout_pipeline_create(HeaacLayoutPipeline **out, const Hea
             ok = lp_pinned((void **)&s->h_coeffs[k], nc * 4096) && lp_devmem((void **)&s->d_coeffs[k], nc * 4096) &&
                  lp_pinned((void **)&s->h_ics[k], nc * sizeof(HeaacIcs)) && lp_devmem((void **)&s->d_ics[k], nc * sizeof(HeaacIcs)) &&
                  lp_pinned((void **)&s->h_tools[k], n * sizeof(HeaacToolsFrame)) && lp_devmem((void **)&s->d_tools[k], n * sizeof(HeaacToolsFrame)) &&
-                 (!p->he || (lp_pinned((void **)&s->h_sbr[k], n * sizeof(HeaacSbrFrame)) && lp_devmem((void **)&s->d_sbr[k], n * sizeof(HeaacSbrFrame))));
+                 (!p->he || (lp_pinned((void **)&s->h_sbr[k], n * sizeof(HeaacSbrFrame)) && lp_devmem((void **)&s->d_sbr[k], n * sizeof(HeaacSbrFrame)))) &&
+                 (p->e[k].cfg != HEAAC_CFG_HEV2 ||
+                  (lp_pinned((void **)&s->h_ps[k], n * sizeof(HeaacPsFrame)) && lp_devmem((void **)&s->d_ps[k], n * sizeof(HeaacPsFrame))));
         }
-        const size_t pcm_bytes = n * (size_t)layout->channels * p->len * 2;
+        const size_t pcm_bytes = n * (size_t)p->out_channels * p->len * 2;
         ok = ok && lp_pinned((void **)&s->h_pcm, pcm_bytes) && lp_devmem((void **)&s->d_pcm, pcm_bytes) &&
              (s->failed = (unsigned char *)calloc(n, 1)) != NULL && (s->seq = (unsigned char *)calloc(n * p->ne, 1)) != NULL &&
              hipEventCreate(&s->done) == hipSuccess;
@@ -407,6 +428,7 @@ extern "C" int heaac_layout_pipeline_submit(HeaacLayoutPipeline *p, const uint8_
         LP_HIP(hipMemcpyAsync(s->d_ics[k], s->h_ics[k], nc * sizeof(HeaacIcs), hipMemcpyHostToDevice, p->run));
         LP_HIP(hipMemcpyAsync(s->d_tools[k], s->h_tools[k], n * sizeof(HeaacToolsFrame), hipMemcpyHostToDevice, p->run));
         if (p->he) LP_HIP(hipMemcpyAsync(s->d_sbr[k], s->h_sbr[k], n * sizeof(HeaacSbrFrame), hipMemcpyHostToDevice, p->run));
+        if (s->d_ps[k]) LP_HIP(hipMemcpyAsync(s->d_ps[k], s->h_ps[k], n * sizeof(HeaacPsFrame), hipMemcpyHostToDevice, p->run));
     }
     if (n_failed) {
         size_t row = 4;
@@ -438,18 +460,18 @@ extern "C" int heaac_layout_pipeline_submit(HeaacLayoutPipeline *p, const uint8_
         const LpElem &e = p->e[k];
         const int rc = p->he
             ? heaac_he_decode_batch_ex(p->dev, e.cfg, p->downsampled ? HEAAC_HE_DOWNSAMPLED : 0, s->d_coeffs[k], s->d_ics[k], s->d_sbr[k],
-                                       p->d_hdr, LP_MAX_HDRS, NULL, e.d_state, e.d_state, e.d_f32, HEAAC_PCM_F32_PLANAR, n, (void *)p->run)
+                                       p->d_hdr, LP_MAX_HDRS, s->d_ps[k], e.d_state, e.d_state, e.d_f32, HEAAC_PCM_F32_PLANAR, n, (void *)p->run)
             : heaac_lc_decode_batch(p->dev, e.channels, s->d_coeffs[k], s->d_ics[k], e.d_state, e.d_state, e.d_f32,
                                     HEAAC_PCM_F32_PLANAR, n, (void *)p->run);
         if (rc != HEAAC_OK) return rc;
-        for (int c = 0; c < e.channels; c++) {
-            planes[p->layout.elem[k].first_channel + c].d_base = e.d_f32 + (size_t)c * p->len;
-            planes[p->layout.elem[k].first_channel + c].frame_stride = (size_t)e.channels * p->len;
+        for (int c = 0; c < e.out; c++) {
+            planes[e.first_out + c].d_base = e.d_f32 + (size_t)c * p->len;
+            planes[e.first_out + c].frame_stride = (size_t)e.out * p->len;
         }
     }
-    int rc = heaac_pcm_interleave_batch(p->dev, p->layout.channels, planes, p->len, HEAAC_PCM_S16_INTERLEAVED, s->d_pcm, n, (void *)p->run);
+    int rc = heaac_pcm_interleave_batch(p->dev, p->out_channels, planes, p->len, HEAAC_PCM_S16_INTERLEAVED, s->d_pcm, n, (void *)p->run);
     if (rc != HEAAC_OK) return rc;
-    const size_t pcm_row = (size_t)p->layout.channels * p->len;
+    const size_t pcm_row = (size_t)p->out_channels * p->len;
     if (n_failed) {
         rc = lp_park(p, s, n_failed, 1);
         if (rc != HEAAC_OK) return rc;
@@ -462,6 +484,8 @@ extern "C" int heaac_layout_pipeline_submit(HeaacLayoutPipeline *p, const uint8_
     p->submitted++;
     return HEAAC_OK;
 }
+
+extern "C" int heaac_layout_pipeline_channels(const HeaacLayoutPipeline *p) { return p ? p->out_channels : 0; }
 
 extern "C" int heaac_layout_pipeline_collect(HeaacLayoutPipeline *p, const int16_t **pcm)
 {

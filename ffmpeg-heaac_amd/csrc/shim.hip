@@ -388,8 +388,8 @@ static int dec_init_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p)
         p->have_layout = p->m4ac.chan_config != 1 && p->m4ac.chan_config != 2;
         // A program-config layout with explicitly signalled SBR leaves ps = -1 (no channel count to rule it out,
         // mpeg4audio.c:137-139), which decode_audio_specific_config turns into ps = 1 (:476-477): the reference then gives
-        // every SCE of the layout a second, Parametric Stereo output channel (che_configure, :203-206).  Not decoded here.
-        if (p->have_layout && p->m4ac.sbr == 1 && p->m4ac.ps == -1) return -1;
+        // every SCE of the layout a second, Parametric Stereo output channel (che_configure, :203-206; codec_layout.hip).
+        if (p->have_layout && p->m4ac.sbr == 1 && p->m4ac.ps == -1) p->m4ac.ps = 1;
         if (p->m4ac.sbr == 1 && heaac_sbr_output_mode(&p->m4ac) < 0) return -1;
         p->have_m4ac = 1;
     }
@@ -422,7 +422,7 @@ static int dec_init_bitstream(HeaacCodecContext *avctx, HeaacDecoderPriv *p)
         if (!(p->lay = heaac_layout_dec_create(p->dev, &p->m4ac, &p->layout))) return -1;
         // tentative (output_configure with OC_GLOBAL_HDR); the first access unit settles implicit SBR
         const int doubled = p->m4ac.sbr == 1 && heaac_sbr_output_mode(&p->m4ac) == 0;
-        avctx->channels = p->layout.channels;
+        avctx->channels = heaac_layout_dec_channels(p->lay);
         avctx->channel_layout = p->layout.channel_layout;
         avctx->frame_size = doubled ? 2048 : 1024;
         avctx->sample_rate = doubled ? 2 * p->m4ac.sample_rate : p->m4ac.sample_rate;

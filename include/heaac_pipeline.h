@@ -69,17 +69,25 @@ void heaac_pipeline_timing(const HeaacPipeline *p, float ms[4]);
  * heaac_codec_decode does for one such stream (csrc/codec_layout.hip), which is what the tests compare it with.
  *   aac->sbr: 0 (AAC-LC / Main: 1024 samples per channel and tick) or 1 (explicit SBR per element; 2048, or 1024 for
  *             downsampled SBR).  Implicit signalling (-1) is settled per stream by its first access unit: HEAAC_ERR_ARG.
+ *   aac->ps:  with aac->sbr == 1, anything but 0 gives every SINGLE CHANNEL element of the layout a second, Parametric
+ *             Stereo output channel directly behind its first, as the reference does for a program-config stream with
+ *             explicitly signalled SBR (ps = -1 becomes 1, aacdec.c:476-477; che_configure :203-206; ff_sbr_apply
+ *             copies the left channel until PS data arrives, aacsbr.c:1751-1758).  heaac_asc_layout leaves ps = 0 for
+ *             the channel configurations 3 ... 7 (mpeg4audio.c:137-139).  heaac_layout_pipeline_channels() says how
+ *             many channels a tick's PCM has.
  *   layout:   without coupling channel elements (HEAAC_ERR_ARG otherwise: one heaac_codec_decode context per stream).
  * The streams must emit their elements in one bitstream order (the noise generator runs through them in that order;
  * the first good access unit sets it).  A stream whose unit does not parse, leaves an element out or deviates from
  * the order (status HEAAC_PARSE_ERR_UNSUPPORTED) gets silence for the tick and keeps its decoder state.
- * Two ticks may be in flight.  PCM: [n_streams][len][layout->channels] int16, pinned, valid until two more submits. */
+ * Two ticks may be in flight.  PCM: [n_streams][len][heaac_layout_pipeline_channels()] int16, pinned, valid until two
+ * more submits. */
 typedef struct HeaacLayoutPipeline HeaacLayoutPipeline;
 int  heaac_layout_pipeline_create(HeaacLayoutPipeline **out, const HeaacAacConfig *aac, const HeaacAacLayout *layout,
                                   size_t n_streams, int threads);
 void heaac_layout_pipeline_destroy(HeaacLayoutPipeline *p);
 int  heaac_layout_pipeline_submit(HeaacLayoutPipeline *p, const uint8_t *const *au, const int *size, int *status);
 int  heaac_layout_pipeline_collect(HeaacLayoutPipeline *p, const int16_t **pcm);
+int  heaac_layout_pipeline_channels(const HeaacLayoutPipeline *p);   /* layout->channels + one per SCE with Parametric Stereo */
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,11 @@ MODES = {
     "he_5_0_downsampled": (5, [(SCE, 0), (CPE, 0), (CPE, 1)], True, "asc_downsampled"),   # extension rate = core rate
     "lc_pce_asc": (0, [(CPE, 1), (LFE, 2), (SCE, 0), (CPE, 0)], False, "asc"),
     "lc_pce_adts": (0, [(SCE, 0), (CPE, 0), (CPE, 1), (LFE, 0)], False, "adts"),
+    # a program config element + explicitly signalled SBR: ps = -1 -> 1 (aacdec.c:476-477) and every SCE of the
+    # layout gets a second, Parametric Stereo output channel (che_configure :203-206)
+    "he_pce_ps_3_0": (0, [(SCE, 0), (CPE, 0)], True, "asc"),
+    "he_pce_ps_mono": (0, [(SCE, 0)], True, "asc"),
+    "he_pce_ps_5_1_downsampled": (0, [(SCE, 0), (CPE, 0), (CPE, 1), (LFE, 0)], True, "asc_downsampled"),
 }
 
 
@@ -90,7 +95,8 @@ def test_codec_decodes_multichannel_streams(pkg, oracle, dev, mode):
     """aac_decode_frame for layouts with several output elements, through heaac_codec_decode on the reference's own
     AVCodecContext / AVPacket records: 3.0, 5.0, 5.1, 7.1, a program config element in the extradata and one at the
     head of the first ADTS frame, AAC-Main prediction, explicit and implicit SBR per element, downsampled SBR (1024
-    samples per frame at the core rate, aacsbr.c:1719).  The checker parses the
+    samples per frame at the core rate, aacsbr.c:1719), Parametric Stereo on the single channel elements of a
+    program-config layout with explicit SBR (two output channels each).  The checker parses the
     same units with the layout parser (pinned by tests/test_parse_layout.py), runs the ORACLE's spectral tools through
     the elements in bitstream order (one noise generator), the oracle's decode per element on its own state, and
     ff_float_to_int16_interleave_c over the planes in layout order."""
@@ -125,18 +131,24 @@ def test_codec_decodes_multichannel_streams(pkg, oracle, dev, mode):
         r, layout, _ = pkg.aac_layout_from_pce(bw.bytes(), 0)
     assert r == 0
     ne, nch = int(layout[0]["n_elements"]), int(layout[0]["channels"])
+    ps_sce = he and cc == 0 and asc is not None
+    slot_out = [2 if ps_sce and int(layout[0]["elem"][e]["type"]) == SCE else int(layout[0]["elem"][e]["channels"]) for e in range(ne)]
+    first_out = [sum(slot_out[:e]) for e in range(ne)]
+    nch = sum(slot_out)
     if asc is not None:
         assert ctx.channels == nch and ctx.channel_layout == int(layout[0]["channel_layout"])
     st = np.zeros(pkg.MAX_ELEMENTS, pkg.AAC_STREAM_DT)
     length = 2048 if he and not down else 1024
     slot_ch = [int(layout[0]["elem"][e]["channels"]) for e in range(ne)]
-    state = [np.zeros((1, pkg.STATE_WORDS[(pkg.CFG_HEV1 if c == 2 else pkg.CFG_HEV1_MONO) if he else
-                                          (pkg.CFG_LC_STEREO if c == 2 else pkg.CFG_LC_MONO)]), np.float32) for c in slot_ch]
+    he_cfg = [pkg.CFG_HEV1 if c == 2 else (pkg.CFG_HEV2 if o == 2 else pkg.CFG_HEV1_MONO) for c, o in zip(slot_ch, slot_out)]
+    state = [np.zeros((1, pkg.STATE_WORDS[h if he else (pkg.CFG_LC_STEREO if c == 2 else pkg.CFG_LC_MONO)]), np.float32)
+             for c, h in zip(slot_ch, he_cfg)]
     pred = [np.tile(np.array([0, 0, 1, 1, 0, 0], np.float32), (1, c * pkg.MAX_PREDICTORS, 1)).reshape(1, -1) for c in slot_ch]
     ref_rng = np.full(1, 0x1f2e3d4c, np.int32)
     tab = pkg.SbrHeaderTable(64)
     sst = pkg.sbr_streams(ne)
-    writers = {k: SW.SbrStreamWriter(pkg, 2 if t == CPE else 1) for k, (t, _) in enumerate(elems)}
+    writers = {k: SW.SbrStreamWriter(pkg, 2 if t == CPE else 1, ps=ps_sce and t == SCE) for k, (t, _) in enumerate(elems)}
+    ps_frames = 0
     # an LFE with SBR payloads of its own (mode he_5_1, frames 1 and 3): the reference's SBR reader takes their headers
     # and refuses the data (aacsbr.c:996-1000)
     lfe_payload = lambda t: mode == "he_5_1" and t in (1, 3)
@@ -191,8 +203,10 @@ def test_codec_decodes_multichannel_streams(pkg, oracle, dev, mode):
             ics = np.ascontiguousarray(p["ics"][e:e + 1, :c])
             if he:
                 ei = p["elem"][e]
+                with_ps = he_cfg[e] == pkg.CFG_HEV2
+                ps_rec = None
                 if int(ei["sbr_payload_bit"]) >= 0:
-                    rr, sbr, _, _ = pkg.sbr_parse_payload(sst[e], tab, 24000, pkt_bytes, c, False, bit=int(ei["sbr_payload_bit"]),
+                    rr, sbr, ps_rec, _ = pkg.sbr_parse_payload(sst[e], tab, 24000, pkt_bytes, c, with_ps, bit=int(ei["sbr_payload_bit"]),
                                                           cnt=int(ei["sbr_payload_bytes"]), misplaced=bool(ei["sbr_misplaced"]))
                     assert rr == (-1 if ei["sbr_misplaced"] else 0)
                     assert bool(ei["sbr_misplaced"]) == (int(layout[0]["elem"][e]["type"]) == LFE)
@@ -202,16 +216,18 @@ def test_codec_decodes_multichannel_streams(pkg, oracle, dev, mode):
                 else:
                     sbr = pkg.sbr_no_payload(sst[e], c)              # an LFE without a payload ("pure upsampling")
                     assert int(layout[0]["elem"][e]["type"]) == LFE
-                pcm, state[e] = oracle.he_decode_batch(pkg.CFG_HEV1 if c == 2 else pkg.CFG_HEV1_MONO, spec[e], ics, sbr,
-                                                       tab.headers(), None, state[e], oracle.PCM_F32, downsampled=down)
+                ps_frames += int(with_ps and int(ps_rec["start"][0]) == 1)
+                pcm, state[e] = oracle.he_decode_batch(he_cfg[e], spec[e], ics, sbr, tab.headers(), ps_rec if with_ps else None,
+                                                       state[e], oracle.PCM_F32, downsampled=down)
             else:
                 pcm, state[e] = oracle.lc_decode_batch(c, spec[e], ics, state[e], oracle.PCM_F32)
-            for j in range(c):
-                planes[int(layout[0]["elem"][e]["first_channel"]) + j] = pcm[0, j]
+            for j in range(slot_out[e] if he else c):
+                planes[first_out[e] + j] = pcm[0, j]
         want = oracle.float_to_int16_interleave(planes)
         assert np.array_equal(got, want), ("frame %d" % t, np.argwhere(got != want)[:4])
         loud = max(loud, int(np.abs(got.astype(int)).max()))
     assert loud > 50 and lfe_headers == (2 if mode == "he_5_1" else 0)
+    assert (ps_frames > 0) == ps_sce
     # an access unit that leaves an element out is refused (the reference would transform stale buffers)
     au, _ = TL.build(rng, si, aot, elems[:-1], extras=False)
     pkt_bytes = _adts(au, aot, si, cc) if how == "adts" else au

@@ -24,7 +24,8 @@ def _stream_units(pkg, rng, mode, ticks):
     cc, elems, he, how = LG.MODES[mode]
     aot = 1 if mode.startswith("main") else 2
     si = 6 if he else 3
-    writers = {k: SW.SbrStreamWriter(pkg, 2 if t == CPE else 1) for k, (t, _) in enumerate(elems)}
+    ps_sce = he and cc == 0                     # program config element + explicit SBR: Parametric Stereo on every SCE
+    writers = {k: SW.SbrStreamWriter(pkg, 2 if t == CPE else 1, ps=ps_sce and t == SCE) for k, (t, _) in enumerate(elems)}
     units = []
     for t in range(ticks):
         payloads = None
@@ -47,7 +48,7 @@ def _stream_units(pkg, rng, mode, ticks):
     return units, aot, si, cc, he
 
 
-@pytest.mark.parametrize("mode", ["lc_5_1", "main_5_0", "he_5_1"])
+@pytest.mark.parametrize("mode", ["lc_5_1", "main_5_0", "he_5_1", "he_pce_ps_3_0", "he_pce_ps_5_1_downsampled"])
 def test_layout_pipeline_equals_one_codec_context_per_stream(pkg, dev, mode):
     import test_parse as TP
     from test_shim_gpu import HeaacCodecContext, HeaacPacket
@@ -56,14 +57,23 @@ def test_layout_pipeline_equals_one_codec_context_per_stream(pkg, dev, mode):
     rng = np.random.default_rng(sum(map(ord, mode)) + 9)
     streams = [_stream_units(pkg, rng, mode, ticks) for _ in range(n)]
     _, aot, si, cc, he = streams[0]
-    asc = LG._asc(aot, si, cc, he=he)
+    pce = None
+    if cc == 0:
+        import test_parse_layout as TL
+        elems = LG.MODES[mode][1]
+        front = [(int(t == CPE), g) for t, g in elems if t in (SCE, CPE) and not (t == CPE and g == 1)]
+        pce = lambda bw: TL.write_pce_body(bw, np.random.default_rng(1), front, [], [(1, 1)] if (CPE, 1) in elems else [],
+                                           [g for t, g in elems if t == LFE])
+    down = LG.MODES[mode][3] == "asc_downsampled"
+    asc = LG._asc(aot, si, cc, he=he, pce=pce, ext_si=si if down else None)
     r, m4, layout = pkg.asc_layout(asc)
     assert r == 0
     if not he:
         assert m4.sbr == -1          # a plain AAC-LC configuration leaves implicit SBR open; these streams carry none
         m4.sbr = 0
-    nch = int(layout[0]["channels"])
-    length = 2048 if he else 1024
+    # a single channel element with Parametric Stereo gives two channels (aacdec.c:203-206)
+    nch = int(layout[0]["channels"]) + (sum(t == SCE for t, _ in LG.MODES[mode][1]) if he and cc == 0 else 0)
+    length = 2048 if he and not down else 1024
     # one damaged unit: its stream gets silence for that tick and goes on as if it had never seen it
     bad_tick, bad = 2, 4
     units = [[streams[i][0][t] for i in range(n)] for t in range(ticks)]
@@ -90,6 +100,7 @@ def test_layout_pipeline_equals_one_codec_context_per_stream(pkg, dev, mode):
         assert lib.heaac_codec_close(C.byref(ctx)) == 0
 
     pl = pkg.LayoutPipeline(m4, layout, n, threads=3)
+    assert pl.ch == nch
     got = []
     for t in range(ticks):
         st = pl.submit(fed[t])
