@@ -1212,30 +1212,32 @@ int heaac_aac_parse_frame_layout(const HeaacAacConfig *cfg, HeaacAacLayout *layo
     return heaac_aac_parse_frame_layout_ex(cfg, layout, st, au, size, coeffs, ics, tools, elem, NULL, info);
 }
 
-int heaac_aac_parse_frame_layout_ex(const HeaacAacConfig *cfg, HeaacAacLayout *layout, HeaacAacStream *st,
-                                    const uint8_t *au, int size,
-                                    float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
-                                    HeaacAacElementInfo *elem, const HeaacCceOut *cce, HeaacAacFrameInfo *info)
-{
-    if (!cfg || !layout || !st || !au || size <= 0 || !coeffs || !ics || !tools || !elem ||
-        cfg->sampling_index < 0 || cfg->sampling_index > 12 ||
-        layout->n_elements < 1 || layout->n_elements > HEAAC_MAX_ELEMENTS ||
-        (cce && (!cce->cce || !cce->coeffs || !cce->ics || !cce->tools)))
-        return HEAAC_PARSE_ERR_ARG;
-    pthread_once(&g_once, tables_init);
-    if (g_tables_bad) return HEAAC_PARSE_ERR_ARG;
+/* What the walk over a layout's access unit leaves for the caller to judge a refusal by (unit_refused above, per
+ * element): the window histories in work, the progress of every element that was completed, of the one the refusal
+ * stands in, and of the loop around them. */
+typedef struct {
     Bits b;
-    bits_init(&b, au, size);
-    if (peek(&b, 12) == 0xfff) {
+    WinInfo w[HEAAC_MAX_ELEMENTS][2];
+    Progress done[HEAAC_MAX_ELEMENTS], at, loop;
+    int at_slot, n_cce;
+} LayoutWalk;
+
+static int layout_walk(const HeaacAacConfig *cfg, HeaacAacLayout *layout, HeaacAacStream *st, const uint8_t *au, int size,
+                       float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools, HeaacAacElementInfo *elem,
+                       const HeaacCceOut *cce, HeaacAacFrameInfo *info, LayoutWalk *lw)
+{
+    Bits *b = &lw->b;
+    bits_init(b, au, size);
+    if (peek(b, 12) == 0xfff) {
         HeaacAdtsHeader h;
         const int hs = heaac_adts_parse_header(&h, au, size);
         if (hs < 0) return HEAAC_PARSE_ERR_DATA;
         if (h.num_aac_frames != 1) return HEAAC_PARSE_ERR_UNSUPPORTED;
         if (h.sampling_index != cfg->sampling_index || h.object_type != cfg->object_type) return HEAAC_PARSE_ERR_DATA;
-        b.pos = hs * 8;
+        b->pos = hs * 8;
     }
     const int ne = layout->n_elements;
-    WinInfo w[HEAAC_MAX_ELEMENTS][2];
+    WinInfo (*w)[2] = lw->w;
     for (int e = 0; e < ne; e++)
         for (int c = 0; c < 2; c++) {
             w[e][c].window_sequence[0] = st[e].window_sequence[c];
@@ -1258,30 +1260,33 @@ int heaac_aac_parse_frame_layout_ex(const HeaacAacConfig *cfg, HeaacAacLayout *l
         memset(cce->elem, 0, HEAAC_MAX_CCE * sizeof(*cce->elem));
         for (int k = 0; k < HEAAC_MAX_CCE; k++) cce->elem[k].sbr_payload_bit = -1;
     }
-    while ((type = (int)bits(&b, 3)) != TYPE_END) {
-        int tag = (int)bits(&b, 4);
+    while ((type = (int)bits(b, 3)) != TYPE_END) {
+        int tag = (int)bits(b, 4);
         int slot = -1;
         switch (type) {
         case TYPE_SCE:
         case TYPE_CPE:
         case TYPE_LFE: {
             slot = layout_find(layout, seen, type, &tag);
-            if (slot < 0) return HEAAC_PARSE_ERR_DATA;                 /* "channel element %d.%d is not allocated" */
+            if (slot < 0) return REF_FAIL(&lw->loop, HEAAC_PARSE_ERR_DATA);    /* "channel element %d.%d is not allocated" */
             if (slot >= ne) return HEAAC_PARSE_ERR_ARG;                /* a layout record not made by the layout functions */
             /* the element decodes as what the bitstream says it is; a pair needs a pair's slot */
             if ((type == TYPE_CPE) != (layout->elem[slot].channels == 2)) return HEAAC_PARSE_ERR_DATA;
             HeaacToolsFrame *t = &tools[slot];
             memset(t, 0, sizeof(*t));
             float *co = coeffs + (size_t)slot * 2048;
-            Progress pg;                               /* refusals are not followed up in the layouts (heaac_parse.h) */
-            memset(&pg, 0, sizeof(pg));
-            if (type == TYPE_CPE) r = read_cpe(cfg, &b, t, w[slot], co, &pg);
-            else r = read_ics(cfg, &b, 0, &t->ch[0], &w[slot][0], co, &pg, 0);
-            if (r < 0) return r;
-            elem[slot].present = 1;
             elem[slot].type = (uint8_t)type;
             elem[slot].tag = (uint8_t)tag;
-            elem[slot].seq = (uint8_t)n_seen++;
+            elem[slot].seq = (uint8_t)n_seen;
+            lw->at_slot = slot;                        /* the element a refusal from here on stands in */
+            memset(&lw->at, 0, sizeof(lw->at));
+            if (type == TYPE_CPE) r = read_cpe(cfg, b, t, w[slot], co, &lw->at);
+            else r = read_ics(cfg, b, 0, &t->ch[0], &w[slot][0], co, &lw->at, 0);
+            if (r < 0) return r;
+            lw->done[slot] = lw->at;
+            lw->at_slot = -1;
+            elem[slot].present = 1;
+            n_seen++;
             break;
         }
         case TYPE_CCE: {
@@ -1290,16 +1295,17 @@ int heaac_aac_parse_frame_layout_ex(const HeaacAacConfig *cfg, HeaacAacLayout *l
             if (tag == 16) return HEAAC_PARSE_ERR_DATA;
             seen[TYPE_CCE][tag] = 1;
             const int k = layout->tag_map[TYPE_CCE][tag] - 1;
-            if (k < 0) return HEAAC_PARSE_ERR_DATA;   /* "channel element 2.%d is not allocated" */
+            if (k < 0) return REF_FAIL(&lw->loop, HEAAC_PARSE_ERR_DATA);       /* "channel element 2.%d is not allocated" */
             if (!cce || k >= HEAAC_MAX_CCE) return HEAAC_PARSE_ERR_UNSUPPORTED;
             wc[k].window_sequence[0] = st[0].cce_window_sequence[tag];
             wc[k].use_kb_window[0] = st[0].cce_use_kb_window[tag];
             wc[k].window_sequence[1] = wc[k].use_kb_window[1] = 0;
             memset(&cce->tools[k], 0, sizeof(HeaacToolsFrame));
-            r = read_cce(cfg, &b, tag, &cbase[k], &lists[k], &cce->tools[k].ch[0], &wc[k], cce->coeffs + k * 1024);
+            r = read_cce(cfg, b, tag, &cbase[k], &lists[k], &cce->tools[k].ch[0], &wc[k], cce->coeffs + k * 1024);
             if (r < 0) return r;
             cbase[k].outputs_before = (uint8_t)n_seen;
             cbase[k].seq = (uint8_t)n_cce++;
+            lw->n_cce = n_cce;
             last_cce = k;
             if (cce->elem) {
                 cce->elem[k].present = 1;
@@ -1310,17 +1316,17 @@ int heaac_aac_parse_frame_layout_ex(const HeaacAacConfig *cfg, HeaacAacLayout *l
             break;
         }
         case TYPE_DSE:
-            if ((r = skip_dse(&b)) < 0) return r;
+            if ((r = skip_dse(b)) < 0) return r;
             break;
         case TYPE_PCE:
-            if ((r = skip_pce(&b)) < 0) return r;
+            if ((r = skip_pce(b)) < 0) return r;
             break;
         case TYPE_FIL: {
             int cnt = tag;
-            if (cnt == 15) cnt += (int)bits(&b, 8) - 1;
-            if (bits_left(&b) < 8 * cnt) return HEAAC_PARSE_ERR_OVERREAD;
+            if (cnt == 15) cnt += (int)bits(b, 8) - 1;
+            if (bits_left(b) < 8 * cnt) return REF_OVERREAD(&lw->loop);              /* :2053-2056 */
             int at, bytes = 0, crc = 0;
-            read_fil(&b, cnt, &at, &bytes, &crc);
+            read_fil(b, cnt, &at, &bytes, &crc);
             if (at >= 0) {
                 /* decode_extension_payload (:1650-1690) hands the payload to the channel element last seen, and to its
                  * SBR reader the type of the element directly in front (:2059): anything but that element itself and
@@ -1348,8 +1354,8 @@ int heaac_aac_parse_frame_layout_ex(const HeaacAacConfig *cfg, HeaacAacLayout *l
         if (slot >= 0) prev_slot = slot;
         if (type < TYPE_DSE && type != TYPE_CCE) last_cce = -1;
         prev_type = type;
-        if (b.over) return HEAAC_PARSE_ERR_OVERREAD;
-        if (bits_left(&b) < 3) return HEAAC_PARSE_ERR_OVERREAD;
+        if (b->over) return HEAAC_PARSE_ERR_OVERREAD;
+        if (bits_left(b) < 3) return REF_OVERREAD(&lw->loop);                         /* :2072-2075 */
     }
     if (!n_seen) return HEAAC_PARSE_ERR_DATA;
     /* every coupling element against every output element: apply_channel_coupling compares the target list with the
@@ -1387,13 +1393,64 @@ int heaac_aac_parse_frame_layout_ex(const HeaacAacConfig *cfg, HeaacAacLayout *l
     if (info) {
         memset(info, 0, sizeof(*info));
         info->channels = layout->channels;
-        info->bits_consumed = b.pos;
+        info->bits_consumed = b->pos;
         info->sbr_payload_bit = -1;
         info->n_cce = n_cce;
     }
     return HEAAC_PARSE_OK;
 }
 
+
+
+int heaac_aac_parse_frame_layout_ex(const HeaacAacConfig *cfg, HeaacAacLayout *layout, HeaacAacStream *st,
+                                    const uint8_t *au, int size,
+                                    float *coeffs, HeaacIcs *ics, HeaacToolsFrame *tools,
+                                    HeaacAacElementInfo *elem, const HeaacCceOut *cce, HeaacAacFrameInfo *info)
+{
+    if (!cfg || !layout || !st || !au || size <= 0 || !coeffs || !ics || !tools || !elem ||
+        cfg->sampling_index < 0 || cfg->sampling_index > 12 ||
+        layout->n_elements < 1 || layout->n_elements > HEAAC_MAX_ELEMENTS ||
+        (cce && (!cce->cce || !cce->coeffs || !cce->ics || !cce->tools)))
+        return HEAAC_PARSE_ERR_ARG;
+    pthread_once(&g_once, tables_init);
+    if (g_tables_bad) return HEAAC_PARSE_ERR_ARG;
+    LayoutWalk lw;
+    memset(&lw, 0, sizeof(lw));
+    lw.at_slot = -1;
+    const int r = layout_walk(cfg, layout, st, au, size, coeffs, ics, tools, elem, cce, info, &lw);
+    if (r >= 0) return r;
+    /* Refused.  As for a one-element stream (unit_refused): where the refusal is the reference's own and no coupling
+     * element has been read, the elements completed before it keep what their decoders did -- window history moved,
+     * noise drawn, predictors stepped: their records stand, `present` and `seq` say which and in which order -- and
+     * the element the refusal stands in is rewritten into records that do as much as its decoder had done. */
+    HeaacAacFrameInfo fi = { 0, 0, -1, 0, 0, 0, 0, 0, 0 };
+    const Progress *why = lw.at_slot >= 0 ? &lw.at : &lw.loop;
+    if (why->as_reference && (!lw.b.over || why->ref_overread) && !lw.n_cce) {
+        fi.refused = HEAAC_REFUSED_AS_REFERENCE;
+        int work = 0;
+        const int main_profile = cfg->object_type == HEAAC_AOT_AAC_MAIN;
+        for (int e = 0; e < layout->n_elements; e++) {
+            if (!elem[e].present) continue;
+            for (int c = 0; c < layout->elem[e].channels; c++) {
+                st[e].window_sequence[c] = lw.w[e][c].window_sequence[0];
+                st[e].use_kb_window[c] = lw.w[e][c].use_kb_window[0];
+                work |= main_profile || noise_draws(&tools[e].ch[c], 128);
+            }
+        }
+        if (lw.at_slot >= 0) {
+            const int e = lw.at_slot;
+            HeaacAacFrameInfo part;
+            unit_refused(cfg, &st[e], &lw.b, lw.w[e], &lw.at, 0, 2, coeffs + (size_t)e * 2048, &tools[e], &part);
+            if (part.refused & HEAAC_REFUSED_RUN_TOOLS) {
+                elem[e].present = 1;                   /* (type, tag and seq were set when the element began) */
+                work = 1;
+            }
+        }
+        if (work) fi.refused |= HEAAC_REFUSED_RUN_TOOLS;
+    }
+    if (info) *info = fi;
+    return r;
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* batch over streams                                                                            */

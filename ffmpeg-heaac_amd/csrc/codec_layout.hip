@@ -223,8 +223,29 @@ int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void
     HeaacCceOut co = { NULL, NULL, NULL, NULL, NULL };
     if (c) { co.cce = &c->h_cce[0][0]; co.coeffs = &c->h_coeffs[0][0]; co.ics = c->h_ics; co.tools = c->h_tools; co.elem = c->h_elem; }
     if (heaac_aac_parse_frame_layout_ex(&d->m4ac, &d->layout, st, buf, size, d->h_coeffs, &d->h_ics[0][0], d->h_tools,
-                                        d->h_elem, c ? &co : NULL, &fi) != HEAAC_PARSE_OK)
+                                        d->h_elem, c ? &co : NULL, &fi) != HEAAC_PARSE_OK) {
+        // No samples.  Where the refusal is the reference's own, what its element decoders had done by then stays
+        // done (heaac_parse.h, HEAAC_REFUSED_*): the window histories the parser has moved, and -- through the records
+        // it left for the elements marked present, in bitstream order -- the noise generator and the predictors.
+        if (fi.refused & HEAAC_REFUSED_AS_REFERENCE)
+            for (int i = 0; i < d->n; i++) d->e[i].ast = st[i];
+        if (fi.refused & HEAAC_REFUSED_RUN_TOOLS) {
+            const int main_profile = d->m4ac.object_type == HEAAC_AOT_AAC_MAIN;
+            for (int seq = 0; seq < d->n; seq++)
+                for (int i = 0; i < d->n; i++) {
+                    if (!d->h_elem[i].present || d->h_elem[i].seq != seq) continue;
+                    LayElem &e = d->e[i];
+                    HeaacPredictorState *pr = main_profile ? e.d_pred : NULL;
+                    if (hipMemcpy(e.d_coeffs, d->h_coeffs + (size_t)i * 2048, (size_t)e.channels * 4096, hipMemcpyHostToDevice) != hipSuccess ||
+                        hipMemcpy(e.d_tools, &d->h_tools[i], sizeof(HeaacToolsFrame), hipMemcpyHostToDevice) != hipSuccess ||
+                        heaac_spectral_tools_batch_ex(d->dev, e.channels, HEAAC_TOOLS_ALL, e.d_coeffs, e.d_tools, d->d_rng, d->d_rng,
+                                                      pr, pr, NULL, NULL, 0, 1, NULL) != HEAAC_OK)
+                        return -1;
+                }
+            (void)hipDeviceSynchronize();
+        }
         return -1;
+    }
     for (int i = 0; i < d->n; i++)
         if (!d->h_elem[i].present) return -1;
     // the coupling elements of this access unit: slot k of the layout's list, the same in every output slot's row

@@ -84,14 +84,17 @@ static inline HeaacSbrStream *sst_at(HeaacSbrStream *base, size_t i)
     return (HeaacSbrStream *)((char *)base + i * heaac_sbr_stream_bytes());
 }
 
-// neutral records of one stream: silence, no tools, no SBR payload (from a COPY of the SBR reader state)
-static void neutral(HeaacLayoutPipeline *p, LpSet *s, size_t i)
+// neutral records of one stream: silence, no tools, no SBR payload (from a COPY of the SBR reader state).
+// keep_tools: the tools records and spectra are already what a refused unit leaves for the spectral tools.
+static void neutral(HeaacLayoutPipeline *p, LpSet *s, size_t i, bool keep_tools = false)
 {
     for (int k = 0; k < p->ne; k++) {
         const int ch = p->e[k].channels;
-        memset(s->h_coeffs[k] + i * (size_t)ch * 1024, 0, (size_t)ch * 4096);
         memset(s->h_ics[k] + i * ch, 0, ch * sizeof(HeaacIcs));
-        memset(&s->h_tools[k][i], 0, sizeof(HeaacToolsFrame));
+        if (!keep_tools) {
+            memset(s->h_coeffs[k] + i * (size_t)ch * 1024, 0, (size_t)ch * 4096);
+            memset(&s->h_tools[k][i], 0, sizeof(HeaacToolsFrame));
+        }
         if (p->he) {
             void *tmp = alloca(heaac_sbr_stream_bytes());
             memcpy(tmp, sst_at(p->e[k].sst, i), heaac_sbr_stream_bytes());
@@ -124,7 +127,27 @@ static void lp_parse_slice(HeaacLayoutPipeline *p, int w)
         if (p->job_status) p->job_status[i] = r;
         s->failed[i] = (unsigned char)(r != HEAAC_PARSE_OK);
         if (r != HEAAC_PARSE_OK) {
-            neutral(p, s, i);
+            // Where the refusal is the reference's own, what its element decoders had done by then stays done
+            // (heaac_parse.h, HEAAC_REFUSED_*): the window histories the parser has moved, and -- through the records it
+            // left for the elements marked present -- the noise generator and the predictors (failed = 2: the tools
+            // run on them, submit() parks the DSP state rows only).
+            if (r < 0 && tc && (fi.refused & HEAAC_REFUSED_AS_REFERENCE))
+                for (int k = 0; k < ne; k++) p->ast[i * ne + k] = st[k];
+            if (r < 0 && tc && (fi.refused & HEAAC_REFUSED_RUN_TOOLS)) {
+                s->failed[i] = 2;
+                for (int k = 0; k < ne; k++) {
+                    const int ch = p->e[k].channels;
+                    s->seq[i * ne + k] = te[k].present ? te[k].seq : 0xff;
+                    if (te[k].present) {
+                        memcpy(s->h_coeffs[k] + i * (size_t)ch * 1024, tc + (size_t)k * 2048, (size_t)ch * 4096);
+                        s->h_tools[k][i] = tt[k];
+                    } else {
+                        memset(s->h_coeffs[k] + i * (size_t)ch * 1024, 0, (size_t)ch * 4096);
+                        memset(&s->h_tools[k][i], 0, sizeof(HeaacToolsFrame));
+                    }
+                }
+            }
+            neutral(p, s, i, s->failed[i] == 2);
             continue;
         }
         for (int k = 0; k < ne; k++) {
@@ -363,15 +386,16 @@ static int lp_park(HeaacLayoutPipeline *p, LpSet *s, size_t n_failed, int restor
             LP_HIP(restore ? hipMemcpyAsync(st, park + off, sb, hipMemcpyDeviceToDevice, p->run)
                            : hipMemcpyAsync(park + off, st, sb, hipMemcpyDeviceToDevice, p->run));
             off += sb;
-            if (e.d_pred) {
+            if (e.d_pred && s->failed[i] != 2) {
                 char *pr = (char *)e.d_pred + i * pb;
                 LP_HIP(restore ? hipMemcpyAsync(pr, park + off, pb, hipMemcpyDeviceToDevice, p->run)
                                : hipMemcpyAsync(park + off, pr, pb, hipMemcpyDeviceToDevice, p->run));
                 off += pb;
             }
         }
-        LP_HIP(restore ? hipMemcpyAsync(p->d_rng + i, park + off, 4, hipMemcpyDeviceToDevice, p->run)
-                       : hipMemcpyAsync(park + off, p->d_rng + i, 4, hipMemcpyDeviceToDevice, p->run));
+        if (s->failed[i] != 2)                         // (2: the tools' side of the stream moves on)
+            LP_HIP(restore ? hipMemcpyAsync(p->d_rng + i, park + off, 4, hipMemcpyDeviceToDevice, p->run)
+                           : hipMemcpyAsync(park + off, p->d_rng + i, 4, hipMemcpyDeviceToDevice, p->run));
         off += 4;
     }
     (void)n_failed;
@@ -400,6 +424,14 @@ extern "C" int heaac_layout_pipeline_submit(HeaacLayoutPipeline *p, const uint8_
     // the element order of the pipeline's streams: the first good unit sets it, a stream that deviates is dropped for the tick
     size_t n_failed = 0;
     for (size_t i = 0; i < n; i++) {
+        if (s->failed[i] == 2) {
+            // the elements a refused unit got through must stand where the pipeline's order has them: the generator
+            // runs through the elements in that order
+            bool same = p->have_order != 0;
+            for (int k = 0; same && k < ne; k++)
+                same = s->seq[i * ne + k] == 0xff || (s->seq[i * ne + k] < ne && p->order[s->seq[i * ne + k]] == k);
+            if (!same) { s->failed[i] = 1; neutral(p, s, i); }
+        }
         if (s->failed[i]) { n_failed++; continue; }
         if (!p->have_order) {
             for (int k = 0; k < ne; k++) p->order[s->seq[i * ne + k] < ne ? s->seq[i * ne + k] : 0] = (unsigned char)k;

@@ -145,11 +145,15 @@ typedef struct HeaacAacFrameInfo {
  * HEAAC_REFUSED_AS_REFERENCE: the refusal is one the reference makes at the same bit of the unit (a reserved value,
  * a range check, one of its three end-of-unit checks) and `st` now holds the window history its decoder is left
  * with.  Clear for the refusals that are this parser's alone -- a read past the end of the unit where the reference
- * reads on unchecked, element combinations it is not built for, any unit with a coupling element, the layout
- * parsers: `st` is then untouched, as if the unit had not been there.
+ * reads on unchecked, element combinations it is not built for, any unit with a coupling element: `st` is then
+ * untouched, as if the unit had not been there.
  * HEAAC_REFUSED_RUN_TOOLS (only with the former): `tools` and `coeffs` have been rewritten into records under which
  * heaac_spectral_tools_batch draws from the stream's noise generator and steps its predictors exactly as far as the
  * reference had; run it on them as for a good unit (both channels of a pair) and discard the coefficients.
+ * heaac_aac_parse_frame_layout(_ex) does the same per element: `st[e]` of every element the unit got through, and of
+ * the one the refusal stands in, holds the reference's window history; with HEAAC_REFUSED_RUN_TOOLS the elements
+ * marked `present` in `elem` (the completed ones with their own records, the refused one rewritten) are to go through
+ * the spectral tools in `seq` order on the stream's one noise generator.
  * The SBR / PS side of a refused unit is not followed up: an extension payload in front of the refusal, which the
  * reference has read by then, is not read here. */
 #define HEAAC_REFUSED_AS_REFERENCE 1

@@ -78,7 +78,9 @@ void heaac_pipeline_timing(const HeaacPipeline *p, float ms[4]);
  *   layout:   without coupling channel elements (HEAAC_ERR_ARG otherwise: one heaac_codec_decode context per stream).
  * The streams must emit their elements in one bitstream order (the noise generator runs through them in that order;
  * the first good access unit sets it).  A stream whose unit does not parse, leaves an element out or deviates from
- * the order (status HEAAC_PARSE_ERR_UNSUPPORTED) gets silence for the tick and keeps its decoder state.
+ * the order (status HEAAC_PARSE_ERR_UNSUPPORTED) gets silence for the tick and keeps its DSP state; window histories,
+ * noise generator and predictors are left as the reference's decoder leaves its own where the refusal is the
+ * reference's (as for heaac_pipeline_submit above).
  * Two ticks may be in flight.  PCM: [n_streams][len][heaac_layout_pipeline_channels()] int16, pinned, valid until two
  * more submits. */
 typedef struct HeaacLayoutPipeline HeaacLayoutPipeline;

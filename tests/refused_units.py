@@ -77,9 +77,11 @@ def _with_escape_at_the_end(rng, d):
     return 13                                       # the zero sits 13 bits from the end
 
 
-def sce_unit(rng, si, aot, kind):
+def sce_element(rng, si, aot, kind, tag=0, lfe=False):
+    """One single channel (or LFE) element: (bits as written with the damage, bits of the undamaged twin, model).
+    kind "good": no damage."""
     bw = W.BitWriter()
-    bw.put(0, 3); bw.put(0, 4)
+    bw.put(3 if lfe else 0, 3); bw.put(tag, 4)
     d = _channel(rng, si, aot, long_only=kind == "tns_order")
     flip = None
     if kind in ("esc_overflow", "ours_only"):
@@ -98,8 +100,7 @@ def sce_unit(rng, si, aot, kind):
         assert bw.bits[-flip] == 0 and all(bw.bits[-flip - 8:-flip])
         bw.bits[-flip] = 1
         model["draws"] = noise_lines(d)
-    elif kind == "fill_overread":
-        bw.put(6, 3); bw.put(15, 4); bw.put(200, 8)            # a fill element of 214 bytes that are not there (:2053-2056)
+    elif kind in ("fill_overread", "good"):
         model["draws"] = noise_lines(d)
         model["predicted"] = [0] if aot == 1 else []
     elif kind == "ours_only":
@@ -108,37 +109,62 @@ def sce_unit(rng, si, aot, kind):
     else:
         assert kind == "tns_order"
     gw = W.BitWriter()
-    gw.put(0, 3); gw.put(0, 4)
+    gw.put(3 if lfe else 0, 3); gw.put(tag, 4)
     W.put_ics(gw, good, si, aot, 0)
-    gw.put(7, 3)
-    bad = bw.bytes()
+    return bw.bits, gw.bits, model
+
+
+def _bytes(bits, pad=8):
+    bw = W.BitWriter()
+    bw.bits = list(bits)
+    return bw.bytes(pad=pad)
+
+
+FILL_OVERREAD = [1, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1]     # a fill element of 15 + 255 - 1 bytes that are not there (:2053-2056)
+END = [1, 1, 1]
+
+
+def sce_unit(rng, si, aot, kind):
+    bad, good, model = sce_element(rng, si, aot, kind)
+    if kind == "fill_overread":
+        bad = bad + FILL_OVERREAD
     if kind == "ours_only":
-        bad = bw.bytes(pad=0)[: max(4, len(bw.bits) // 8 - 3)]
-    return bad, gw.bytes(), model
+        # the unit ends 8 bits early, inside the 12 bits behind the escape prefix: at most 4 + 7 bits are left to read
+        return _bytes(bad[:-8], pad=0), _bytes(good + END), model
+    return _bytes(bad), _bytes(good + END), model
 
 
 def cpe_unit(rng, si, aot, kind):
+    bad, good, model = cpe_element(rng, si, aot, kind)
+    if kind == "fill_overread":
+        bad = bad + FILL_OVERREAD
+    return _bytes(bad), _bytes(good + END), model
+
+
+def cpe_element(rng, si, aot, kind, tag=0):
     bw, gw = W.BitWriter(), W.BitWriter()
     for w in (bw, gw):
-        w.put(1, 3); w.put(0, 4)
-    if kind in ("second_channel_reserved_bit", "fill_overread"):
+        w.put(1, 3); w.put(tag, 4)
+    if kind in ("second_channel_reserved_bit", "fill_overread", "good", "ours_only"):
         a, b = _channel(rng, si, aot), _channel(rng, si, aot)
+        if kind == "ours_only":
+            _with_escape_at_the_end(rng, b)
         for w in (bw, gw):
             w.put(0, 1)
             W.put_ics(w, a, si, aot, 0)
         at = len(bw.bits)
         for w in (bw, gw):
             W.put_ics(w, b, si, aot, 0)
-        gw.put(7, 3)
-        if kind == "fill_overread":
-            bw.put(6, 3); bw.put(15, 4); bw.put(255, 8)
+        if kind == "ours_only":
+            return bw.bits[:-8], gw.bits, dict(history=[None, None], draws=0, predicted=[])
+        if kind in ("fill_overread", "good"):
             model = dict(history=[(a["window_sequence"], a["window_shape"]), (b["window_sequence"], b["window_shape"])],
                          draws=noise_lines(a) + noise_lines(b), predicted=[0, 1] if aot == 1 else [])
         else:
             bw.bits[at + 8] = 1                                 # the second channel's ics_info: reserved bit
             model = dict(history=[(a["window_sequence"], a["window_shape"]), (0, 0)], draws=noise_lines(a),
                          predicted=[0] if aot == 1 else [])
-        return bw.bytes(), gw.bytes(), model
+        return bw.bits, gw.bits, model
     a = _channel(rng, si, aot)
     b = _channel(rng, si, aot, like=a)
     a["band_type"][a["band_type"] >= 14] = 0
@@ -153,6 +179,7 @@ def cpe_unit(rng, si, aot, kind):
         bw.put(0, 64)
         model = dict(history=both, draws=0, predicted=[])
     else:
+        assert kind == "common_window_esc_overflow"
         bw.put(0, 2)
         W.put_ics(bw, a, si, aot, 1)
         W.put_ics(bw, b, si, aot, 1)
@@ -162,5 +189,30 @@ def cpe_unit(rng, si, aot, kind):
         model = dict(history=both, draws=noise_lines(a) + noise_lines(b), predicted=[])
     W.put_ics(gw, a, si, aot, 1)
     W.put_ics(gw, b, si, aot, 1)
-    gw.put(7, 3)
-    return bw.bytes(), gw.bytes(), model
+    return bw.bits, gw.bits, model
+
+
+# ---- a 3.0 layout (channel configuration 3: SCE then CPE) ----
+KINDS_3_0 = ["pair_esc_overflow", "pair_second_channel_reserved_bit", "centre_tns_order", "fill_overread", "not_allocated", "ours_only"]
+
+
+def unit_3_0(rng, si, aot, kind):
+    """(damaged unit, undamaged twin, model): the model's history / predicted are per element [SCE, CPE]; an element
+    the decoder never reached is None."""
+    sce_kind = {"centre_tns_order": "tns_order"}.get(kind, "good")
+    cpe_kind = {"pair_esc_overflow": "common_window_esc_overflow", "pair_second_channel_reserved_bit": "second_channel_reserved_bit",
+                "ours_only": "ours_only"}.get(kind, "good")
+    sb, sg, sm = sce_element(rng, si, aot, sce_kind)
+    cb, cg, cm = cpe_element(rng, si, aot, cpe_kind)
+    twin = _bytes(sg + cg + END)
+    if kind == "centre_tns_order":
+        return _bytes(sb + cb + END), twin, dict(elements=[sm, None], draws=0)
+    if kind == "ours_only":
+        # the pair ends inside its spectrum: nothing of the unit counts, not even the centre element in front
+        return _bytes(sb + cb, pad=0), twin, dict(elements=[None, None], draws=0)
+    tail = []
+    if kind == "fill_overread":
+        tail = FILL_OVERREAD
+    elif kind == "not_allocated":
+        tail = [0, 1, 1, 0, 0, 0, 0]                            # an LFE: channel configuration 3 has none (:2011-2015)
+    return _bytes(sb + cb + tail), twin, dict(elements=[sm, cm], draws=sm["draws"] + cm["draws"])

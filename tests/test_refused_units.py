@@ -217,3 +217,165 @@ def test_the_codec_surface_carries_on_behind_a_refused_unit(pkg, oracle, dev, cp
             got = np.frombuffer(out, np.int16, 1024 * ch).reshape(1024, ch)
             assert np.array_equal(got, want[t][i]), (i, t)
         assert lib.heaac_codec_close(C.byref(ctx)) == 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# several output elements per unit (a 3.0 layout: centre SCE, then the front pair)
+# ------------------------------------------------------------------------------------------------------------------
+def _layout_3_0(pkg, aot):
+    cfg = TP._cfg(pkg, aot, SI, 3)
+    r, layout = pkg.aac_layout_default(3)
+    assert r == 0 and int(layout[0]["n_elements"]) == 2
+    # slot of the centre element and of the pair in the layout's (output) order
+    slot = {int(layout[0]["elem"][e]["channels"]): e for e in range(2)}
+    return cfg, layout, slot[1], slot[2]
+
+
+@pytest.mark.parametrize("aot", [2, 1])
+def test_the_layout_parser_leaves_every_element_where_the_reference_decoder_would_be(pkg, aot):
+    cfg, layout0, s_sce, s_cpe = _layout_3_0(pkg, aot)
+    rng = np.random.default_rng(311 + aot)
+    for kind in R.KINDS_3_0 * 4:
+        bad, twin, model = R.unit_3_0(rng, SI, aot, kind)
+        layout = layout0.copy()
+        st = np.zeros(pkg.MAX_ELEMENTS, pkg.AAC_STREAM_DT)
+        st["window_sequence"][:2] = (3, 1); st["use_kb_window"][:2] = (1, 1)
+        before = st.copy()
+        r, out = pkg.aac_parse_frame_layout(cfg, layout, st, bad)
+        info = out["info"][0]
+        assert r < 0 and info["channels"] == 0, kind
+        if kind == "ours_only":
+            assert info["refused"] == 0 and st.tobytes() == before.tobytes()
+            continue
+        assert info["refused"] & pkg.REFUSED_AS_REFERENCE, kind
+        draws = 0
+        for e, m, nch in ((s_sce, model["elements"][0], 1), (s_cpe, model["elements"][1], 2)):
+            for c in range(nch):
+                want = m["history"][c] if m is not None and m["history"][c] is not None else (int(before["window_sequence"][e, c]), int(before["use_kb_window"][e, c]))
+                assert (int(st["window_sequence"][e, c]), int(st["use_kb_window"][e, c])) == want, (kind, e, c)
+            if out["elem"][e]["present"]:
+                draws += sum(_record_draws(out["tools"][e]["ch"][c]) for c in range(nch))
+            else:
+                assert m is None or not (m["draws"] or m["predicted"]), kind
+        run = bool(info["refused"] & pkg.REFUSED_RUN_TOOLS)
+        assert run == bool(model["draws"] or any(m and m["predicted"] for m in model["elements"])), kind
+        if run:
+            assert draws == model["draws"], kind
+            # bitstream order: the centre element first
+            assert int(out["elem"][s_sce]["seq"]) == 0 and (not out["elem"][s_cpe]["present"] or int(out["elem"][s_cpe]["seq"]) == 1)
+
+
+def _expected_layout_run(pkg, oracle, cfg, layout0, slots, aot, ticks_good, bad_tick, models):
+    """The oracle over the good units of n 3.0 streams (tools through the elements in bitstream order on one
+    generator per stream, decode per element on its own state, float_to_int16_interleave over the planes in layout
+    order), the refused tick replaced per stream by its model as in _expected_run."""
+    n = len(ticks_good[0])
+    s_sce, s_cpe = slots
+    nch = {s_sce: 1, s_cpe: 2}
+    first = {e: int(layout0[0]["elem"][e]["first_channel"]) for e in (s_sce, s_cpe)}
+    layouts = [layout0.copy() for _ in range(n)]
+    st = [np.zeros(pkg.MAX_ELEMENTS, pkg.AAC_STREAM_DT) for _ in range(n)]
+    state = {e: np.zeros((n, 512 * nch[e]), np.float32) for e in nch}
+    pred = {e: np.tile(np.array([0, 0, 1, 1, 0, 0], np.float32), (n, nch[e], pkg.MAX_PREDICTORS, 1)) for e in nch}
+    rs = np.full(n, 0x1f2e3d4c, np.int32)
+    out = []
+    for t, aus in enumerate(ticks_good):
+        pcm_t = np.zeros((n, 1024, 3), np.int16)
+        for i in range(n):
+            before = st[i].copy()
+            r, p = pkg.aac_parse_frame_layout(cfg, layouts[i], st[i], aus[i])
+            assert r == 0
+            m = models.get(i) if t == bad_tick else None
+            rs_before = int(rs[i])
+            planes = [None] * 3
+            for e in (s_sce, s_cpe):                       # bitstream order of a 3.0 unit
+                c = nch[e]
+                tools = p["tools"][e:e + 1].copy()
+                if m is not None:
+                    em = m["elements"][0 if e == s_sce else 1]
+                    for k in range(2):
+                        if em is None or k not in em["predicted"]:
+                            tools["ch"][0, k] = np.zeros((), tools.dtype["ch"].base)
+                    tools["common_window"][0] = tools["ms_present"][0] = 0
+                    tools["ch"]["tns"]["present"][0] = 0
+                co = np.ascontiguousarray(p["coeffs"][e:e + 1, :c])
+                if aot == 1:
+                    spec, r1, pr = oracle.spectral_tools_batch(c, co, tools, rng=rs[i:i + 1], pred=pred[e][i:i + 1])
+                    pred[e][i:i + 1] = pr
+                else:
+                    spec, r1 = oracle.spectral_tools_batch(c, co, tools, rng=rs[i:i + 1])
+                rs[i] = r1[0]
+                if m is not None:
+                    continue
+                ics = np.ascontiguousarray(p["ics"][e:e + 1, :c])
+                pcm, state[e][i:i + 1] = oracle.lc_decode_batch(c, spec, ics, state[e][i:i + 1], oracle.PCM_F32)
+                for j in range(c):
+                    planes[first[e] + j] = pcm[0, j]
+            if m is not None:
+                st[i][:] = before
+                for e, em in ((s_sce, m["elements"][0]), (s_cpe, m["elements"][1])):
+                    for c, h in enumerate(em["history"] if em is not None else []):
+                        if h is not None:
+                            st[i]["window_sequence"][e, c], st[i]["use_kb_window"][e, c] = h
+                rs[i] = R.lcg(rs_before, m["draws"])
+            else:
+                pcm_t[i] = oracle.float_to_int16_interleave(planes)
+        out.append(pcm_t)
+    return out
+
+
+def _streams_3_0(pkg, aot, seed, ticks=5, bad_tick=2, rounds=2):
+    import test_parse_layout as TL
+    rng = np.random.default_rng(seed)
+    n = rounds * len(R.KINDS_3_0) + 2
+    good = [[TL.build(rng, SI, aot, [(0, 0), (1, 0)], extras=False)[0] for _ in range(n)] for _ in range(ticks)]
+    fed = [list(a) for a in good]
+    models = {}
+    for j, kind in enumerate(R.KINDS_3_0 * rounds):
+        bad, twin, model = R.unit_3_0(rng, SI, aot, kind)
+        fed[bad_tick][j + 1] = bad
+        good[bad_tick][j + 1] = twin
+        models[j + 1] = model
+    return good, fed, models, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aot", [2, 1])
+def test_layout_streams_carry_on_behind_a_refused_unit(pkg, oracle, dev, aot):
+    """3.0 streams through the layout pipeline and through one codec context each."""
+    from test_shim_gpu import HeaacCodecContext, HeaacPacket
+    lib = pkg.lib()
+    bad_tick = 2
+    cfg, layout, s_sce, s_cpe = _layout_3_0(pkg, aot)
+    cfg.sbr = 0
+    good, fed, models, n = _streams_3_0(pkg, aot, 91 + aot, bad_tick=bad_tick)
+    want = _expected_layout_run(pkg, oracle, cfg, layout, (s_sce, s_cpe), aot, good, bad_tick, models)
+    pl = pkg.LayoutPipeline(cfg, layout, n, threads=2)
+    for t in range(len(fed)):
+        status = pl.submit(fed[t])
+        got = pl.collect().copy()
+        assert [i for i in range(n) if status[i] < 0] == (sorted(models) if t == bad_tick else []), t
+        assert np.array_equal(got, want[t]), (t, [i for i in range(n) if not np.array_equal(got[i], want[t][i])])
+    pl.close()
+    asc = bytes([(aot << 3) | (SI >> 1), ((SI & 1) << 7) | (3 << 3)])
+    codec = C.c_void_p.in_dll(lib, "heaac_aac_decoder")
+    out = (C.c_int16 * (192000 // 2))()
+    for i in sorted(models):
+        ctx = HeaacCodecContext(cfg=-1, extradata=asc, extradata_size=len(asc))
+        assert lib.heaac_codec_open(C.byref(ctx), C.c_void_p(C.addressof(codec))) == 0
+        for t in range(len(fed)):
+            buf = C.create_string_buffer(fed[t][i], len(fed[t][i]))
+            pkt = HeaacPacket(C.cast(buf, C.c_void_p), len(fed[t][i]))
+            size = C.c_int(192000)
+            used = lib.heaac_codec_decode(C.byref(ctx), out, C.byref(size), C.byref(pkt))
+            if t == bad_tick:
+                assert used < 0, (i, t)
+                continue
+            assert used == len(fed[t][i]) and size.value == 1024 * 3 * 2, (i, t, used)
+            assert np.array_equal(np.frombuffer(out, np.int16, 1024 * 3).reshape(1024, 3), want[t][i]), (i, t)
+        assert lib.heaac_codec_close(C.byref(ctx)) == 0
+    # the model matters
+    skipped = _expected_layout_run(pkg, oracle, cfg, layout, (s_sce, s_cpe), aot, good, bad_tick,
+                                   {i: dict(elements=[None, None], draws=0) for i in models})
+    differ = [i for i in models if any(not np.array_equal(skipped[t][i], want[t][i]) for t in range(bad_tick + 1, len(fed)))]
+    assert len(differ) >= len(models) // 2, differ
