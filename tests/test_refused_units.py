@@ -379,3 +379,72 @@ def test_layout_streams_carry_on_behind_a_refused_unit(pkg, oracle, dev, aot):
                                    {i: dict(elements=[None, None], draws=0) for i in models})
     differ = [i for i in models if any(not np.array_equal(skipped[t][i], want[t][i]) for t in range(bad_tick + 1, len(fed)))]
     assert len(differ) >= len(models) // 2, differ
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# HE-AAC: the core element's refusal moves the core's state; the SBR / PS side stays where it was
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfgname", ["CFG_HEV2", "CFG_HEV1"])
+def test_he_streams_carry_on_behind_a_refused_unit(pkg, oracle, dev, cfgname):
+    """HE-AACv2 (mono + SBR + PS) and HE-AACv1 stereo streams through the pipeline: a unit refused inside its core
+    element leaves the window history and the noise generator as the model says, the SBR / PS reader and the whole
+    DSP state record as they were (ff_sbr_apply never ran: spectral_to_sample is not reached, aacdec.c:2069-2078)."""
+    import test_pipeline as TPL
+    import test_sbr_parse as TS
+    hcfg = getattr(pkg, cfgname)
+    cpe = hcfg == pkg.CFG_HEV1
+    ch, ps, si, bad_tick, ticks = (2 if cpe else 1), not cpe, 6, 2, 5
+    rng = np.random.default_rng(77 + cpe)
+    kinds = [k for k in (R.KINDS_CPE if cpe else R.KINDS_SCE)]
+    n = len(kinds) + 2
+    good = TPL._ticks(pkg, rng, ch, ps, n, ticks)
+    fed = [list(a) for a in good]
+    models = {}
+    for j, kind in enumerate(kinds):
+        bad, _, model = (R.cpe_unit if cpe else R.sce_unit)(rng, si, 2, kind)
+        fed[bad_tick][j + 1] = bad
+        models[j + 1] = model
+    m4 = TS._he_cfg(pkg, ch, ps)
+    # the oracle over the units each stream decodes (a refused unit is absent from its stream's SBR / DSP history)
+    tab = pkg.SbrHeaderTable(256)
+    st, sst = np.zeros(n, pkg.AAC_STREAM_DT), pkg.sbr_streams(n)
+    state = np.zeros((n, pkg.STATE_WORDS[hcfg]), np.float32)
+    rs = np.full(n, 0x1f2e3d4c, np.int32)
+    want = []
+    for t in range(ticks):
+        if t == bad_tick:
+            # parse the good units of the other streams; the refused streams keep parser and decoder state
+            idx = [i for i in range(n) if i not in models]
+        else:
+            idx = list(range(n))
+        sub_st, sub_sst = st[idx].copy(), np.ascontiguousarray(sst[idx])
+        p = pkg.heaac_parse_batch(m4, sub_st, sub_sst, tab, [good[t][i] for i in idx], with_ps=ps)
+        # (behind the refused unit a stream's SBR payload may fail -- its time-differential data build on a frame the
+        # reader never saw -- which turns SBR off for that unit on both sides; the core element always parses)
+        assert (p["info"]["channels"] == ch).all()
+        st[idx], sst[idx] = sub_st, sub_sst
+        coeffs = np.ascontiguousarray(p["coeffs"][:, :ch])
+        ref_c, r1 = oracle.spectral_tools_batch(ch, coeffs, p["tools"], rng=rs[idx])
+        rs[idx] = r1
+        pcm, s1 = oracle.he_decode_batch(hcfg, ref_c, np.ascontiguousarray(p["ics"][:, :ch]), p["sbr"], tab.headers(),
+                                         p["ps"] if ps else None, state[idx], oracle.PCM_S16)
+        state[idx] = s1
+        full = np.zeros((n,) + pcm.shape[1:], np.int16)
+        full[idx] = pcm
+        want.append(full)
+        if t == bad_tick:
+            for i, m in models.items():
+                for c, h in enumerate(m["history"]):
+                    if h is not None:
+                        st["window_sequence"][i, c], st["use_kb_window"][i, c] = h
+                rs[i] = R.lcg(rs[i], m["draws"])
+    pl = pkg.Pipeline(m4, hcfg, n, threads=2)
+    for t in range(ticks):
+        status = pl.submit(fed[t])
+        got = pl.collect().copy()
+        if t == bad_tick:
+            assert all(status[i] < 0 for i in models) and all(status[i] == 0 for i in range(n) if i not in models)
+        assert np.array_equal(got, want[t]), (t, [i for i in range(n) if not np.array_equal(got[i], want[t][i])])
+    pl.close()
+    assert all(any(want[t][i].any() for t in range(bad_tick + 1, ticks)) for i in models)
