@@ -357,11 +357,13 @@ struct SynIn {
 // (A lane reading its own 256-byte row in 16-byte pieces pulls every line through the vector L1 eight
 // times; with 7 waves per CU the L1 keeps none of them.)
 #define SYN_STAGE_STRIDE 68       // floats per staged row: 64 + 4 (b128 reads of 64 different rows spread over all banks)
-// Streamed once: X rows and ring state in (default policy: non-temporal loads measured no gain), PCM and
-// ring state out (non-temporal stores: -5.9 % kernel time, profiles/r02_experiments.md E7).
+// Streamed once: X rows and ring state in -- non-temporal loads: nothing for the float output (within the noise of
+// a box), but the int16 output's half-line stores find their lines still in L2 more often (k_synth<1> writes 22.6
+// instead of 25.4 KiB per frame and runs 3 % shorter: profiles/r04_experiments.md E6) -- PCM and ring state out
+// (non-temporal stores: -5.9 % kernel time, profiles/r02_experiments.md E7).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 syn_ld4(const f32x4 *p) { return *p; }
-__device__ __forceinline__ float syn_ld1(const float *p) { return *p; }
+__device__ __forceinline__ f32x4 syn_ld4(const f32x4 *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ float syn_ld1(const float *p) { return __builtin_nontemporal_load(p); }
 template <class T>
 __device__ __forceinline__ void syn_st(T *p, T v) { __builtin_nontemporal_store(v, p); }
 // PLANES = true: X0 / X1 are the re / im planes [32][64] of the stage-level entry point (heaac_qmf_synthesis_batch).
@@ -552,10 +554,13 @@ void k_synth(const float *__restrict__ g_tab, const float *g_X,
             }
         } else {
             // float_to_int16_interleave (dsputil.c:3989-4001) as 2-byte stores, one pass per channel: the left
-            // samples of a frame land in L2 first, the right ones fill the other halves of the same lines a few
-            // microseconds later, so HBM sees whole lines.  Nothing of the left channel waits in registers or
-            // LDS, and the channel loop keeps ONE instance of the polyphase sum as the float path does (two
-            // inlined instances with different store code cost 152 spilled VGPRs and 40 % of this kernel's time).
+            // samples of a frame go out first, the right ones fill the other halves of the same lines a few
+            // microseconds later.  Most lines do NOT merge on the way: WRITE_SIZE shows 22.6 KiB per frame where 17.4
+            // are algorithmic (profiles/traffic.json, hev2_s16; 25.4 before the loads above went non-temporal).  Packing (L, R) into one 4-byte store needs the left
+            // channel's 4 KiB to wait somewhere, and there is nowhere: the v rows fill the LDS at seven waves (151 of
+            // 160 KB; no row is dead while the right channel's sum starts), the registers are full at 256, and two
+            // inlined instances of the polyphase sum with different store code cost 152 spilled VGPRs and 40 % of
+            // this kernel's time.  So the channel loop keeps ONE instance of the sum, as the float path does.
             int16_t *o = reinterpret_cast<int16_t *>(g_pcm) + (pcm_frame0 + f) * 2048 * nout;
             for (int ch = 0; ch < nout; ch++)
                 channel(ch, [&](int i, int n, float v) {
