@@ -159,11 +159,13 @@ HeaacLayoutDec *heaac_layout_dec_create(HeaacDevice *dev, const HeaacAacConfig *
     // che_configure then gives EVERY single channel element of the layout a second output channel (:203-206):
     // ff_sbr_apply runs ff_ps_apply on it once PS data has arrived and copies the left channel until then
     // (aacsbr.c:1751-1758).  An LFE stays one channel (its type is not TYPE_SCE).
+    // (A one-channel layout that signals SBR implicitly gets there in its first access unit: heaac_layout_dec_frame.)
     const int ps_sce = m4ac->sbr == 1 && m4ac->ps == 1;
     int outs = 0;
     for (int i = 0; i < layout->n_elements; i++)
         outs += ps_sce && layout->elem[i].type == HEAAC_ELEM_SCE ? 2 : layout->elem[i].channels;
     if (outs > HEAAC_MAX_PCM_PLANES) return NULL;
+    const int most_outs = outs < 2 ? 2 : outs;
     HeaacLayoutDec *d = (HeaacLayoutDec *)calloc(1, sizeof(*d));
     if (!d) return NULL;
     d->dev = dev;
@@ -204,7 +206,7 @@ HeaacLayoutDec *heaac_layout_dec_create(HeaacDevice *dev, const HeaacAacConfig *
     for (int i = 0; i < LAY_MAX_HDRS; i++) d->hdr[i].kx = 32;          // kx' = 32, m = 0 (aacsbr.c:130)
     ok = ok && hipMalloc((void **)&d->d_hdr, sizeof(d->hdr)) == hipSuccess &&
          hipMalloc((void **)&d->d_rng, 4) == hipSuccess &&
-         hipMalloc((void **)&d->d_pcm, (size_t)outs * 2048 * 2) == hipSuccess &&
+         hipMalloc((void **)&d->d_pcm, (size_t)most_outs * 2048 * 2) == hipSuccess &&
          hipMemcpy(d->d_hdr, d->hdr, sizeof(d->hdr), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(d->d_rng, &seed, 4, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { heaac_layout_dec_destroy(d); return NULL; }
@@ -272,6 +274,14 @@ int heaac_layout_dec_frame(HeaacLayoutDec *d, const uint8_t *buf, int size, void
                 if (d->h_elem[i].sbr_payload_bit >= 0) d->m4ac.sbr = 1;
             for (int k = 0; c && k < HEAAC_MAX_CCE; k++)
                 if (cce_here[k] && c->h_elem[k].sbr_payload_bit >= 0) d->m4ac.sbr = 1;
+            // ... and in a stream of ONE channel the first payload turns Parametric Stereo on with it: the output is
+            // configured again, now with two channels (decode_extension_payload, aacdec.c:1670-1673)
+            if (d->m4ac.sbr == 1 && d->m4ac.ps == -1 && d->out_channels == 1 && d->n == 1 &&
+                d->layout.elem[0].type == HEAAC_ELEM_SCE) {
+                d->m4ac.ps = 1;
+                d->e[0].cfg_he = HEAAC_CFG_HEV2;
+                d->e[0].out_channels = d->out_channels = 2;
+            }
         }
         d->locked = 1;
     }

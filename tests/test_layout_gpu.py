@@ -87,6 +87,9 @@ MODES = {
     "he_pce_ps_3_0": (0, [(SCE, 0), (CPE, 0)], True, "asc"),
     "he_pce_ps_mono": (0, [(SCE, 0)], True, "asc"),
     "he_pce_ps_5_1_downsampled": (0, [(SCE, 0), (CPE, 0), (CPE, 1), (LFE, 0)], True, "asc_downsampled"),
+    # ... and a ONE-channel program-config stream whose first access unit carries an SBR payload: implicit SBR turns
+    # Parametric Stereo on with it and the output is configured again with two channels (aacdec.c:1670-1673)
+    "he_pce_ps_mono_implicit": (0, [(SCE, 0)], True, "asc_implicit"),
 }
 
 
@@ -131,12 +134,13 @@ def test_codec_decodes_multichannel_streams(pkg, oracle, dev, mode):
         r, layout, _ = pkg.aac_layout_from_pce(bw.bytes(), 0)
     assert r == 0
     ne, nch = int(layout[0]["n_elements"]), int(layout[0]["channels"])
-    ps_sce = he and cc == 0 and asc is not None
+    ps_sce = he and cc == 0 and asc is not None and (how != "asc_implicit" or nch == 1)
     slot_out = [2 if ps_sce and int(layout[0]["elem"][e]["type"]) == SCE else int(layout[0]["elem"][e]["channels"]) for e in range(ne)]
     first_out = [sum(slot_out[:e]) for e in range(ne)]
     nch = sum(slot_out)
     if asc is not None:
-        assert ctx.channels == nch and ctx.channel_layout == int(layout[0]["channel_layout"])
+        # (implicit Parametric Stereo shows in the first access unit, not at open)
+        assert ctx.channels == (1 if mode == "he_pce_ps_mono_implicit" else nch) and ctx.channel_layout == int(layout[0]["channel_layout"])
     st = np.zeros(pkg.MAX_ELEMENTS, pkg.AAC_STREAM_DT)
     length = 2048 if he and not down else 1024
     slot_ch = [int(layout[0]["elem"][e]["channels"]) for e in range(ne)]
