@@ -515,7 +515,8 @@ class AdtsHeader(C.Structure):
 
 COUPLING_DT = np.dtype([("gain", "<f4", (2,)), ("on", "u1", (2,)), ("pad", "u1", (2,))])
 AAC_STREAM_DT = np.dtype([("window_sequence", "u1", (2,)), ("use_kb_window", "u1", (2,)),
-                          ("cce_window_sequence", "u1", (16,)), ("cce_use_kb_window", "u1", (16,))])
+                          ("cce_window_sequence", "u1", (16,)), ("cce_use_kb_window", "u1", (16,)),
+                          ("mapped_tag", "u1"), ("pad", "u1", (3,))])
 AAC_INFO_DT = np.dtype([("channels", "<i4"), ("bits_consumed", "<i4"), ("sbr_payload_bit", "<i4"),
                         ("sbr_payload_bytes", "<i4"), ("sbr_crc", "<i4"), ("elem_id", "<i4"), ("n_cce", "<i4"),
                         ("sbr_misplaced", "<i4"), ("refused", "<i4")])

@@ -780,6 +780,21 @@ int heaac_aac_parse_frame(const HeaacAacConfig *cfg, HeaacAacStream *st,
     return heaac_aac_parse_frame_ex(cfg, st, au, size, 2, coeffs, ics, tools, NULL, info);
 }
 
+/* get_che (aacdec.c:113-177) for a stream of channel configuration 1 or 2: the configuration's one element -- an SCE
+ * for 1, a CPE for 2 -- is mapped to the instance tag it is first met with; anything else, a second element of the
+ * unit (its tag counts as seen, the next one is not mapped) and the same element under another tag in a later unit
+ * find no element allocated and fail the unit there (:2011-2015), with nothing of their own read. */
+static int output_element_allowed(const HeaacAacConfig *cfg, HeaacAacStream *st, int type, int tag, int have_one, Progress *pg)
+{
+    if (have_one) return REF_FAIL(pg, HEAAC_PARSE_ERR_UNSUPPORTED);
+    if (cfg->chan_config == 1 || cfg->chan_config == 2) {
+        if ((type == TYPE_CPE) != (cfg->chan_config == 2)) return REF_FAIL(pg, HEAAC_PARSE_ERR_DATA);
+        if (st->mapped_tag && st->mapped_tag != tag + 1) return REF_FAIL(pg, HEAAC_PARSE_ERR_DATA);
+        st->mapped_tag = (uint8_t)(tag + 1);           /* (kept whatever becomes of the unit, as tag_che_map is) */
+    }
+    return HEAAC_PARSE_OK;
+}
+
 /* The walk over one access unit of a one-element stream; `b`, `w`, `pg`, `n_cce_seen` are the caller's so that it
  * can tell, after a refusal, how far the walk had got. */
 static int frame_walk(const HeaacAacConfig *cfg, HeaacAacStream *st, const uint8_t *au, int size, int coeff_channels,
@@ -817,13 +832,13 @@ static int frame_walk(const HeaacAacConfig *cfg, HeaacAacStream *st, const uint8
         int elem_id = (int)bits(b, 4);
         switch (elem) {
         case TYPE_SCE:
-            if (fi.channels) return HEAAC_PARSE_ERR_UNSUPPORTED;
+            if ((r = output_element_allowed(cfg, st, TYPE_SCE, elem_id, fi.channels, pg)) < 0) return r;
             if ((r = read_ics(cfg, b, 0, &tools->ch[0], &w[0], coeffs, pg, 0)) < 0) return r;
             fi.channels = 1;
             fi.elem_id = elem_id;
             break;
         case TYPE_CPE: {
-            if (fi.channels) return HEAAC_PARSE_ERR_UNSUPPORTED;
+            if ((r = output_element_allowed(cfg, st, TYPE_CPE, elem_id, fi.channels, pg)) < 0) return r;
             if (coeff_channels < 2) return HEAAC_PARSE_ERR_ARG;
             if ((r = read_cpe(cfg, b, tools, w, coeffs, pg)) < 0) return r;
             fi.channels = 2;

@@ -118,6 +118,12 @@ typedef struct HeaacAacStream {
     uint8_t use_kb_window[2];
     uint8_t cce_window_sequence[16];  /* the same for the coupling channels, by instance tag (che[TYPE_CCE][tag]) */
     uint8_t cce_use_kb_window[16];
+    uint8_t mapped_tag;           /* heaac_aac_parse_frame(_ex): 1 + the instance tag the stream's output element was first
+                                     seen with, 0 before.  get_che maps the one element of a channel configuration 1 / 2
+                                     stream to the first tag it meets and to no other (ac->tag_che_map, tags_mapped,
+                                     aacdec.c:131-177): a later unit whose element carries another tag is refused
+                                     ("channel element %d.%d is not allocated", :2011-2015) */
+    uint8_t pad[3];
 } HeaacAacStream;
 
 typedef struct HeaacAacFrameInfo {

@@ -448,3 +448,49 @@ def test_he_streams_carry_on_behind_a_refused_unit(pkg, oracle, dev, cfgname):
         assert np.array_equal(got, want[t]), (t, [i for i in range(n) if not np.array_equal(got[i], want[t][i])])
     pl.close()
     assert all(any(want[t][i].any() for t in range(bad_tick + 1, ticks)) for i in models)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# get_che: which element a channel configuration 1 / 2 stream has, and under which tag
+# ------------------------------------------------------------------------------------------------------------------
+def test_elements_the_configuration_has_no_place_for_fail_the_unit_where_get_che_does(pkg):
+    """aacdec.c:113-177, :2011-2015.  The one element of the configuration is mapped to the tag it is first met with:
+    the other element type, the element under another tag later on, and a second element in one unit all find nothing
+    allocated -- the unit fails there, with whatever stood in front of the refusal decoded."""
+    rng = np.random.default_rng(12)
+    # the wrong type: nothing is read, nothing moves, no tag is mapped
+    for ch, writer in ((2, R.sce_element), (1, R.cpe_element)):
+        cfg = TP._cfg(pkg, 2, SI, ch)
+        st = np.zeros(1, pkg.AAC_STREAM_DT)
+        st["window_sequence"][0] = (3, 1)
+        before = st.copy()
+        bits, _, _ = writer(rng, SI, 2, "good")
+        r, out = pkg.aac_parse_frame_ex(cfg, st[0:1], R._bytes(bits + R.END), with_cce=False)
+        assert r < 0 and out["info"][0]["refused"] == pkg.REFUSED_AS_REFERENCE and st.tobytes() == before.tobytes()
+    # the tag: the first one met stays
+    cfg = TP._cfg(pkg, 2, SI, 1)
+    st = np.zeros(1, pkg.AAC_STREAM_DT)
+    for tag, ok in ((5, True), (5, True), (0, False), (6, False), (5, True)):
+        bits, _, model = R.sce_element(rng, SI, 2, "good", tag=tag)
+        before = st.copy()
+        r, out = pkg.aac_parse_frame_ex(cfg, st[0:1], R._bytes(bits + R.END), with_cce=False)
+        assert (r == 0) == ok, (tag, r)
+        assert int(st["mapped_tag"][0]) == 6
+        if ok:
+            assert int(out["info"][0]["elem_id"]) == 5 and _history(st, 0) == model["history"][0]
+        else:
+            assert out["info"][0]["refused"] == pkg.REFUSED_AS_REFERENCE and st.tobytes() == before.tobytes()
+    # a second element in the unit: refused behind the first, whose decoder has run
+    for ch, writer in ((1, R.sce_element), (2, R.cpe_element)):
+        cfg = TP._cfg(pkg, 2, SI, ch)
+        for second in (R.sce_element, R.cpe_element):
+            st = np.zeros(1, pkg.AAC_STREAM_DT)
+            a, _, model = writer(rng, SI, 2, "good")
+            b, _, _ = second(rng, SI, 2, "good", tag=1)
+            r, out = pkg.aac_parse_frame_ex(cfg, st[0:1], R._bytes(a + b + R.END), with_cce=False)
+            info = out["info"][0]
+            assert r < 0 and info["refused"] & pkg.REFUSED_AS_REFERENCE
+            assert [_history(st, c) for c in range(ch)] == model["history"]
+            assert bool(info["refused"] & pkg.REFUSED_RUN_TOOLS) == bool(model["draws"])
+            if model["draws"]:
+                assert sum(_record_draws(out["tools"][0]["ch"][c]) for c in range(ch)) == model["draws"]
