@@ -149,3 +149,70 @@ def test_layout_pipeline_refuses_what_it_does_not_take(pkg, dev):
         pl.submit([bytes(16)] * 4)                             # a third tick in flight
     assert not pl.collect().any()
     pl.close()
+
+
+@pytest.mark.parametrize("mode", ["lc_5_1", "main_5_0", "he_5_1", "he_pce_ps_3_0"])
+def test_layout_pipeline_and_codec_agree_on_damaged_streams(pkg, dev, mode):
+    """Mutated access units (bit flips, byte noise, truncation, splices) through the layout pipeline and through one
+    codec context per stream: the same verdict unit for unit -- refused and silent, or the same PCM -- and the same
+    streams afterwards (what a refused unit leaves behind is followed up per element on both paths,
+    tests/test_refused_units.py)."""
+    from test_damaged_streams_gpu import _mutate
+    from test_shim_gpu import HeaacCodecContext, HeaacPacket
+    lib = pkg.lib()
+    n, ticks = 16, 9
+    rng = np.random.default_rng(sum(map(ord, mode)) + 77)
+    streams = [_stream_units(pkg, rng, mode, ticks) for _ in range(n)]
+    _, aot, si, cc, he = streams[0]
+    pce = None
+    if cc == 0:
+        import test_parse_layout as TL
+        elems = LG.MODES[mode][1]
+        front = [(int(t == CPE), g) for t, g in elems if t in (SCE, CPE) and not (t == CPE and g == 1)]
+        pce = lambda bw: TL.write_pce_body(bw, np.random.default_rng(1), front, [], [(1, 1)] if (CPE, 1) in elems else [],
+                                           [g for t, g in elems if t == LFE])
+    asc = LG._asc(aot, si, cc, he=he, pce=pce)
+    r, m4, layout = pkg.asc_layout(asc)
+    assert r == 0
+    if not he:
+        m4.sbr = 0
+    units = [[streams[i][0][t] for i in range(n)] for t in range(ticks)]
+    pool = [u for tick in units for u in tick]
+    fed = [list(u) for u in units]
+    for t in range(2, ticks):
+        for i in range(n):
+            if rng.random() < 0.4:
+                fed[t][i] = _mutate(rng, fed[t][i], pool)
+    pl = pkg.LayoutPipeline(m4, layout, n, threads=3)
+    nch, length = pl.ch, pl.len
+    got, status = [], []
+    for t in range(ticks):
+        status.append(np.array(pl.submit(fed[t])).copy())
+        got.append(pl.collect().copy())
+    pl.close()
+    codec = C.c_void_p.in_dll(lib, "heaac_aac_decoder")
+    out = (C.c_int16 * (192000 // 2))()
+    refused = after = 0
+    for i in range(n):
+        ctx = HeaacCodecContext(cfg=-1, extradata=asc, extradata_size=len(asc))
+        assert lib.heaac_codec_open(C.byref(ctx), C.c_void_p(C.addressof(codec))) == 0
+        seen = False
+        for t in range(ticks):
+            b = fed[t][i]
+            buf = C.create_string_buffer(b, len(b))
+            pkt = HeaacPacket(C.cast(buf, C.c_void_p), len(b))
+            size = C.c_int(192000)
+            used = lib.heaac_codec_decode(C.byref(ctx), out, C.byref(size), C.byref(pkt))
+            if used < 0:
+                assert status[t][i] < 0 and not got[t][i].any(), (mode, i, t, int(status[t][i]))
+                refused += 1
+                seen = True
+                continue
+            if status[t][i] == -3:
+                break           # (the pipeline wants one element order for all its streams: this stream left it)
+            assert status[t][i] == 0 and size.value == length * nch * 2, (mode, i, t, int(status[t][i]))
+            pcm = np.frombuffer(out, np.int16, length * nch).reshape(length, nch)
+            assert np.array_equal(pcm, got[t][i]), (mode, i, t)
+            after += seen
+        assert lib.heaac_codec_close(C.byref(ctx)) == 0
+    assert refused > n // 3 and after > n // 2
