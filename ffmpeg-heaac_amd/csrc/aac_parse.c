@@ -786,8 +786,9 @@ int heaac_aac_parse_frame(const HeaacAacConfig *cfg, HeaacAacStream *st,
  * find no element allocated and fail the unit there (:2011-2015), with nothing of their own read. */
 static int output_element_allowed(const HeaacAacConfig *cfg, HeaacAacStream *st, int type, int tag, int have_one, Progress *pg)
 {
-    if (have_one) return REF_FAIL(pg, HEAAC_PARSE_ERR_UNSUPPORTED);
-    if (cfg->chan_config == 1 || cfg->chan_config == 2) {
+    const int one_element = cfg->chan_config == 1 || cfg->chan_config == 2;
+    if (have_one) return one_element ? REF_FAIL(pg, HEAAC_PARSE_ERR_UNSUPPORTED) : HEAAC_PARSE_ERR_UNSUPPORTED;
+    if (one_element) {
         if ((type == TYPE_CPE) != (cfg->chan_config == 2)) return REF_FAIL(pg, HEAAC_PARSE_ERR_DATA);
         if (st->mapped_tag && st->mapped_tag != tag + 1) return REF_FAIL(pg, HEAAC_PARSE_ERR_DATA);
         st->mapped_tag = (uint8_t)(tag + 1);           /* (kept whatever becomes of the unit, as tag_che_map is) */
