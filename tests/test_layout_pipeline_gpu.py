@@ -151,8 +151,9 @@ def test_layout_pipeline_refuses_what_it_does_not_take(pkg, dev):
     pl.close()
 
 
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("HEAAC_FUZZ_SEEDS", "1")))))
 @pytest.mark.parametrize("mode", ["lc_5_1", "main_5_0", "he_5_1", "he_pce_ps_3_0"])
-def test_layout_pipeline_and_codec_agree_on_damaged_streams(pkg, dev, mode):
+def test_layout_pipeline_and_codec_agree_on_damaged_streams(pkg, dev, mode, seed):
     """Mutated access units (bit flips, byte noise, truncation, splices) through the layout pipeline and through one
     codec context per stream: the same verdict unit for unit -- refused and silent, or the same PCM -- and the same
     streams afterwards (what a refused unit leaves behind is followed up per element on both paths,
@@ -161,7 +162,7 @@ def test_layout_pipeline_and_codec_agree_on_damaged_streams(pkg, dev, mode):
     from test_shim_gpu import HeaacCodecContext, HeaacPacket
     lib = pkg.lib()
     n, ticks = 16, 9
-    rng = np.random.default_rng(sum(map(ord, mode)) + 77)
+    rng = np.random.default_rng(sum(map(ord, mode)) + 77 + 1000 * seed)
     streams = [_stream_units(pkg, rng, mode, ticks) for _ in range(n)]
     _, aot, si, cc, he = streams[0]
     pce = None

@@ -14,9 +14,12 @@ import test_sbr_parse as TS
 from test_damaged_streams_gpu import _mutate
 
 pytestmark = pytest.mark.gpu
+# HEAAC_FUZZ_SEEDS=n: n seeds instead of three (a longer soak: `HEAAC_FUZZ_SEEDS=40 pytest tests/test_pipeline_vs_codec_gpu.py`)
+import os
+SEEDS = list(range(int(os.environ.get("HEAAC_FUZZ_SEEDS", "3"))))
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("seed", SEEDS)
 @pytest.mark.parametrize("mode", ["main_stereo", "lc_mono", "hev2", "hev1"])
 def test_pipeline_and_codec_agree_on_damaged_streams(pkg, dev, mode, seed):
     from test_shim_gpu import HeaacCodecContext, HeaacPacket
