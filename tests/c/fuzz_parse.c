@@ -194,6 +194,16 @@ int main(int argc, char **argv)
             memset(&info, 0, sizeof(info));
             const int r = heaac_aac_parse_frame_layout(&lcfg, &lay, lst, au, (int)len, lcoeffs, &lics[0][0], ltools, lelem, &info);
             if (r >= 0) ok++; else err++;
+            if (r < 0 && (info.refused & HEAAC_REFUSED_RUN_TOOLS)) {
+                /* what a refused unit leaves for the spectral tools: the elements marked present, in seq order */
+                tools_runs++;
+                for (int e = 0; e < lay.n_elements; e++) {
+                    if (!lelem[e].present) continue;
+                    int v = lelem[e].seq >= lay.n_elements;
+                    for (int c = 0; c < lay.elem[e].channels; c++) v |= tools_channel_bad(&ltools[e].ch[c], 1);
+                    if (v) { layout_bad++; if (layout_bad < 5) printf("iteration %ld: refused layout unit leaves a tools record out of range\n", it); }
+                }
+            }
             if (r == HEAAC_PARSE_OK) {
                 layout_units++;
                 int seen = 0;
