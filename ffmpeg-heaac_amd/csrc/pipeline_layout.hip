@@ -34,7 +34,26 @@ struct LpElem {
     HeaacSbrStream *sst;            // [n] host: the element's SBR reader state per stream
 };
 
+// The coupling channel elements of a layout (AAC-LC / Main; slots 0 .. K-1 of the layout's list): individual channel
+// streams of their own, batched per slot like an output element
+struct LpCoupled {
+    int K;
+    float *d_state[HEAAC_MAX_CCE];                  // [n][512]: overlap of a coupling channel that couples AFTER_IMDCT
+    HeaacPredictorState *d_pred[HEAAC_MAX_CCE];     // [n][672] (AAC-Main)
+    float *d_ret[HEAAC_MAX_CCE];                    // [n][1024]: the coupling channel's own output
+    float *d_state_tmp;                             // [n][512]
+    unsigned char *seen;                            // [n][K]: an earlier unit of the stream carried the element
+};
+
 struct LpSet {
+    // coupling elements: per output element the records that land there, per slot the channel's own records
+    HeaacCceFrame *h_cce[HEAAC_MAX_ELEMENTS], *d_cce[HEAAC_MAX_ELEMENTS];   // [n][K]
+    float *h_ccoef[HEAAC_MAX_CCE], *d_ccoef[HEAAC_MAX_CCE];                 // [n][1024]
+    HeaacIcs *h_cics[HEAAC_MAX_CCE], *d_cics[HEAAC_MAX_CCE];
+    HeaacToolsFrame *h_ctools[HEAAC_MAX_CCE], *d_ctools[HEAAC_MAX_CCE];
+    float *d_ccoef_fm;                              // [n][K][1024]: the spectra frame-major, as the tools' POST half reads them
+    HeaacCoupling *h_gain, *d_gain;                 // [ne][K][HEAAC_MAX_CCE_LINKS][n]: AFTER_IMDCT gains, call by call
+    unsigned char *cpos;                            // [n][K][3]: present, outputs_before, seq of each coupling element
     // per element, [n] each; pinned host / device
     float *h_coeffs[HEAAC_MAX_ELEMENTS], *d_coeffs[HEAAC_MAX_ELEMENTS];
     HeaacIcs *h_ics[HEAAC_MAX_ELEMENTS], *d_ics[HEAAC_MAX_ELEMENTS];
@@ -64,6 +83,7 @@ struct HeaacLayoutPipeline {
     HeaacAacStream *ast;            // [n][ne]
     HeaacAacLayout *lay;            // [n]: every stream's own tag map
     int have_order; unsigned char order[HEAAC_MAX_ELEMENTS];     // order[seq] = element at that bitstream position
+    LpCoupled *cpl;                 // layouts whose program config element names coupling elements (AAC-LC / Main)
     // parked state of the streams whose unit failed
     float *d_park; size_t park_bytes;
     unsigned long submitted, collected;
@@ -88,6 +108,16 @@ static inline HeaacSbrStream *sst_at(HeaacSbrStream *base, size_t i)
 // keep_tools: the tools records and spectra are already what a refused unit leaves for the spectral tools.
 static void neutral(HeaacLayoutPipeline *p, LpSet *s, size_t i, bool keep_tools = false)
 {
+    if (p->cpl) {
+        const int K = p->cpl->K;
+        for (int e = 0; e < p->ne; e++) memset(s->h_cce[e] + i * K, 0, (size_t)K * sizeof(HeaacCceFrame));
+        for (int k = 0; k < K; k++) {
+            memset(s->h_ccoef[k] + i * 1024, 0, 4096);
+            memset(&s->h_cics[k][i], 0, sizeof(HeaacIcs));
+            memset(&s->h_ctools[k][i], 0, sizeof(HeaacToolsFrame));
+        }
+        memset(s->cpos + i * K * 3, 0, (size_t)K * 3);
+    }
     for (int k = 0; k < p->ne; k++) {
         const int ch = p->e[k].channels;
         memset(s->h_ics[k] + i * ch, 0, ch * sizeof(HeaacIcs));
@@ -113,6 +143,18 @@ static void lp_parse_slice(HeaacLayoutPipeline *p, int w)
     HeaacToolsFrame *tt = (HeaacToolsFrame *)malloc((size_t)ne * sizeof(HeaacToolsFrame));
     HeaacAacElementInfo te[HEAAC_MAX_ELEMENTS];
     HeaacAacStream st[HEAAC_MAX_ELEMENTS];
+    // the parser's coupling output (rows of HEAAC_MAX_CCE slots per output element)
+    const int K = p->cpl ? p->cpl->K : 0;
+    HeaacCceOut co = { NULL, NULL, NULL, NULL, NULL };
+    HeaacAacElementInfo ce[HEAAC_MAX_CCE];
+    if (K) {
+        co.cce = (HeaacCceFrame *)malloc((size_t)ne * HEAAC_MAX_CCE * sizeof(HeaacCceFrame));
+        co.coeffs = (float *)malloc(HEAAC_MAX_CCE * 4096);
+        co.ics = (HeaacIcs *)malloc(HEAAC_MAX_CCE * sizeof(HeaacIcs));
+        co.tools = (HeaacToolsFrame *)malloc(HEAAC_MAX_CCE * sizeof(HeaacToolsFrame));
+        co.elem = ce;
+        if (!co.cce || !co.coeffs || !co.ics || !co.tools) { free(tc); tc = NULL; }
+    }
     for (size_t i = lo; i < hi; i++) {
         int r = HEAAC_PARSE_ERR_ARG;
         HeaacAacFrameInfo fi;
@@ -120,9 +162,13 @@ static void lp_parse_slice(HeaacLayoutPipeline *p, int w)
         if (tc && ti && tt) {
             // the parser works on copies of the window histories until the whole unit has parsed
             for (int k = 0; k < ne; k++) st[k] = p->ast[i * ne + k];
-            r = heaac_aac_parse_frame_layout_ex(&p->aac, &p->lay[i], st, p->job_au[i], p->job_size[i], tc, ti, tt, te, NULL, &fi);
+            r = heaac_aac_parse_frame_layout_ex(&p->aac, &p->lay[i], st, p->job_au[i], p->job_size[i], tc, ti, tt, te, K ? &co : NULL, &fi);
             for (int k = 0; r == HEAAC_PARSE_OK && k < ne; k++)
                 if (!te[k].present) r = HEAAC_PARSE_ERR_DATA;      // an element of the layout left out (codec_layout.hip: refused)
+            // ... or a coupling element an earlier unit of the stream carried (the reference would couple whatever its
+            // buffers still hold)
+            for (int k = 0; r == HEAAC_PARSE_OK && k < K; k++)
+                if (p->cpl->seen[i * K + k] && !co.cce[k].present) r = HEAAC_PARSE_ERR_DATA;
         }
         if (p->job_status) p->job_status[i] = r;
         s->failed[i] = (unsigned char)(r != HEAAC_PARSE_OK);
@@ -150,6 +196,27 @@ static void lp_parse_slice(HeaacLayoutPipeline *p, int w)
             neutral(p, s, i, s->failed[i] == 2);
             continue;
         }
+        for (int k = 0; k < K; k++) {
+            const HeaacCceFrame &c0 = co.cce[k];            // (the same element in every output slot's row)
+            unsigned char *cp = s->cpos + (i * K + k) * 3;
+            cp[0] = c0.present; cp[1] = c0.outputs_before; cp[2] = c0.seq;
+            if (c0.present) p->cpl->seen[i * K + k] = 1;
+            for (int e = 0; e < ne; e++) {
+                HeaacCceFrame &o = s->h_cce[e][i * K + k];
+                o = co.cce[e * HEAAC_MAX_CCE + k];
+                // "Dependent coupling is not supported together with LTP" (apply_dependent_coupling :1822-1826 returns)
+                if (p->aac.object_type == 4 && o.coupling_point != HEAAC_CC_AFTER_IMDCT) o.n_links = 0;
+            }
+            if (c0.present) {
+                memcpy(s->h_ccoef[k] + i * 1024, co.coeffs + k * 1024, 4096);
+                s->h_cics[k][i] = co.ics[k];
+                s->h_ctools[k][i] = co.tools[k];
+            } else {
+                memset(s->h_ccoef[k] + i * 1024, 0, 4096);
+                memset(&s->h_cics[k][i], 0, sizeof(HeaacIcs));
+                memset(&s->h_ctools[k][i], 0, sizeof(HeaacToolsFrame));
+            }
+        }
         for (int k = 0; k < ne; k++) {
             const int ch = p->e[k].channels;
             p->ast[i * ne + k] = st[k];
@@ -171,6 +238,7 @@ static void lp_parse_slice(HeaacLayoutPipeline *p, int w)
         }
     }
     free(tc); free(ti); free(tt);
+    free(co.cce); free(co.coeffs); free(co.ics); free(co.tools);
 }
 
 static void *lp_worker(void *arg)
@@ -220,6 +288,20 @@ extern "C" void heaac_layout_pipeline_destroy(HeaacLayoutPipeline *p)
             for (void *x : h) if (x) (void)hipHostFree(x);
             for (void *x : d) if (x) (void)hipFree(x);
         }
+        for (int k = 0; k < HEAAC_MAX_ELEMENTS; k++) {
+            if (s->h_cce[k]) (void)hipHostFree(s->h_cce[k]);
+            if (s->d_cce[k]) (void)hipFree(s->d_cce[k]);
+        }
+        for (int k = 0; k < HEAAC_MAX_CCE; k++) {
+            void *h[] = { s->h_ccoef[k], s->h_cics[k], s->h_ctools[k] };
+            void *d[] = { s->d_ccoef[k], s->d_cics[k], s->d_ctools[k] };
+            for (void *x : h) if (x) (void)hipHostFree(x);
+            for (void *x : d) if (x) (void)hipFree(x);
+        }
+        if (s->d_ccoef_fm) (void)hipFree(s->d_ccoef_fm);
+        if (s->h_gain) (void)hipHostFree(s->h_gain);
+        if (s->d_gain) (void)hipFree(s->d_gain);
+        free(s->cpos);
         if (s->h_pcm) (void)hipHostFree(s->h_pcm);
         if (s->d_pcm) (void)hipFree(s->d_pcm);
         if (s->done) (void)hipEventDestroy(s->done);
@@ -230,6 +312,16 @@ extern "C" void heaac_layout_pipeline_destroy(HeaacLayoutPipeline *p)
         if (p->e[k].d_pred) (void)hipFree(p->e[k].d_pred);
         if (p->e[k].d_f32) (void)hipFree(p->e[k].d_f32);
         free(p->e[k].sst);
+    }
+    if (p->cpl) {
+        for (int k = 0; k < HEAAC_MAX_CCE; k++) {
+            if (p->cpl->d_state[k]) (void)hipFree(p->cpl->d_state[k]);
+            if (p->cpl->d_pred[k]) (void)hipFree(p->cpl->d_pred[k]);
+            if (p->cpl->d_ret[k]) (void)hipFree(p->cpl->d_ret[k]);
+        }
+        if (p->cpl->d_state_tmp) (void)hipFree(p->cpl->d_state_tmp);
+        free(p->cpl->seen);
+        free(p->cpl);
     }
     if (p->d_rng) (void)hipFree(p->d_rng);
     if (p->d_hdr) (void)hipFree(p->d_hdr);
@@ -250,8 +342,14 @@ extern "C" int heaac_layout_pipeline_create(HeaacLayoutPipeline **out, const Hea
         layout->channels < 1 || layout->channels > HEAAC_MAX_PCM_PLANES || aac->sampling_index < 0 || aac->sampling_index > 12 ||
         (aac->sbr != 0 && aac->sbr != 1))                 // implicit signalling (-1) is settled per stream by its first unit
         return HEAAC_ERR_ARG;
+    // coupling channel elements: AAC-LC / Main layouts; with SBR (a coupling channel then goes through SBR itself and
+    // couples over 2048 samples) one heaac_codec_decode context per stream
+    int n_cce_slots = 0;
     for (int id = 0; id < 16; id++)
-        if (layout->slot_of[HEAAC_ELEM_CCE][id]) return HEAAC_ERR_ARG;         // coupling elements: heaac_codec_decode
+        if (layout->slot_of[HEAAC_ELEM_CCE][id]) {
+            if (layout->slot_of[HEAAC_ELEM_CCE][id] > n_cce_slots) n_cce_slots = layout->slot_of[HEAAC_ELEM_CCE][id];
+        }
+    if (n_cce_slots > HEAAC_MAX_CCE || (n_cce_slots && aac->sbr == 1)) return HEAAC_ERR_ARG;
     {
         int outs = 0;
         for (int k = 0; k < layout->n_elements; k++)
@@ -307,6 +405,42 @@ extern "C" int heaac_layout_pipeline_create(HeaacLayoutPipeline **out, const Hea
             }
             free(ps);
             ps = NULL;
+        }
+    }
+    if (ok && n_cce_slots) {
+        const int K = n_cce_slots;
+        LpCoupled *c = p->cpl = (LpCoupled *)calloc(1, sizeof(LpCoupled));
+        ok = c != NULL;
+        if (ok) {
+            c->K = K;
+            c->seen = (unsigned char *)calloc(n * K, 1);
+            ok = c->seen != NULL && lp_devmem((void **)&c->d_state_tmp, n * 512 * 4);
+        }
+        HeaacPredictorState *reset = NULL;
+        if (ok && p->main_profile) {
+            reset = (HeaacPredictorState *)calloc(n * HEAAC_MAX_PREDICTORS, sizeof(*reset));
+            ok = reset != NULL;
+            for (size_t i = 0; ok && i < n * HEAAC_MAX_PREDICTORS; i++) reset[i].var0 = reset[i].var1 = 1.0f;
+        }
+        for (int k = 0; ok && k < K; k++) {
+            ok = lp_devmem((void **)&c->d_state[k], n * 512 * 4) && hipMemset(c->d_state[k], 0, n * 512 * 4) == hipSuccess &&
+                 lp_devmem((void **)&c->d_ret[k], n * 1024 * 4) &&
+                 (!reset || (lp_devmem((void **)&c->d_pred[k], n * HEAAC_MAX_PREDICTORS * sizeof(*reset)) &&
+                             hipMemcpy(c->d_pred[k], reset, n * HEAAC_MAX_PREDICTORS * sizeof(*reset), hipMemcpyHostToDevice) == hipSuccess));
+        }
+        free(reset);
+        for (int q = 0; q < LP_DEPTH && ok; q++) {
+            LpSet *s = &p->set[q];
+            for (int e = 0; e < p->ne && ok; e++)
+                ok = lp_pinned((void **)&s->h_cce[e], n * K * sizeof(HeaacCceFrame)) && lp_devmem((void **)&s->d_cce[e], n * K * sizeof(HeaacCceFrame));
+            for (int k = 0; k < K && ok; k++)
+                ok = lp_pinned((void **)&s->h_ccoef[k], n * 4096) && lp_devmem((void **)&s->d_ccoef[k], n * 4096) &&
+                     lp_pinned((void **)&s->h_cics[k], n * sizeof(HeaacIcs)) && lp_devmem((void **)&s->d_cics[k], n * sizeof(HeaacIcs)) &&
+                     lp_pinned((void **)&s->h_ctools[k], n * sizeof(HeaacToolsFrame)) && lp_devmem((void **)&s->d_ctools[k], n * sizeof(HeaacToolsFrame));
+            const size_t ng = (size_t)p->ne * K * HEAAC_MAX_CCE_LINKS * n;
+            ok = ok && lp_devmem((void **)&s->d_ccoef_fm, n * K * 4096) &&
+                 lp_pinned((void **)&s->h_gain, ng * sizeof(HeaacCoupling)) && lp_devmem((void **)&s->d_gain, ng * sizeof(HeaacCoupling)) &&
+                 (s->cpos = (unsigned char *)calloc(n * K, 3)) != NULL;
         }
     }
     for (int q = 0; q < LP_DEPTH && ok; q++) {
@@ -446,6 +580,27 @@ extern "C" int heaac_layout_pipeline_submit(HeaacLayoutPipeline *p, const uint8_
             neutral(p, s, i);
         }
     }
+    // ... and where the coupling elements stand among them, tick by tick: the first good stream of the tick says, the
+    // others must agree (the coupling POINT may differ from stream to stream)
+    const int K = p->cpl ? p->cpl->K : 0;
+    unsigned char cpat[HEAAC_MAX_CCE][3];
+    int have_cpat = 0, n_cce_tick = 0;
+    memset(cpat, 0, sizeof(cpat));
+    for (size_t i = 0; K && i < n; i++) {
+        if (s->failed[i]) continue;
+        const unsigned char *cp = s->cpos + i * K * 3;
+        if (!have_cpat) { memcpy(cpat, cp, (size_t)K * 3); have_cpat = 1; continue; }
+        bool same = true;
+        for (int k = 0; k < K; k++)
+            same = same && cp[3 * k] == cpat[k][0] && (!cp[3 * k] || (cp[3 * k + 1] == cpat[k][1] && cp[3 * k + 2] == cpat[k][2]));
+        if (!same) {
+            s->failed[i] = 1;
+            n_failed++;
+            if (status) status[i] = HEAAC_PARSE_ERR_UNSUPPORTED;
+            neutral(p, s, i);
+        }
+    }
+    for (int k = 0; k < K; k++) n_cce_tick += cpat[k][0];
     const size_t have = heaac_sbr_table_count(p->tab);
     if (have > LP_MAX_HDRS) return HEAAC_ERR_ARG;
     // H2D (the run stream carries everything: the tick before has the GPU meanwhile)
@@ -461,6 +616,15 @@ extern "C" int heaac_layout_pipeline_submit(HeaacLayoutPipeline *p, const uint8_
         LP_HIP(hipMemcpyAsync(s->d_tools[k], s->h_tools[k], n * sizeof(HeaacToolsFrame), hipMemcpyHostToDevice, p->run));
         if (p->he) LP_HIP(hipMemcpyAsync(s->d_sbr[k], s->h_sbr[k], n * sizeof(HeaacSbrFrame), hipMemcpyHostToDevice, p->run));
         if (s->d_ps[k]) LP_HIP(hipMemcpyAsync(s->d_ps[k], s->h_ps[k], n * sizeof(HeaacPsFrame), hipMemcpyHostToDevice, p->run));
+    }
+    if (n_cce_tick) {
+        for (int e = 0; e < ne; e++)
+            LP_HIP(hipMemcpyAsync(s->d_cce[e], s->h_cce[e], n * K * sizeof(HeaacCceFrame), hipMemcpyHostToDevice, p->run));
+        for (int k = 0; k < K; k++) {
+            LP_HIP(hipMemcpyAsync(s->d_ccoef[k], s->h_ccoef[k], n * 4096, hipMemcpyHostToDevice, p->run));
+            LP_HIP(hipMemcpyAsync(s->d_cics[k], s->h_cics[k], n * sizeof(HeaacIcs), hipMemcpyHostToDevice, p->run));
+            LP_HIP(hipMemcpyAsync(s->d_ctools[k], s->h_ctools[k], n * sizeof(HeaacToolsFrame), hipMemcpyHostToDevice, p->run));
+        }
     }
     if (n_failed) {
         size_t row = 4;
@@ -479,13 +643,57 @@ extern "C" int heaac_layout_pipeline_submit(HeaacLayoutPipeline *p, const uint8_
         const int rc = lp_park(p, s, n_failed, 0);
         if (rc != HEAAC_OK) return rc;
     }
-    // the spectral tools of the elements in bitstream order (one noise generator per stream)
-    for (int q = 0; q < ne; q++) {
+    // the spectral tools of the elements in bitstream order (one noise generator per stream).  A coupling element's
+    // tools as a whole at its place in the stream (nothing couples INTO it); with coupling elements in the tick an
+    // output element's first half there and its second half -- coupling, TNS, coupling -- once every coupling
+    // element is through (codec_layout.hip; spectral_to_sample walks the element types downwards, aacdec.c:1907).
+    for (int q = 0; q <= ne; q++) {
+        for (int seq = 0; seq < n_cce_tick; seq++)
+            for (int k = 0; k < K; k++) {
+                if (!cpat[k][0] || cpat[k][1] != q || cpat[k][2] != seq) continue;
+                const int rc = heaac_spectral_tools_batch_ex(p->dev, 1, HEAAC_TOOLS_ALL, s->d_ccoef[k], s->d_ctools[k], p->d_rng, p->d_rng,
+                                                             p->cpl->d_pred[k], p->cpl->d_pred[k], NULL, NULL, 0, n, (void *)p->run);
+                if (rc != HEAAC_OK) return rc;
+            }
+        if (q == ne) break;
         const int k = p->have_order ? p->order[q] : q;
         const LpElem &e = p->e[k];
-        const int rc = heaac_spectral_tools_batch(p->dev, e.channels, s->d_coeffs[k], s->d_tools[k], p->d_rng, p->d_rng,
-                                                  e.d_pred, e.d_pred, n, (void *)p->run);
+        const int rc = heaac_spectral_tools_batch_ex(p->dev, e.channels, n_cce_tick ? HEAAC_TOOLS_PRE : HEAAC_TOOLS_ALL, s->d_coeffs[k],
+                                                     s->d_tools[k], p->d_rng, p->d_rng, e.d_pred, e.d_pred, NULL, NULL, 0, n, (void *)p->run);
         if (rc != HEAAC_OK) return rc;
+    }
+    if (n_cce_tick) {
+        // the coupling channels' spectra frame-major, K slots per stream, as the second half reads them
+        for (int k = 0; k < K; k++)
+            LP_HIP(hipMemcpy2DAsync(s->d_ccoef_fm + (size_t)k * 1024, (size_t)K * 4096, s->d_ccoef[k], 4096, 4096, n,
+                                    hipMemcpyDeviceToDevice, p->run));
+        for (int k = 0; k < ne; k++) {
+            const LpElem &e = p->e[k];
+            const int rc = heaac_spectral_tools_batch_ex(p->dev, e.channels, HEAAC_TOOLS_POST, s->d_coeffs[k], s->d_tools[k], NULL, NULL,
+                                                         NULL, NULL, s->d_cce[k], s->d_ccoef_fm, K, n, (void *)p->run);
+            if (rc != HEAAC_OK) return rc;
+        }
+        // the coupling channels that couple behind the IMDCT: their own IMDCT first (type 2 before types 1 and 0).  Only
+        // the streams whose element couples there this tick may move its overlap state: where all do the call works in
+        // place, where some do the others' rows are taken from a scratch copy of the state.
+        for (int k = 0; k < K; k++) {
+            if (!cpat[k][0]) continue;
+            size_t after = 0, live = 0;
+            for (size_t i = 0; i < n; i++) {
+                live += !s->failed[i];
+                after += !s->failed[i] && s->h_cce[0][i * K + k].present && s->h_cce[0][i * K + k].coupling_point == HEAAC_CC_AFTER_IMDCT;
+            }
+            if (!after) continue;
+            float *st = p->cpl->d_state[k];
+            const bool all = after == n && live == n;
+            const int rc = heaac_lc_decode_batch(p->dev, 1, s->d_ccoef[k], s->d_cics[k], st, all ? st : p->cpl->d_state_tmp,
+                                                 p->cpl->d_ret[k], HEAAC_PCM_F32_PLANAR, n, (void *)p->run);
+            if (rc != HEAAC_OK) return rc;
+            if (!all)
+                for (size_t i = 0; i < n; i++)
+                    if (!s->failed[i] && s->h_cce[0][i * K + k].present && s->h_cce[0][i * K + k].coupling_point == HEAAC_CC_AFTER_IMDCT)
+                        LP_HIP(hipMemcpyAsync(st + i * 512, p->cpl->d_state_tmp + i * 512, 2048, hipMemcpyDeviceToDevice, p->run));
+        }
     }
     HeaacPlaneRef planes[HEAAC_MAX_PCM_PLANES];
     for (int k = 0; k < ne; k++) {
@@ -496,6 +704,29 @@ extern "C" int heaac_layout_pipeline_submit(HeaacLayoutPipeline *p, const uint8_
             : heaac_lc_decode_batch(p->dev, e.channels, s->d_coeffs[k], s->d_ics[k], e.d_state, e.d_state, e.d_f32,
                                     HEAAC_PCM_F32_PLANAR, n, (void *)p->run);
         if (rc != HEAAC_OK) return rc;
+        // every AFTER_IMDCT element in tag order, every gain list that lands on this element (apply_channel_coupling
+        // :1870-1898; apply_independent_coupling :1849-1862): one batched call per list, gains per stream
+        for (int kc = 0; kc < K && n_cce_tick; kc++) {
+            if (!cpat[kc][0]) continue;
+            for (int l = 0; l < HEAAC_MAX_CCE_LINKS; l++) {
+                HeaacCoupling *g = s->h_gain + (((size_t)k * K + kc) * HEAAC_MAX_CCE_LINKS + l) * n;
+                size_t used = 0;
+                for (size_t i = 0; i < n; i++) {
+                    const HeaacCceFrame &r = s->h_cce[k][i * K + kc];
+                    memset(&g[i], 0, sizeof(g[i]));
+                    if (s->failed[i] || !r.present || r.coupling_point != HEAAC_CC_AFTER_IMDCT || l >= r.n_links) continue;
+                    const int tch = r.link[l].target_ch < e.channels ? r.link[l].target_ch : 0;
+                    g[i].on[tch] = 1;
+                    g[i].gain[tch] = r.link[l].gain[0];
+                    used++;
+                }
+                if (!used) continue;
+                HeaacCoupling *dg = s->d_gain + (g - s->h_gain);
+                LP_HIP(hipMemcpyAsync(dg, g, n * sizeof(HeaacCoupling), hipMemcpyHostToDevice, p->run));
+                const int rc2 = heaac_couple_after_imdct_batch(p->dev, e.channels, e.d_f32, p->cpl->d_ret[kc], dg, NULL, n, (void *)p->run);
+                if (rc2 != HEAAC_OK) return rc2;
+            }
+        }
         for (int c = 0; c < e.out; c++) {
             planes[e.first_out + c].d_base = e.d_f32 + (size_t)c * p->len;
             planes[e.first_out + c].frame_stride = (size_t)e.out * p->len;

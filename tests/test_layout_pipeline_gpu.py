@@ -139,9 +139,12 @@ def test_layout_pipeline_refuses_what_it_does_not_take(pkg, dev):
         pkg.LayoutPipeline(m4, layout, 4)
     m4.sbr = 0
     l2 = layout.copy()
-    l2[0]["slot_of"][2][5] = 1                                 # a coupling channel element in the layout
+    l2[0]["slot_of"][2][5] = 1                                 # a coupling channel element in the layout ...
+    m4.sbr = 1                                                 # ... of an SBR stream: one codec context per stream
+    m4.ext_sample_rate = 2 * m4.sample_rate
     with pytest.raises(pkg.HeaacError):
         pkg.LayoutPipeline(m4, l2, 4)
+    m4.sbr, m4.ext_sample_rate = 0, 0
     pl = pkg.LayoutPipeline(m4, layout, 4)
     for _ in range(2):
         pl.submit([bytes(16)] * 4)                             # (garbage units: every stream fails, silence)
@@ -217,3 +220,88 @@ def test_layout_pipeline_and_codec_agree_on_damaged_streams(pkg, dev, mode, seed
             after += seen
         assert lib.heaac_codec_close(C.byref(ctx)) == 0
     assert refused > n // 3 and after > n // 2
+
+
+def _coupled_unit(rng, si, aot, elems, tags, at, points):
+    """An access unit of a layout with coupling elements, as tests/coupled_ref.py writes them, but with the elements
+    in the given order and coupling element `tags[k]` in front of output element number `at[k]` (len(elems): behind
+    the last): the order every stream of a pipeline shares.  Targets, gain lists and coupling points are drawn."""
+    import aac_bitwriter as W
+    import test_parse_layout as TL
+    import test_parse_wide as TW
+    real = [e for e in elems if e[0] != LFE]
+    bw = W.BitWriter()
+    for pos in range(len(elems) + 1):
+        for k, tag in enumerate(tags):
+            if at[k] != pos:
+                continue
+            targets = []
+            for _ in range(int(rng.integers(1, 3))):
+                t, g = real[int(rng.integers(0, len(real)))]
+                targets.append((t, g, int(rng.integers(0, 4)) if t == CPE else 2))
+            TW.write_cce(bw, rng, si, aot, tag, targets, int(rng.choice(points)), quiet=False)
+        if pos < len(elems):
+            TL.write_elem(bw, rng, si, aot, *elems[pos], quiet=False)
+    bw.put(7, 3)
+    return bw.bytes()
+
+
+@pytest.mark.parametrize("name", ["five_one", "main_three", "pair_dependent", "mono_independent"])
+def test_layout_pipeline_with_coupling_elements_equals_one_codec_context_per_stream(pkg, dev, name):
+    """AAC-LC / Main layouts whose program config element names coupling channel elements (tests/test_coupling_gpu.py
+    pins the codec path to the oracle on them): dependent coupling around every target's TNS, independent coupling
+    behind its IMDCT -- the coupling point drawn per stream and unit, so that a tick mixes them -- onto one and onto
+    several output elements.  Some units are damaged; one stream leaves a coupling element out for a unit."""
+    import coupled_ref as CR
+    import test_coupling_gpu as TC
+    from test_damaged_streams_gpu import _mutate
+    from test_shim_gpu import HeaacCodecContext, HeaacPacket
+    lib = pkg.lib()
+    aot, elems, cc_tags, points = TC.STREAMS[name]
+    rng = np.random.default_rng(sum(map(ord, name)) + 5)
+    si, n, ticks = 3, 10, 8
+    asc = CR.asc(aot, si, elems, cc_tags, rng)
+    r, m4, layout = pkg.asc_layout(asc)
+    assert r == 0
+    m4.sbr = 0
+    nch = int(layout[0]["channels"])
+    at = [int(x) for x in sorted(rng.integers(0, len(elems) + 1, len(cc_tags)))]
+    fed = [[_coupled_unit(rng, si, aot, elems, cc_tags, at, points) for _ in range(n)] for _ in range(ticks)]
+    pool = [u for t in fed for u in t]
+    for t in range(2, ticks):
+        for i in range(n):
+            if rng.random() < 0.25:
+                fed[t][i] = _mutate(rng, fed[t][i], pool)
+    fed[4][3] = _coupled_unit(rng, si, aot, elems, cc_tags[:-1], at[:-1], points)      # a coupling element left out: refused
+    pl = pkg.LayoutPipeline(m4, layout, n, threads=3)
+    assert pl.ch == nch and pl.len == 1024
+    got, status = [], []
+    for t in range(ticks):
+        status.append(np.array(pl.submit(fed[t])).copy())
+        got.append(pl.collect().copy())
+    pl.close()
+    codec = C.c_void_p.in_dll(lib, "heaac_aac_decoder")
+    out = (C.c_int16 * (192000 // 2))()
+    decoded = refused = 0
+    for i in range(n):
+        ctx = HeaacCodecContext(cfg=-1, extradata=asc, extradata_size=len(asc))
+        assert lib.heaac_codec_open(C.byref(ctx), C.c_void_p(C.addressof(codec))) == 0
+        for t in range(ticks):
+            b = fed[t][i]
+            buf = C.create_string_buffer(b, len(b))
+            pkt = HeaacPacket(C.cast(buf, C.c_void_p), len(b))
+            size = C.c_int(192000)
+            used = lib.heaac_codec_decode(C.byref(ctx), out, C.byref(size), C.byref(pkt))
+            if used < 0:
+                assert status[t][i] < 0 and not got[t][i].any(), (name, i, t, int(status[t][i]))
+                refused += 1
+                continue
+            if status[t][i] == -3:
+                break                   # (a damaged unit moved an element: the pipeline wants one order for all its streams)
+            assert status[t][i] == 0 and size.value == 1024 * nch * 2, (name, i, t, int(status[t][i]))
+            pcm = np.frombuffer(out, np.int16, 1024 * nch).reshape(1024, nch)
+            assert np.array_equal(pcm, got[t][i]), (name, i, t, np.argwhere(pcm != got[t][i])[:3])
+            decoded += 1
+        assert lib.heaac_codec_close(C.byref(ctx)) == 0
+    assert status[4][3] < 0 and decoded > n * ticks // 2 and refused >= 1
+    assert max(int(np.abs(g.astype(int)).max()) for g in got) > 50
