@@ -34,14 +34,16 @@ struct LpElem {
     HeaacSbrStream *sst;            // [n] host: the element's SBR reader state per stream
 };
 
-// The coupling channel elements of a layout (AAC-LC / Main; slots 0 .. K-1 of the layout's list): individual channel
-// streams of their own, batched per slot like an output element
+// The coupling channel elements of a layout (slots 0 .. K-1 of the layout's list): individual channel streams of
+// their own, batched per slot like an output element
 struct LpCoupled {
-    int K;
-    float *d_state[HEAAC_MAX_CCE];                  // [n][512]: overlap of a coupling channel that couples AFTER_IMDCT
+    int K, words;                                   // words: 512 (the overlap), behind SBR a mono element's whole state
+    float *d_state[HEAAC_MAX_CCE];                  // [n][words]: state of a coupling channel that couples AFTER_IMDCT
     HeaacPredictorState *d_pred[HEAAC_MAX_CCE];     // [n][672] (AAC-Main)
-    float *d_ret[HEAAC_MAX_CCE];                    // [n][1024]: the coupling channel's own output
-    float *d_state_tmp;                             // [n][512]
+    float *d_ret[HEAAC_MAX_CCE];                    // [n][len]: the coupling channel's own output
+    float *d_state_tmp;                             // [n][words]
+    float *d_plane;                                 // [n][len]: one channel of a two-channel element, gathered for the coupling op
+    HeaacSbrStream *sst[HEAAC_MAX_CCE];             // [n] host: a coupling channel's own SBR reader (che->sbr)
     unsigned char *seen;                            // [n][K]: an earlier unit of the stream carried the element
 };
 
@@ -51,8 +53,9 @@ struct LpSet {
     float *h_ccoef[HEAAC_MAX_CCE], *d_ccoef[HEAAC_MAX_CCE];                 // [n][1024]
     HeaacIcs *h_cics[HEAAC_MAX_CCE], *d_cics[HEAAC_MAX_CCE];
     HeaacToolsFrame *h_ctools[HEAAC_MAX_CCE], *d_ctools[HEAAC_MAX_CCE];
+    HeaacSbrFrame *h_csbr[HEAAC_MAX_CCE], *d_csbr[HEAAC_MAX_CCE];
     float *d_ccoef_fm;                              // [n][K][1024]: the spectra frame-major, as the tools' POST half reads them
-    HeaacCoupling *h_gain, *d_gain;                 // [ne][K][HEAAC_MAX_CCE_LINKS][n]: AFTER_IMDCT gains, call by call
+    HeaacCoupling *h_gain, *d_gain;                 // [ne][K][HEAAC_MAX_CCE_LINKS][n * len / 1024]: AFTER_IMDCT gains, call by call
     unsigned char *cpos;                            // [n][K][3]: present, outputs_before, seq of each coupling element
     // per element, [n] each; pinned host / device
     float *h_coeffs[HEAAC_MAX_ELEMENTS], *d_coeffs[HEAAC_MAX_ELEMENTS];
@@ -115,6 +118,11 @@ static void neutral(HeaacLayoutPipeline *p, LpSet *s, size_t i, bool keep_tools 
             memset(s->h_ccoef[k] + i * 1024, 0, 4096);
             memset(&s->h_cics[k][i], 0, sizeof(HeaacIcs));
             memset(&s->h_ctools[k][i], 0, sizeof(HeaacToolsFrame));
+            if (p->he) {
+                void *tmp = alloca(heaac_sbr_stream_bytes());
+                memcpy(tmp, sst_at(p->cpl->sst[k], i), heaac_sbr_stream_bytes());
+                heaac_sbr_no_payload((HeaacSbrStream *)tmp, 1, &s->h_csbr[k][i], NULL);
+            }
         }
         memset(s->cpos + i * K * 3, 0, (size_t)K * 3);
     }
@@ -207,6 +215,24 @@ static void lp_parse_slice(HeaacLayoutPipeline *p, int w)
                 // "Dependent coupling is not supported together with LTP" (apply_dependent_coupling :1822-1826 returns)
                 if (p->aac.object_type == 4 && o.coupling_point != HEAAC_CC_AFTER_IMDCT) o.n_links = 0;
             }
+            if (p->he) {
+                // A coupling channel's own SBR (it goes through ff_sbr_apply when it couples AFTER_IMDCT, aacdec.c:1920-1927).
+                // A payload behind an element that couples in the spectrum is read all the same; without one the
+                // reader's state only moves where the channel is transformed.
+                HeaacSbrStream *cs = sst_at(p->cpl->sst[k], i);
+                const bool after = c0.present && c0.coupling_point == HEAAC_CC_AFTER_IMDCT;
+                if (c0.present && ce[k].sbr_payload_bit >= 0) {
+                    (void)heaac_sbr_parse_payload(cs, p->tab, p->aac.sample_rate, p->job_au[i], p->job_size[i], ce[k].sbr_payload_bit,
+                                                  ce[k].sbr_payload_bytes, ce[k].sbr_crc, 1, ce[k].sbr_misplaced ? HEAAC_SBR_MISPLACED : 0,
+                                                  &s->h_csbr[k][i], NULL, NULL);
+                } else if (after) {
+                    heaac_sbr_no_payload(cs, 1, &s->h_csbr[k][i], NULL);
+                } else {
+                    void *tmp = alloca(heaac_sbr_stream_bytes());
+                    memcpy(tmp, cs, heaac_sbr_stream_bytes());
+                    heaac_sbr_no_payload((HeaacSbrStream *)tmp, 1, &s->h_csbr[k][i], NULL);
+                }
+            }
             if (c0.present) {
                 memcpy(s->h_ccoef[k] + i * 1024, co.coeffs + k * 1024, 4096);
                 s->h_cics[k][i] = co.ics[k];
@@ -293,8 +319,8 @@ extern "C" void heaac_layout_pipeline_destroy(HeaacLayoutPipeline *p)
             if (s->d_cce[k]) (void)hipFree(s->d_cce[k]);
         }
         for (int k = 0; k < HEAAC_MAX_CCE; k++) {
-            void *h[] = { s->h_ccoef[k], s->h_cics[k], s->h_ctools[k] };
-            void *d[] = { s->d_ccoef[k], s->d_cics[k], s->d_ctools[k] };
+            void *h[] = { s->h_ccoef[k], s->h_cics[k], s->h_ctools[k], s->h_csbr[k] };
+            void *d[] = { s->d_ccoef[k], s->d_cics[k], s->d_ctools[k], s->d_csbr[k] };
             for (void *x : h) if (x) (void)hipHostFree(x);
             for (void *x : d) if (x) (void)hipFree(x);
         }
@@ -318,8 +344,10 @@ extern "C" void heaac_layout_pipeline_destroy(HeaacLayoutPipeline *p)
             if (p->cpl->d_state[k]) (void)hipFree(p->cpl->d_state[k]);
             if (p->cpl->d_pred[k]) (void)hipFree(p->cpl->d_pred[k]);
             if (p->cpl->d_ret[k]) (void)hipFree(p->cpl->d_ret[k]);
+            free(p->cpl->sst[k]);
         }
         if (p->cpl->d_state_tmp) (void)hipFree(p->cpl->d_state_tmp);
+        if (p->cpl->d_plane) (void)hipFree(p->cpl->d_plane);
         free(p->cpl->seen);
         free(p->cpl);
     }
@@ -342,14 +370,13 @@ extern "C" int heaac_layout_pipeline_create(HeaacLayoutPipeline **out, const Hea
         layout->channels < 1 || layout->channels > HEAAC_MAX_PCM_PLANES || aac->sampling_index < 0 || aac->sampling_index > 12 ||
         (aac->sbr != 0 && aac->sbr != 1))                 // implicit signalling (-1) is settled per stream by its first unit
         return HEAAC_ERR_ARG;
-    // coupling channel elements: AAC-LC / Main layouts; with SBR (a coupling channel then goes through SBR itself and
-    // couples over 2048 samples) one heaac_codec_decode context per stream
+    // coupling channel elements: slots 0 .. K-1 of the layout's list
     int n_cce_slots = 0;
     for (int id = 0; id < 16; id++)
         if (layout->slot_of[HEAAC_ELEM_CCE][id]) {
             if (layout->slot_of[HEAAC_ELEM_CCE][id] > n_cce_slots) n_cce_slots = layout->slot_of[HEAAC_ELEM_CCE][id];
         }
-    if (n_cce_slots > HEAAC_MAX_CCE || (n_cce_slots && aac->sbr == 1)) return HEAAC_ERR_ARG;
+    if (n_cce_slots > HEAAC_MAX_CCE) return HEAAC_ERR_ARG;
     {
         int outs = 0;
         for (int k = 0; k < layout->n_elements; k++)
@@ -413,8 +440,10 @@ extern "C" int heaac_layout_pipeline_create(HeaacLayoutPipeline **out, const Hea
         ok = c != NULL;
         if (ok) {
             c->K = K;
+            c->words = p->he ? HEAAC_STATE_WORDS_HEV1_MONO : 512;
             c->seen = (unsigned char *)calloc(n * K, 1);
-            ok = c->seen != NULL && lp_devmem((void **)&c->d_state_tmp, n * 512 * 4);
+            ok = c->seen != NULL && lp_devmem((void **)&c->d_state_tmp, n * (size_t)c->words * 4) &&
+                 lp_devmem((void **)&c->d_plane, n * (size_t)p->len * 4);
         }
         HeaacPredictorState *reset = NULL;
         if (ok && p->main_profile) {
@@ -423,8 +452,14 @@ extern "C" int heaac_layout_pipeline_create(HeaacLayoutPipeline **out, const Hea
             for (size_t i = 0; ok && i < n * HEAAC_MAX_PREDICTORS; i++) reset[i].var0 = reset[i].var1 = 1.0f;
         }
         for (int k = 0; ok && k < K; k++) {
-            ok = lp_devmem((void **)&c->d_state[k], n * 512 * 4) && hipMemset(c->d_state[k], 0, n * 512 * 4) == hipSuccess &&
-                 lp_devmem((void **)&c->d_ret[k], n * 1024 * 4) &&
+            const size_t sb = n * (size_t)c->words * 4;
+            if (p->he) {
+                c->sst[k] = (HeaacSbrStream *)malloc(n * heaac_sbr_stream_bytes());
+                ok = c->sst[k] != NULL;
+                if (ok) heaac_sbr_stream_init(c->sst[k], n);
+            }
+            ok = ok && lp_devmem((void **)&c->d_state[k], sb) && hipMemset(c->d_state[k], 0, sb) == hipSuccess &&
+                 lp_devmem((void **)&c->d_ret[k], n * (size_t)p->len * 4) &&
                  (!reset || (lp_devmem((void **)&c->d_pred[k], n * HEAAC_MAX_PREDICTORS * sizeof(*reset)) &&
                              hipMemcpy(c->d_pred[k], reset, n * HEAAC_MAX_PREDICTORS * sizeof(*reset), hipMemcpyHostToDevice) == hipSuccess));
         }
@@ -436,8 +471,9 @@ extern "C" int heaac_layout_pipeline_create(HeaacLayoutPipeline **out, const Hea
             for (int k = 0; k < K && ok; k++)
                 ok = lp_pinned((void **)&s->h_ccoef[k], n * 4096) && lp_devmem((void **)&s->d_ccoef[k], n * 4096) &&
                      lp_pinned((void **)&s->h_cics[k], n * sizeof(HeaacIcs)) && lp_devmem((void **)&s->d_cics[k], n * sizeof(HeaacIcs)) &&
-                     lp_pinned((void **)&s->h_ctools[k], n * sizeof(HeaacToolsFrame)) && lp_devmem((void **)&s->d_ctools[k], n * sizeof(HeaacToolsFrame));
-            const size_t ng = (size_t)p->ne * K * HEAAC_MAX_CCE_LINKS * n;
+                     lp_pinned((void **)&s->h_ctools[k], n * sizeof(HeaacToolsFrame)) && lp_devmem((void **)&s->d_ctools[k], n * sizeof(HeaacToolsFrame)) &&
+                     (!p->he || (lp_pinned((void **)&s->h_csbr[k], n * sizeof(HeaacSbrFrame)) && lp_devmem((void **)&s->d_csbr[k], n * sizeof(HeaacSbrFrame))));
+            const size_t ng = (size_t)p->ne * K * HEAAC_MAX_CCE_LINKS * n * (p->len / 1024);
             ok = ok && lp_devmem((void **)&s->d_ccoef_fm, n * K * 4096) &&
                  lp_pinned((void **)&s->h_gain, ng * sizeof(HeaacCoupling)) && lp_devmem((void **)&s->d_gain, ng * sizeof(HeaacCoupling)) &&
                  (s->cpos = (unsigned char *)calloc(n * K, 3)) != NULL;
@@ -624,6 +660,7 @@ extern "C" int heaac_layout_pipeline_submit(HeaacLayoutPipeline *p, const uint8_
             LP_HIP(hipMemcpyAsync(s->d_ccoef[k], s->h_ccoef[k], n * 4096, hipMemcpyHostToDevice, p->run));
             LP_HIP(hipMemcpyAsync(s->d_cics[k], s->h_cics[k], n * sizeof(HeaacIcs), hipMemcpyHostToDevice, p->run));
             LP_HIP(hipMemcpyAsync(s->d_ctools[k], s->h_ctools[k], n * sizeof(HeaacToolsFrame), hipMemcpyHostToDevice, p->run));
+            if (p->he) LP_HIP(hipMemcpyAsync(s->d_csbr[k], s->h_csbr[k], n * sizeof(HeaacSbrFrame), hipMemcpyHostToDevice, p->run));
         }
     }
     if (n_failed) {
@@ -685,14 +722,19 @@ extern "C" int heaac_layout_pipeline_submit(HeaacLayoutPipeline *p, const uint8_
             }
             if (!after) continue;
             float *st = p->cpl->d_state[k];
+            const size_t words = (size_t)p->cpl->words;
             const bool all = after == n && live == n;
-            const int rc = heaac_lc_decode_batch(p->dev, 1, s->d_ccoef[k], s->d_cics[k], st, all ? st : p->cpl->d_state_tmp,
-                                                 p->cpl->d_ret[k], HEAAC_PCM_F32_PLANAR, n, (void *)p->run);
+            const int rc = p->he
+                ? heaac_he_decode_batch_ex(p->dev, HEAAC_CFG_HEV1_MONO, p->downsampled ? HEAAC_HE_DOWNSAMPLED : 0, s->d_ccoef[k], s->d_cics[k],
+                                           s->d_csbr[k], p->d_hdr, LP_MAX_HDRS, NULL, st, all ? st : p->cpl->d_state_tmp, p->cpl->d_ret[k],
+                                           HEAAC_PCM_F32_PLANAR, n, (void *)p->run)
+                : heaac_lc_decode_batch(p->dev, 1, s->d_ccoef[k], s->d_cics[k], st, all ? st : p->cpl->d_state_tmp,
+                                        p->cpl->d_ret[k], HEAAC_PCM_F32_PLANAR, n, (void *)p->run);
             if (rc != HEAAC_OK) return rc;
             if (!all)
                 for (size_t i = 0; i < n; i++)
                     if (!s->failed[i] && s->h_cce[0][i * K + k].present && s->h_cce[0][i * K + k].coupling_point == HEAAC_CC_AFTER_IMDCT)
-                        LP_HIP(hipMemcpyAsync(st + i * 512, p->cpl->d_state_tmp + i * 512, 2048, hipMemcpyDeviceToDevice, p->run));
+                        LP_HIP(hipMemcpyAsync(st + i * words, p->cpl->d_state_tmp + i * words, words * 4, hipMemcpyDeviceToDevice, p->run));
         }
     }
     HeaacPlaneRef planes[HEAAC_MAX_PCM_PLANES];
@@ -708,23 +750,61 @@ extern "C" int heaac_layout_pipeline_submit(HeaacLayoutPipeline *p, const uint8_
         // :1870-1898; apply_independent_coupling :1849-1862): one batched call per list, gains per stream
         for (int kc = 0; kc < K && n_cce_tick; kc++) {
             if (!cpat[kc][0]) continue;
+            // The batched op adds a [frames][1024] coupling signal into [frames][channels][1024] targets.  Planes of 1024
+            // samples are that as they stand; planes of 2048 (behind SBR) are two such frames per stream with the stream's
+            // gain twice -- for an element of one plane directly, for one of two planes channel by channel on a gathered
+            // copy of the plane (apply_independent_coupling runs over 1024 << sbr samples, aacdec.c:1849-1862).
+            const int sub = p->len / 1024;
+            const bool direct = sub == 1 || e.out == 1;
             for (int l = 0; l < HEAAC_MAX_CCE_LINKS; l++) {
-                HeaacCoupling *g = s->h_gain + (((size_t)k * K + kc) * HEAAC_MAX_CCE_LINKS + l) * n;
-                size_t used = 0;
+                HeaacCoupling *g = s->h_gain + (((size_t)k * K + kc) * HEAAC_MAX_CCE_LINKS + l) * n * sub;
+                size_t used[2] = { 0, 0 };
                 for (size_t i = 0; i < n; i++) {
                     const HeaacCceFrame &r = s->h_cce[k][i * K + kc];
-                    memset(&g[i], 0, sizeof(g[i]));
+                    memset(&g[i * sub], 0, sub * sizeof(g[0]));
                     if (s->failed[i] || !r.present || r.coupling_point != HEAAC_CC_AFTER_IMDCT || l >= r.n_links) continue;
                     const int tch = r.link[l].target_ch < e.channels ? r.link[l].target_ch : 0;
-                    g[i].on[tch] = 1;
-                    g[i].gain[tch] = r.link[l].gain[0];
-                    used++;
+                    for (int q = 0; q < sub; q++) {
+                        // (gathered planes are one-channel frames: the gain sits in channel 0 of the record)
+                        g[i * sub + q].on[direct ? tch : 0] = 1;
+                        g[i * sub + q].gain[direct ? tch : 0] = r.link[l].gain[0];
+                    }
+                    used[tch]++;
                 }
-                if (!used) continue;
+                if (!used[0] && !used[1]) continue;
                 HeaacCoupling *dg = s->d_gain + (g - s->h_gain);
-                LP_HIP(hipMemcpyAsync(dg, g, n * sizeof(HeaacCoupling), hipMemcpyHostToDevice, p->run));
-                const int rc2 = heaac_couple_after_imdct_batch(p->dev, e.channels, e.d_f32, p->cpl->d_ret[kc], dg, NULL, n, (void *)p->run);
-                if (rc2 != HEAAC_OK) return rc2;
+                if (direct) {
+                    LP_HIP(hipMemcpyAsync(dg, g, n * sub * sizeof(HeaacCoupling), hipMemcpyHostToDevice, p->run));
+                    const int rc2 = heaac_couple_after_imdct_batch(p->dev, sub == 1 ? e.out : 1, e.d_f32, p->cpl->d_ret[kc], dg, NULL,
+                                                                   n * sub, (void *)p->run);
+                    if (rc2 != HEAAC_OK) return rc2;
+                    continue;
+                }
+                // two planes of 2048: a gain list lands on ONE channel per stream, and which one may differ from stream to
+                // stream -- one pass per channel, each with the gains of the streams that target it
+                for (int tc2 = 0; tc2 < 2; tc2++) {
+                    if (!used[tc2]) continue;
+                    if (used[tc2 ^ 1]) {
+                        // mixed targets: this pass takes only the streams whose list lands on tc2
+                        for (size_t i = 0; i < n; i++) {
+                            const HeaacCceFrame &r = s->h_cce[k][i * K + kc];
+                            const bool mine = !s->failed[i] && r.present && r.coupling_point == HEAAC_CC_AFTER_IMDCT && l < r.n_links &&
+                                              (r.link[l].target_ch < e.channels ? r.link[l].target_ch : 0) == tc2;
+                            for (int q = 0; q < sub; q++) {
+                                g[i * sub + q].on[0] = mine;
+                                g[i * sub + q].gain[0] = mine ? r.link[l].gain[0] : 0.0f;
+                            }
+                        }
+                        LP_HIP(hipStreamSynchronize(p->run));      // (the staging area is about to be rewritten for the other channel)
+                    }
+                    LP_HIP(hipMemcpyAsync(dg, g, n * sub * sizeof(HeaacCoupling), hipMemcpyHostToDevice, p->run));
+                    const size_t row = (size_t)p->len * 4;
+                    LP_HIP(hipMemcpy2DAsync(p->cpl->d_plane, row, e.d_f32 + (size_t)tc2 * p->len, 2 * row, row, n, hipMemcpyDeviceToDevice, p->run));
+                    const int rc2 = heaac_couple_after_imdct_batch(p->dev, 1, p->cpl->d_plane, p->cpl->d_ret[kc], dg, NULL, n * sub, (void *)p->run);
+                    if (rc2 != HEAAC_OK) return rc2;
+                    LP_HIP(hipMemcpy2DAsync(e.d_f32 + (size_t)tc2 * p->len, 2 * row, p->cpl->d_plane, row, row, n, hipMemcpyDeviceToDevice, p->run));
+                    if (used[tc2 ^ 1]) LP_HIP(hipStreamSynchronize(p->run));
+                }
             }
         }
         for (int c = 0; c < e.out; c++) {

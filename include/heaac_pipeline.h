@@ -75,12 +75,11 @@ void heaac_pipeline_timing(const HeaacPipeline *p, float ms[4]);
  *             copies the left channel until PS data arrives, aacsbr.c:1751-1758).  heaac_asc_layout leaves ps = 0 for
  *             the channel configurations 3 ... 7 (mpeg4audio.c:137-139).  heaac_layout_pipeline_channels() says how
  *             many channels a tick's PCM has.
- *   layout:   may name coupling channel elements where aac->sbr == 0 (AAC-LC / Main: each is one more batched
- *             individual channel stream per slot -- its own tools at its place in the stream, dependent coupling around
- *             every target's TNS, its own IMDCT and independent coupling behind the targets' where it couples
- *             AFTER_IMDCT; the coupling POINT may differ from stream to stream, the coupling elements' PLACES in the
- *             unit must be the same for all streams of a tick).  With SBR a coupling channel goes through SBR itself
- *             and couples over 2048 samples: HEAAC_ERR_ARG, one heaac_codec_decode context per stream.
+ *   layout:   may name coupling channel elements: each is one more batched individual channel stream per slot -- its
+ *             own tools at its place in the stream, dependent coupling around every target's TNS, its own IMDCT (and,
+ *             in an SBR stream, its own SBR with the payload behind it) and independent coupling behind the targets'
+ *             where it couples AFTER_IMDCT.  The coupling POINT may differ from stream to stream; the coupling
+ *             elements' PLACES in the unit must be the same for all streams of a tick.
  * The streams must emit their elements in one bitstream order (the noise generator runs through them in that order;
  * the first good access unit sets it).  A stream whose unit does not parse, leaves an element out or deviates from
  * the order (status HEAAC_PARSE_ERR_UNSUPPORTED) gets silence for the tick and keeps its DSP state; window histories,

@@ -140,11 +140,9 @@ def test_layout_pipeline_refuses_what_it_does_not_take(pkg, dev):
     m4.sbr = 0
     l2 = layout.copy()
     l2[0]["slot_of"][2][5] = 1                                 # a coupling channel element in the layout ...
-    m4.sbr = 1                                                 # ... of an SBR stream: one codec context per stream
-    m4.ext_sample_rate = 2 * m4.sample_rate
+    l2[0]["slot_of"][2][6] = 17                                # ... in a slot the layout's list cannot have
     with pytest.raises(pkg.HeaacError):
         pkg.LayoutPipeline(m4, l2, 4)
-    m4.sbr, m4.ext_sample_rate = 0, 0
     pl = pkg.LayoutPipeline(m4, layout, 4)
     for _ in range(2):
         pl.submit([bytes(16)] * 4)                             # (garbage units: every stream fails, silence)
@@ -222,11 +220,12 @@ def test_layout_pipeline_and_codec_agree_on_damaged_streams(pkg, dev, mode, seed
     assert refused > n // 3 and after > n // 2
 
 
-def _coupled_unit(rng, si, aot, elems, tags, at, points):
+def _coupled_unit(rng, si, aot, elems, tags, at, points, payloads=None, cce_payloads=None, quiet=False):
     """An access unit of a layout with coupling elements, as tests/coupled_ref.py writes them, but with the elements
     in the given order and coupling element `tags[k]` in front of output element number `at[k]` (len(elems): behind
     the last): the order every stream of a pipeline shares.  Targets, gain lists and coupling points are drawn."""
     import aac_bitwriter as W
+    import coupled_ref as CR
     import test_parse_layout as TL
     import test_parse_wide as TW
     real = [e for e in elems if e[0] != LFE]
@@ -239,19 +238,24 @@ def _coupled_unit(rng, si, aot, elems, tags, at, points):
             for _ in range(int(rng.integers(1, 3))):
                 t, g = real[int(rng.integers(0, len(real)))]
                 targets.append((t, g, int(rng.integers(0, 4)) if t == CPE else 2))
-            TW.write_cce(bw, rng, si, aot, tag, targets, int(rng.choice(points)), quiet=False)
+            TW.write_cce(bw, rng, si, aot, tag, targets, int(rng.choice(points)), quiet=quiet)
+            if cce_payloads and cce_payloads.get(tag) is not None:
+                CR.put_sbr_fill(bw, cce_payloads[tag])
         if pos < len(elems):
-            TL.write_elem(bw, rng, si, aot, *elems[pos], quiet=False)
+            TL.write_elem(bw, rng, si, aot, *elems[pos], quiet=quiet)
+            if payloads and payloads.get(pos) is not None:
+                CR.put_sbr_fill(bw, payloads[pos])
     bw.put(7, 3)
     return bw.bytes()
 
 
-@pytest.mark.parametrize("name", ["five_one", "main_three", "pair_dependent", "mono_independent"])
+@pytest.mark.parametrize("name", ["five_one", "main_three", "pair_dependent", "mono_independent", "he_three_dependent", "he_three_all"])
 def test_layout_pipeline_with_coupling_elements_equals_one_codec_context_per_stream(pkg, dev, name):
     """AAC-LC / Main layouts whose program config element names coupling channel elements (tests/test_coupling_gpu.py
     pins the codec path to the oracle on them): dependent coupling around every target's TNS, independent coupling
     behind its IMDCT -- the coupling point drawn per stream and unit, so that a tick mixes them -- onto one and onto
-    several output elements.  Some units are damaged; one stream leaves a coupling element out for a unit."""
+    several output elements; in the HE-AAC layouts the coupling channels go through SBR with payloads of their own and
+    couple over 2048 samples.  Some units are damaged; one stream leaves a coupling element out for a unit."""
     import coupled_ref as CR
     import test_coupling_gpu as TC
     from test_damaged_streams_gpu import _mutate
@@ -259,22 +263,35 @@ def test_layout_pipeline_with_coupling_elements_equals_one_codec_context_per_str
     lib = pkg.lib()
     aot, elems, cc_tags, points = TC.STREAMS[name]
     rng = np.random.default_rng(sum(map(ord, name)) + 5)
-    si, n, ticks = 3, 10, 8
-    asc = CR.asc(aot, si, elems, cc_tags, rng)
+    he = name.startswith("he_")
+    si, n, ticks = (6 if he else 3), 10, 8
+    length = 2048 if he else 1024
+    asc = CR.asc(aot, si, elems, cc_tags, rng, he=he)
     r, m4, layout = pkg.asc_layout(asc)
     assert r == 0
-    m4.sbr = 0
+    if not he:
+        m4.sbr = 0
     nch = int(layout[0]["channels"])
     at = [int(x) for x in sorted(rng.integers(0, len(elems) + 1, len(cc_tags)))]
-    fed = [[_coupled_unit(rng, si, aot, elems, cc_tags, at, points) for _ in range(n)] for _ in range(ticks)]
+    # per stream: the SBR payload writers of its elements and coupling channels (HE layouts)
+    uws = [CR.UnitWriter(pkg, rng, si, aot, elems, cc_tags, points, he) for _ in range(n)]
+
+    def one(i, tags=None, places=None):
+        uw = uws[i]
+        tags = cc_tags if tags is None else tags
+        pay = {k: uw._payload(w) for k, w in uw.writers.items()}
+        cpay = {g: uw._payload(w) for g, w in uw.cce_writers.items() if g in tags}
+        return _coupled_unit(rng, si, aot, elems, tags, at if places is None else places, points, pay, cpay, quiet=he)
+
+    fed = [[one(i) for i in range(n)] for _ in range(ticks)]
     pool = [u for t in fed for u in t]
     for t in range(2, ticks):
         for i in range(n):
             if rng.random() < 0.25:
                 fed[t][i] = _mutate(rng, fed[t][i], pool)
-    fed[4][3] = _coupled_unit(rng, si, aot, elems, cc_tags[:-1], at[:-1], points)      # a coupling element left out: refused
+    fed[4][3] = one(3, cc_tags[:-1], at[:-1])              # a coupling element left out: refused
     pl = pkg.LayoutPipeline(m4, layout, n, threads=3)
-    assert pl.ch == nch and pl.len == 1024
+    assert pl.ch == nch and pl.len == length
     got, status = [], []
     for t in range(ticks):
         status.append(np.array(pl.submit(fed[t])).copy())
@@ -298,8 +315,9 @@ def test_layout_pipeline_with_coupling_elements_equals_one_codec_context_per_str
                 continue
             if status[t][i] == -3:
                 break                   # (a damaged unit moved an element: the pipeline wants one order for all its streams)
-            assert status[t][i] == 0 and size.value == 1024 * nch * 2, (name, i, t, int(status[t][i]))
-            pcm = np.frombuffer(out, np.int16, 1024 * nch).reshape(1024, nch)
+            # (a negative status with samples: an SBR payload that failed behind a damaged unit -- SBR off for the unit)
+            assert size.value == length * nch * 2, (name, i, t, int(status[t][i]))
+            pcm = np.frombuffer(out, np.int16, length * nch).reshape(length, nch)
             assert np.array_equal(pcm, got[t][i]), (name, i, t, np.argwhere(pcm != got[t][i])[:3])
             decoded += 1
         assert lib.heaac_codec_close(C.byref(ctx)) == 0
