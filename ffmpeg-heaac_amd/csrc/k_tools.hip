@@ -6,17 +6,16 @@
 // sit in LDS.  M/S and intensity walk the scalefactor bands in the reference's order
 // (band conditions are wave-uniform) with the lanes spread over a band's coefficients.
 // TNS is an all-pole recursion along frequency -- serial by nature -- so one lane runs one
-// (channel, window): 2 lanes for long windows, 16 for eight short ones.  Every difference
-// and product is the reference's, in its order.
+// (channel, window, filter) with the recursion's state in its registers: up to 6 lanes for long
+// windows, 16 for eight short ones.  Every difference and product is the reference's, in its order.
 #include "k_common.h"
 #include "kernels.h"
 
-#define TL_WAVES 8
+#define TL_WAVES 10
 
 struct ToolsWave {
     float coef[2][1024];
     HeaacToolsFrame t;
-    float lpc[16][HEAAC_TNS_MAX_ORDER];      // per (channel, window) lane
 };
 
 // lcg_random (aacdec.c:502-505) j steps ahead: x -> mulA[j] * x + addC[j]  (mod 2^32)
@@ -24,83 +23,120 @@ struct ToolsWave {
 struct LcgSkip { unsigned mulA[LCG_SKIP], addC[LCG_SKIP]; };
 
 // The NOISE_BT branch of decode_spectrum_and_dequant (aacdec.c:1003-1029) for one channel.
-// The generator is sequential in the reference; element k of a band is k + 1 steps ahead of
-// the state at the band's start, so the lanes jump there directly.  The band energy is the
-// reference's left-to-right sum (every lane forms it from LDS).
+// The generator is sequential in the reference, but a band's start state only depends on how many numbers the bands in
+// front of it draw: x -> A x + C maps compose (mod 2^32), so every lane forms the map of ITS band (idx = g * max_sfb +
+// sfb: group_len * width draws for a noise band, the identity otherwise), a prefix scan over the lanes gives each
+// band the state it starts from, and the bands run side by side -- each lane draws its band's numbers window by
+// window, sums the energy left to right as scalarproduct_float_c does, and scales (:1016-1029).
+struct Affine { unsigned a, c; };           // x -> a x + c
+__device__ __forceinline__ Affine after(Affine first, Affine then) { return Affine{ then.a * first.a, then.a * first.c + then.c }; }
+
 __device__ __forceinline__ unsigned tools_pns(ToolsWave &w, const LcgSkip &K, int ch, unsigned rs, int lane)
 {
     const HeaacToolsIcs &ics = w.t.ch[ch].ics;
     float *coef = w.coef[ch];
-    int idx = 0, base = 0;
-    for (int g = 0; g < ics.num_window_groups; g++) {
-        const int glen = ics.group_len[g];
-        for (int i = 0; i < ics.max_sfb; i++, idx++) {
-            if (w.t.ch[ch].band_type[idx] != HEAAC_NOISE_BT) continue;
-            const int o = ics.swb_offset[i], len = ics.swb_offset[i + 1] - o;
+    const int ng = ics.num_window_groups < 8 ? ics.num_window_groups : 8;
+    const int nb = ng * ics.max_sfb < 128 ? ng * ics.max_sfb : 128;
+    for (int first = 0; first < nb; first += WAVE) {                 // (at most two rounds: 120 bands)
+        const int idx = first + lane;
+        const bool mine = idx < nb && w.t.ch[ch].band_type[idx] == HEAAC_NOISE_BT;
+        int g = 0, i = 0, glen = 0, o = 0, len = 0, base = 0;
+        if (mine) {
+            g = idx / ics.max_sfb; i = idx - g * ics.max_sfb;
+            for (int q = 0; q < g; q++) base += ics.group_len[q] * 128;
+            glen = ics.group_len[g];
+            o = ics.swb_offset[i];
+            len = ics.swb_offset[i + 1] - o;
+            // (a record no band table gives must not become an address outside the channel's 1024 lines: nothing drawn)
+            if (len < 0 || len >= LCG_SKIP || glen < 1 || glen > 8 || base + (glen - 1) * 128 + o + len > 1024) len = 0;
+        }
+        // this band's map: glen times the map of `len` draws
+        Affine m = { 1u, 0u };
+        const Affine one = { K.mulA[len], K.addC[len] };
+        for (int q = 0; q < glen; q++) m = after(m, one);
+        // inclusive scan over the lanes
+        Affine p = m;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const unsigned oa = __shfl_up(p.a, off), oc = __shfl_up(p.c, off);
+            if (lane >= off) p = after(Affine{ oa, oc }, p);
+        }
+        // the state this band starts from: the lanes in front of it, applied to the state the round starts from
+        unsigned ea = __shfl_up(p.a, 1), ec = __shfl_up(p.c, 1);
+        if (lane == 0) { ea = 1u; ec = 0u; }
+        unsigned r = ea * rs + ec;
+        const unsigned ta = __shfl(p.a, WAVE - 1), tc = __shfl(p.c, WAVE - 1);
+        rs = ta * rs + tc;                                            // ... and the state the next round (or channel) starts from
+        if (mine && len > 0) {
             const float sf = w.t.ch[ch].sf[idx];
             for (int group = 0; group < glen; group++) {
                 float *cfo = coef + base + group * 128 + o;
-                for (int k = lane; k < len; k += WAVE)
-                    cfo[k] = (float)(int)(K.mulA[k + 1] * rs + K.addC[k + 1]);
-                rs = K.mulA[len] * rs + K.addC[len];
-                wave_sync();
                 float band_energy = 0.0f;
-                for (int k = 0; k < len; k++) band_energy += cfo[k] * cfo[k];
+                for (int k = 0; k < len; k++) {
+                    r = r * 1664525u + 1013904223u;
+                    const float v = (float)(int)r;
+                    cfo[k] = v;
+                    band_energy += v * v;
+                }
                 const float scale = sf / sqrtf(band_energy);
-                wave_sync();
-                for (int k = lane; k < len; k += WAVE) cfo[k] = cfo[k] * scale;
+                for (int k = 0; k < len; k++) cfo[k] = cfo[k] * scale;
             }
         }
-        base += glen * 128;
     }
     wave_sync();
     return rs;
 }
 
+// Where band idx = g * max_sfb + sfb of a channel's grouping lies: its first line, its width, the windows of its
+// group.  A record no band table gives (lines beyond the channel's 1024) yields len = 0.
+struct BandPlace { int first, len, glen; };
+__device__ __forceinline__ BandPlace band_place(const HeaacToolsIcs &ics, int idx)
+{
+    const int g = idx / ics.max_sfb, i = idx - g * ics.max_sfb;
+    int base = 0;
+    for (int q = 0; q < g && q < 8; q++) base += ics.group_len[q] * 128;
+    BandPlace b = { base + ics.swb_offset[i], ics.swb_offset[i + 1] - ics.swb_offset[i], g < 8 ? ics.group_len[g] : 0 };
+    if (b.len < 0 || b.glen < 1 || b.glen > 8 || b.first + (b.glen - 1) * 128 + b.len > 1024) b.len = 0;
+    return b;
+}
+
+// apply_mid_side_stereo (aacdec.c:1390-1411) and apply_intensity_stereo (:1420-1451) touch every band on its own:
+// one lane per band (two rounds for up to 120 of them), each walking its band's lines window by window.
 __device__ __forceinline__ void tools_mid_side(ToolsWave &w, int lane)
 {
     const HeaacToolsIcs &ics = w.t.ch[0].ics;
-    int idx = 0, base = 0;
-    for (int g = 0; g < ics.num_window_groups; g++) {
-        const int glen = ics.group_len[g];
-        for (int i = 0; i < ics.max_sfb; i++, idx++) {
-            if (w.t.ms_mask[idx] && w.t.ch[0].band_type[idx] < HEAAC_NOISE_BT &&
-                w.t.ch[1].band_type[idx] < HEAAC_NOISE_BT) {
-                const int o = ics.swb_offset[i], len = ics.swb_offset[i + 1] - o;
-                for (int e = lane; e < glen * len; e += WAVE) {
-                    const int group = e / len, k = e - group * len;
-                    const int p = base + group * 128 + o + k;
-                    const float a = w.coef[0][p], b = w.coef[1][p];     // butterflies_float_c
-                    w.coef[0][p] = a + b;
-                    w.coef[1][p] = a - b;
-                }
+    const int ng = ics.num_window_groups < 8 ? ics.num_window_groups : 8;
+    const int nb = ng * ics.max_sfb < 128 ? ng * ics.max_sfb : 128;
+    for (int idx = lane; idx < nb; idx += WAVE) {
+        if (!(w.t.ms_mask[idx] && w.t.ch[0].band_type[idx] < HEAAC_NOISE_BT && w.t.ch[1].band_type[idx] < HEAAC_NOISE_BT)) continue;
+        const BandPlace b = band_place(ics, idx);
+        for (int group = 0; group < b.glen; group++)
+            for (int k = 0; k < b.len; k++) {
+                const int p = b.first + group * 128 + k;
+                const float x = w.coef[0][p], y = w.coef[1][p];         // butterflies_float_c
+                w.coef[0][p] = x + y;
+                w.coef[1][p] = x - y;
             }
-        }
-        base += glen * 128;
     }
 }
 
 __device__ __forceinline__ void tools_intensity(ToolsWave &w, int lane)
 {
     const HeaacToolsIcs &ics = w.t.ch[1].ics;
-    int idx = 0, base = 0;
-    for (int g = 0; g < ics.num_window_groups; g++) {
-        const int glen = ics.group_len[g];
-        for (int i = 0; i < ics.max_sfb; i++, idx++) {
-            const int bt = w.t.ch[1].band_type[idx];
-            if (bt == HEAAC_INTENSITY_BT || bt == HEAAC_INTENSITY_BT2) {
-                int c = -1 + 2 * (bt - 14);
-                if (w.t.ms_present) c *= 1 - 2 * w.t.ms_mask[idx];
-                const float scale = c * w.t.ch[1].sf[idx];
-                const int o = ics.swb_offset[i], len = ics.swb_offset[i + 1] - o;
-                for (int e = lane; e < glen * len; e += WAVE) {
-                    const int group = e / len, k = e - group * len;
-                    const int p = base + group * 128 + o + k;
-                    w.coef[1][p] = scale * w.coef[0][p];
-                }
+    const int ng = ics.num_window_groups < 8 ? ics.num_window_groups : 8;
+    const int nb = ng * ics.max_sfb < 128 ? ng * ics.max_sfb : 128;
+    for (int idx = lane; idx < nb; idx += WAVE) {
+        const int bt = w.t.ch[1].band_type[idx];
+        if (bt != HEAAC_INTENSITY_BT && bt != HEAAC_INTENSITY_BT2) continue;
+        int c = -1 + 2 * (bt - 14);
+        if (w.t.ms_present) c *= 1 - 2 * w.t.ms_mask[idx];
+        const float scale = c * w.t.ch[1].sf[idx];
+        const BandPlace b = band_place(ics, idx);
+        for (int group = 0; group < b.glen; group++)
+            for (int k = 0; k < b.len; k++) {
+                const int p = b.first + group * 128 + k;
+                w.coef[1][p] = scale * w.coef[0][p];
             }
-        }
-        base += glen * 128;
     }
 }
 
@@ -166,45 +202,174 @@ __device__ __forceinline__ void tools_prediction(ToolsWave &w, int ch, const Hea
     wave_sync();
 }
 
-// one lane = window `win` of channel `ch`
-__device__ __forceinline__ void tools_tns_window(ToolsWave &w, int ch, int win, float *lpc)
+// The all-pole filter of one TNS filter (apply_tns, aacdec.c:1722-1733) over its `size` lines from `start` in steps of
+// `inc`: every output is the input minus the last min(m, order) OUTPUTS times the LPC coefficients, subtracted one
+// product at a time in the reference's order.  The recursion is serial; what the lane can do is keep it out of the
+// LDS: coefficients and the last MAXORD outputs live in registers, the next input is on its way while the chain of
+// the current one runs.  (Terms beyond min(m, order) are skipped, not fed zeros: x - (-0) would turn a -0 into +0.)
+template <int MAXORD>
+__device__ __forceinline__ void tns_ar(float *coef, int start, int inc, int size, int order, const float *tcoef)
 {
-    const HeaacTns &tns = w.t.ch[ch].tns;
-    const HeaacToolsIcs &ics = w.t.ch[ch].ics;
-    float *coef = w.coef[ch];
-    const int mmm = ics.tns_max_bands < ics.max_sfb ? ics.tns_max_bands : ics.max_sfb;
-    int bottom = ics.num_swb;
-    for (int filt = 0; filt < tns.n_filt[win]; filt++) {
-        const int top = bottom;
-        bottom = top - tns.length[win][filt] > 0 ? top - tns.length[win][filt] : 0;
-        const int order = tns.order[win][filt];
-        if (order == 0) continue;
-        // compute_lpc_coefs(coef, order, lpc, 0, 0, 0)
-        for (int i = 0; i < order; i++) {
-            const float r = -tns.coef[win][filt][i];
+    // compute_lpc_coefs(coef, order, lpc, 0, 0, 0)  (lpc.h:61-103, LPC_TYPE float, no normalisation)
+    float lpc[MAXORD], h[MAXORD];
+#pragma unroll
+    for (int i = 0; i < MAXORD; i++) { lpc[i] = 0.0f; h[i] = 0.0f; }
+#pragma unroll
+    for (int i = 0; i < MAXORD; i++) {
+        if (i < order) {
+            const float r = -tcoef[i];
             lpc[i] = r;
+#pragma unroll
             for (int j = 0; j < (i + 1) >> 1; j++) {
                 const float f = lpc[j], b = lpc[i - 1 - j];
                 lpc[j]         = f + r * b;
                 lpc[i - 1 - j] = b + r * f;
             }
         }
-        int start = ics.swb_offset[bottom < mmm ? bottom : mmm];
-        const int end = ics.swb_offset[top < mmm ? top : mmm];
-        const int size = end - start;
-        if (size <= 0) continue;
-        int inc = 1;
-        if (tns.direction[win][filt]) { inc = -1; start = end - 1; }
-        start += win * 128;
-        // ar filter
-        for (int m = 0; m < size; m++, start += inc) {
-            float acc = coef[start];
-            const int lim = m < order ? m : order;
-            for (int i = 1; i <= lim; i++)
-                acc -= coef[start - i * inc] * lpc[i - 1];
-            coef[start] = acc;
+    }
+    float nxt = coef[start];
+    for (int m = 0; m < size; m++, start += inc) {
+        float acc = nxt;
+        if (m + 1 < size) nxt = coef[start + inc];
+        const int lim = m < order ? m : order;
+#pragma unroll
+        for (int i = 1; i <= MAXORD; i++)
+            if (i <= lim) acc -= h[i - 1] * lpc[i - 1];
+        coef[start] = acc;
+#pragma unroll
+        for (int i = MAXORD - 1; i > 0; i--) h[i] = h[i - 1];
+        h[0] = acc;
+    }
+}
+
+// The same recursion for 64 different (frame, channel) units at once, one per lane, straight on the spectra in global
+// memory: this is what the stand-alone TNS pass runs (k_tns below).  `on`: this lane has a filter in this round;
+// rounds are as long as the wave's longest filter.
+template <int MAXORD>
+__device__ __forceinline__ void tns_ar_lanes(float *coef, bool on, int start, int inc, int size, int order, const float *tcoef,
+                                             int max_size)
+{
+    float lpc[MAXORD], h[MAXORD];
+#pragma unroll
+    for (int i = 0; i < MAXORD; i++) { lpc[i] = 0.0f; h[i] = 0.0f; }
+#pragma unroll
+    for (int i = 0; i < MAXORD; i++) {
+        if (on && i < order) {
+            const float r = -tcoef[i];
+            lpc[i] = r;
+#pragma unroll
+            for (int j = 0; j < (i + 1) >> 1; j++) {
+                const float f = lpc[j], b = lpc[i - 1 - j];
+                lpc[j]         = f + r * b;
+                lpc[i - 1 - j] = b + r * f;
+            }
         }
     }
+    float nxt = on ? coef[start] : 0.0f;
+    for (int m = 0; m < max_size; m++, start += inc) {
+        const bool here = on && m < size;
+        float acc = nxt;
+        if (on && m + 1 < size) nxt = coef[start + inc];
+        const int lim = m < order ? m : order;
+#pragma unroll
+        for (int i = 1; i <= MAXORD; i++)
+            if (i <= lim) acc -= h[i - 1] * lpc[i - 1];
+        if (here) coef[start] = acc;
+#pragma unroll
+        for (int i = MAXORD - 1; i > 0; i--) h[i] = h[i - 1];
+        h[0] = acc;
+    }
+}
+
+__device__ __forceinline__ int wave_max(int v)
+{
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const int o = __shfl_xor(v, off);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// apply_tns (aacdec.c:1698-1736) as a pass of its own: one lane = one of the (up to three) filters a window of one
+// channel of one frame can have -- the filters of a window work on disjoint line ranges, each from its `top` down over
+// `length` bands, the next one below it (:1707-1712) -- and every window round is wave-uniform (lanes without a filter
+// there sit it out).  One frame per wave leaves 58 to 63 lanes idle for the whole recursion, which was most of what the
+// spectral tools cost (profiles/r04_experiments.md E8).
+#define TNS_FILTERS 3              // n_filt is two bits for a long window (0 .. 3), one for a short one
+template <int CH>
+__global__ __launch_bounds__(256)
+void k_tns(float *g_coeffs, const HeaacToolsFrame *__restrict__ g_tools, unsigned long long n)
+{
+    const unsigned long long u = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = u < n * CH * TNS_FILTERS;
+    const unsigned long long f = live ? u / (CH * TNS_FILTERS) : 0;
+    const int r = live ? (int)(u - f * (CH * TNS_FILTERS)) : 0;
+    const int ch = r / TNS_FILTERS, filt = r - ch * TNS_FILTERS;
+    const HeaacToolsChannel &t = g_tools[f].ch[ch];
+    const HeaacTns &tns = t.tns;
+    const HeaacToolsIcs &ics = t.ics;
+    const bool has = live && tns.present;
+    if (wave_max(has) == 0) return;
+    float *coef = g_coeffs + (f * CH + ch) * 1024;
+    const int num_windows = has ? (ics.num_windows == 8 ? 8 : 1) : 0;
+    const int mmm = ics.tns_max_bands < ics.max_sfb ? ics.tns_max_bands : ics.max_sfb;
+    const int windows = wave_max(num_windows);
+    for (int win = 0; win < windows; win++) {
+        bool on = win < num_windows && filt < tns.n_filt[win];
+        int order = 0, start = 0, size = 0, inc = 1;
+        if (on) {
+            int bottom = ics.num_swb, top = bottom;
+            for (int q = 0; q <= filt; q++) {
+                top = bottom;
+                bottom = top - tns.length[win][q] > 0 ? top - tns.length[win][q] : 0;
+            }
+            order = tns.order[win][filt];
+            if (order > HEAAC_TNS_MAX_ORDER) order = HEAAC_TNS_MAX_ORDER;
+            start = ics.swb_offset[bottom < mmm ? bottom : mmm];
+            const int end = ics.swb_offset[top < mmm ? top : mmm];
+            size = end - start;
+            if (tns.direction[win][filt]) { inc = -1; start = end - 1; }
+            start += win * 128;
+            // (a record no band table gives must not become an address outside the channel's 1024 lines)
+            if (order == 0 || size <= 0 || start < 0 || start >= 1024 || start + inc * (size - 1) < 0 || start + inc * (size - 1) >= 1024) {
+                on = false; size = 0; order = 0;
+            }
+        }
+        const int max_size = wave_max(size), max_order = wave_max(order);
+        if (max_size == 0) continue;
+        const float *tc = tns.coef[win][filt];
+        if (max_order <= 7)       tns_ar_lanes<7>(coef, on, start, inc, size, order, tc, max_size);
+        else if (max_order <= 12) tns_ar_lanes<12>(coef, on, start, inc, size, order, tc, max_size);
+        else                      tns_ar_lanes<HEAAC_TNS_MAX_ORDER>(coef, on, start, inc, size, order, tc, max_size);
+    }
+}
+
+// one lane = filter `filt` of window `win` of channel `ch`: the filters of a window work on disjoint line ranges
+// (each from its `top` down over `length` bands, the next one below it, :1707-1712), so they run side by side
+__device__ __forceinline__ void tools_tns_filter(ToolsWave &w, int ch, int win, int filt)
+{
+    const HeaacTns &tns = w.t.ch[ch].tns;
+    const HeaacToolsIcs &ics = w.t.ch[ch].ics;
+    const int mmm = ics.tns_max_bands < ics.max_sfb ? ics.tns_max_bands : ics.max_sfb;
+    int bottom = ics.num_swb, top = bottom;
+    for (int f = 0; f <= filt; f++) {
+        top = bottom;
+        bottom = top - tns.length[win][f] > 0 ? top - tns.length[win][f] : 0;
+    }
+    const int order = tns.order[win][filt];
+    if (order == 0) return;
+    int start = ics.swb_offset[bottom < mmm ? bottom : mmm];
+    const int end = ics.swb_offset[top < mmm ? top : mmm];
+    const int size = end - start;
+    if (size <= 0) return;
+    int inc = 1;
+    if (tns.direction[win][filt]) { inc = -1; start = end - 1; }
+    start += win * 128;
+    const float *tc = tns.coef[win][filt];
+    if (order <= 7)       tns_ar<7>(w.coef[ch], start, inc, size, order, tc);
+    else if (order <= 12) tns_ar<12>(w.coef[ch], start, inc, size, order, tc);
+    else                  tns_ar<HEAAC_TNS_MAX_ORDER>(w.coef[ch], start, inc, size, order < HEAAC_TNS_MAX_ORDER ? order : HEAAC_TNS_MAX_ORDER, tc);
 }
 
 // apply_channel_coupling (aacdec.c:1870-1898) with apply_dependent_coupling (:1813-1843) at one coupling point:
@@ -308,10 +473,10 @@ void k_spectral_tools(float *g_coeffs, const HeaacToolsFrame *__restrict__ g_too
             if (n_cce)
                 tools_dependent_coupling<CH>(w, g_cce + f * n_cce, g_cce_coeffs + f * n_cce * 1024, n_cce,
                                              HEAAC_CC_BEFORE_TNS, lane);
-            // lane -> (channel, window)
-            const int ch = lane >> 3, win = lane & 7;
-            if (ch < CH && w.t.ch[ch].tns.present && win < w.t.ch[ch].ics.num_windows)
-                tools_tns_window(w, ch, win, w.lpc[lane]);
+            // lane -> (channel, window, filter)
+            const int ch = lane >> 5, win = (lane >> 2) & 7, filt = lane & 3;
+            if (ch < CH && w.t.ch[ch].tns.present && win < w.t.ch[ch].ics.num_windows && filt < w.t.ch[ch].tns.n_filt[win])
+                tools_tns_filter(w, ch, win, filt);
             wave_sync();
             if (n_cce)
                 tools_dependent_coupling<CH>(w, g_cce + f * n_cce, g_cce_coeffs + f * n_cce * 1024, n_cce,
@@ -335,17 +500,28 @@ extern "C" int heaac_launch_spectral_tools(int channels, float *d_coeffs, const 
                                            size_t n, hipStream_t s)
 {
     if (n == 0) return HEAAC_OK;
+    if (channels != 1 && channels != 2) return HEAAC_ERR_ARG;
     unsigned long long g = (n + TL_WAVES - 1) / TL_WAVES;
     if (g > 256) g = 256;
-    if (channels == 2)
-        hipLaunchKernelGGL(k_spectral_tools<2>, dim3((unsigned)g), dim3(TL_WAVES * WAVE), 0, s, d_coeffs, d_tools,
-                           d_rng_in, d_rng_out, d_pred_in, d_pred_out, stages, d_cce, d_cce_coeffs, n_cce,
-                           (unsigned long long)n);
-    else if (channels == 1)
-        hipLaunchKernelGGL(k_spectral_tools<1>, dim3((unsigned)g), dim3(TL_WAVES * WAVE), 0, s, d_coeffs, d_tools,
-                           d_rng_in, d_rng_out, d_pred_in, d_pred_out, stages, d_cce, d_cce_coeffs, n_cce,
-                           (unsigned long long)n);
-    else
-        return HEAAC_ERR_ARG;
+    // Without coupling elements the second half is TNS alone: it runs as a pass of its own, one lane per channel of a
+    // frame (k_tns), behind the first half.  With them it stays inside the frame's wave, between the two coupling points.
+    const bool tns_pass = (stages & HEAAC_TOOLS_POST) && n_cce == 0;
+    const int in_wave = tns_pass ? (stages & ~HEAAC_TOOLS_POST) : stages;
+    if (in_wave) {
+        if (channels == 2)
+            hipLaunchKernelGGL(k_spectral_tools<2>, dim3((unsigned)g), dim3(TL_WAVES * WAVE), 0, s, d_coeffs, d_tools,
+                               d_rng_in, d_rng_out, d_pred_in, d_pred_out, in_wave, d_cce, d_cce_coeffs, n_cce,
+                               (unsigned long long)n);
+        else
+            hipLaunchKernelGGL(k_spectral_tools<1>, dim3((unsigned)g), dim3(TL_WAVES * WAVE), 0, s, d_coeffs, d_tools,
+                               d_rng_in, d_rng_out, d_pred_in, d_pred_out, in_wave, d_cce, d_cce_coeffs, n_cce,
+                               (unsigned long long)n);
+    }
+    if (tns_pass) {
+        const unsigned long long units = (unsigned long long)n * channels * TNS_FILTERS, blocks = (units + 255) / 256;
+        if (blocks > 0x7fffffffull) return HEAAC_ERR_ARG;
+        if (channels == 2) hipLaunchKernelGGL(k_tns<2>, dim3((unsigned)blocks), dim3(256), 0, s, d_coeffs, d_tools, (unsigned long long)n);
+        else               hipLaunchKernelGGL(k_tns<1>, dim3((unsigned)blocks), dim3(256), 0, s, d_coeffs, d_tools, (unsigned long long)n);
+    }
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
 }
