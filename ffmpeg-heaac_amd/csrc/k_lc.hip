@@ -338,7 +338,10 @@ void k_couple(float *__restrict__ g_pcm, const float *__restrict__ g_cce, const 
 // ---------------------------------------------------------------------------
 // k_interleave: float_to_int16_interleave (dsputil.c:3989-4001) for the planes of a channel layout, elementwise and
 // HBM-bound: one lane = four consecutive samples of one frame in every channel (a float4 per plane in, 8 x channels
-// consecutive bytes out; neighbouring lanes write neighbouring pieces).
+// consecutive bytes out; neighbouring lanes write neighbouring pieces).  For up to eight channels the lane packs its
+// 4 x channels samples in registers and writes them as `channels` 8-byte stores (k_interleave_packed: 24 two-byte
+// stores per lane for 5.1 took 2.9 ms per 65 536 frames of 2048 samples, 0.21 of the roofline --
+// profiles/r04_experiments.md E9); more channels take the sample-by-sample form.
 // ---------------------------------------------------------------------------
 struct PlaneArgs {
     const float *base[HEAAC_MAX_PCM_PLANES];
@@ -363,6 +366,47 @@ void k_interleave(PlaneArgs p, int channels, int len, int16_t *__restrict__ g_ou
     }
 }
 
+template <int FMT, int CH>
+__global__ __launch_bounds__(256)
+void k_interleave_packed(PlaneArgs p, int len, int16_t *__restrict__ g_out, unsigned long long n)
+{
+    const unsigned long long quads = (unsigned long long)(len >> 2);
+    const unsigned long long t = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long f = t / quads;
+    if (f >= n) return;
+    const unsigned long long q = t - f * quads;
+    // sample k of channel c is int16 number k * CH + c of the lane's 4 * CH: two to a dword, four to a store
+    unsigned half[4 * CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const float4 v = *reinterpret_cast<const float4 *>(p.base[c] + f * p.stride[c] + 4 * q);
+        half[c]          = (unsigned)(unsigned short)(int16_t)pcm_int16<FMT>(v.x);
+        half[CH + c]     = (unsigned)(unsigned short)(int16_t)pcm_int16<FMT>(v.y);
+        half[2 * CH + c] = (unsigned)(unsigned short)(int16_t)pcm_int16<FMT>(v.z);
+        half[3 * CH + c] = (unsigned)(unsigned short)(int16_t)pcm_int16<FMT>(v.w);
+    }
+    uint2 *o = reinterpret_cast<uint2 *>(g_out + (f * (unsigned long long)len + 4 * q) * CH);      // 8 * CH bytes per lane: 8-byte aligned
+#pragma unroll
+    for (int j = 0; j < CH; j++)
+        o[j] = make_uint2(half[4 * j] | (half[4 * j + 1] << 16), half[4 * j + 2] | (half[4 * j + 3] << 16));
+}
+
+template <int FMT>
+static bool launch_interleave_packed(const PlaneArgs &a, int channels, int len, int16_t *d_out, size_t n, unsigned blocks, hipStream_t stream)
+{
+    switch (channels) {
+    case 1: k_interleave_packed<FMT, 1><<<blocks, 256, 0, stream>>>(a, len, d_out, n); return true;
+    case 2: k_interleave_packed<FMT, 2><<<blocks, 256, 0, stream>>>(a, len, d_out, n); return true;
+    case 3: k_interleave_packed<FMT, 3><<<blocks, 256, 0, stream>>>(a, len, d_out, n); return true;
+    case 4: k_interleave_packed<FMT, 4><<<blocks, 256, 0, stream>>>(a, len, d_out, n); return true;
+    case 5: k_interleave_packed<FMT, 5><<<blocks, 256, 0, stream>>>(a, len, d_out, n); return true;
+    case 6: k_interleave_packed<FMT, 6><<<blocks, 256, 0, stream>>>(a, len, d_out, n); return true;
+    case 7: k_interleave_packed<FMT, 7><<<blocks, 256, 0, stream>>>(a, len, d_out, n); return true;
+    case 8: k_interleave_packed<FMT, 8><<<blocks, 256, 0, stream>>>(a, len, d_out, n); return true;
+    default: return false;
+    }
+}
+
 extern "C" int heaac_launch_interleave(int channels, const HeaacPlaneRef *planes, int len, int pcm_format,
                                        int16_t *d_out, size_t n, hipStream_t stream)
 {
@@ -371,6 +415,11 @@ extern "C" int heaac_launch_interleave(int channels, const HeaacPlaneRef *planes
     const unsigned long long lanes = (unsigned long long)n * (unsigned)(len >> 2);
     const unsigned long long blocks = (lanes + 255) / 256;
     if (blocks > 0x7fffffffull) return HEAAC_ERR_ARG;
+    if (((uintptr_t)d_out & 7) == 0 &&                  // (the packed form writes 8-byte words)
+        (pcm_format == HEAAC_PCM_S16_INTERLEAVED_SSE2
+            ? launch_interleave_packed<HEAAC_PCM_S16_INTERLEAVED_SSE2>(a, channels, len, d_out, n, (unsigned)blocks, stream)
+            : launch_interleave_packed<HEAAC_PCM_S16_INTERLEAVED>(a, channels, len, d_out, n, (unsigned)blocks, stream)))
+        return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
     if (pcm_format == HEAAC_PCM_S16_INTERLEAVED_SSE2)
         k_interleave<HEAAC_PCM_S16_INTERLEAVED_SSE2><<<(unsigned)blocks, 256, 0, stream>>>(a, channels, len, d_out, n);
     else
