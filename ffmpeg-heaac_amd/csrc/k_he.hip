@@ -630,10 +630,11 @@ void k_qmf_synthesis(const float *__restrict__ g_tab, const float *__restrict__ 
 // the slots' 128-point IMDCTs (one per slot), then every lane forms two output samples per pass:
 // lane = (slot parity, n).
 #define DS_STRIDE 65
+#define DS_WAVES 8                // two waves per SIMD (212 - 256 VGPRs); 10.7 KB of LDS each
 struct SynDsLds {
     float win[320];               // sbr_qmf_window_ds
     float rot[64], c16[8], c32[12];
-    float vb[SYN_WAVES][41 * DS_STRIDE];
+    float vb[DS_WAVES][41 * DS_STRIDE];
 };
 __device__ __forceinline__ void syn_ds_lds_init(SynDsLds &S, const float *g_tab)
 {
@@ -654,18 +655,54 @@ __device__ __forceinline__ void synth_ds_channel(const SynDsLds &S, float *vb, c
 {
     // history: 9 slots of 64 behind the 32 new ones
     for (int t = lane; t < 576; t += WAVE) vb[(32 + (t >> 6)) * DS_STRIDE + (t & 63)] = v_in[t];
-    if (lane < 32) {
-        const int i = lane;
-        const float *r0 = PLANES ? X0 + i * 64 : X0 + i * 128, *r1 = PLANES ? X1 + i * 64 : X0 + i * 128 + 1;
-        constexpr int step = PLANES ? 1 : 2;
-        float o[64];
-        // X[0][i][n] = -X[0][i][n]; X[0][i][32+n] = X[1][i][31-n]
-        imdct128_reg([&](int j) -> float { return j < 32 ? -r0[step * j] : r1[step * (63 - j)]; }, o, S.rot, S.c16, S.c32);
-        float *v = vb + (31 - i) * DS_STRIDE;
+    if constexpr (PLANES) {
+        if (lane < 32) {
+            const int i = lane;
+            const float *r0 = X0 + i * 64, *r1 = X1 + i * 64;
+            float o[64];
+            // X[0][i][n] = -X[0][i][n]; X[0][i][32+n] = X[1][i][31-n]
+            imdct128_reg([&](int j) -> float { return j < 32 ? -r0[j] : r1[63 - j]; }, o, S.rot, S.c16, S.c32);
+            float *v = vb + (31 - i) * DS_STRIDE;
 #pragma unroll
-        for (int k = 0; k < 32; k++) {
-            v[k]      =  o[63 - 2 * k];
-            v[63 - k] = -o[62 - 2 * k];
+            for (int k = 0; k < 32; k++) {
+                v[k]      =  o[63 - 2 * k];
+                v[63 - k] = -o[62 - 2 * k];
+            }
+        }
+    } else {
+        // The workspace rows [slot][band][re, im]: bands 0..31 of the 32 slots are 32 x 256 bytes.  The wave fetches
+        // them together, 16 bytes per lane and load (a lane walking its own row pulls every line through the vector
+        // L1 sixteen times; -4 % kernel time, r04_experiments.md E9), and hands each slot's row to the slot's lane
+        // through the v rows' memory, which is free until then.
+        {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(X0);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int piece = lane + 64 * q, slot = piece >> 4, part = piece & 15;
+                const f32x4 t = src[slot * 32 + part];          // row stride 128 floats = 32 pieces; the first 16 hold bands 0..31
+                float *d = vb + slot * DS_STRIDE + 4 * part;
+                d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+            }
+        }
+        wave_sync();
+        float x[64];
+        if (lane < 32) {
+            const float *row = vb + lane * DS_STRIDE;
+#pragma unroll
+            for (int j = 0; j < 64; j++) x[j] = row[j];
+        }
+        wave_sync();
+        if (lane < 32) {
+            const int i = lane;
+            float o[64];
+            // X[0][i][n] = -X[0][i][n]; X[0][i][32+n] = X[1][i][31-n]   (x[2 b] = re, x[2 b + 1] = im of band b)
+            imdct128_reg([&](int j) -> float { return j < 32 ? -x[2 * j] : x[2 * (63 - j) + 1]; }, o, S.rot, S.c16, S.c32);
+            float *v = vb + (31 - i) * DS_STRIDE;
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                v[k]      =  o[63 - 2 * k];
+                v[63 - k] = -o[62 - 2 * k];
+            }
         }
     }
     wave_sync();
@@ -688,7 +725,7 @@ __device__ __forceinline__ void synth_ds_channel(const SynDsLds &S, float *vb, c
     wave_sync();
 }
 
-__global__ __launch_bounds__(SYN_WAVES * WAVE)
+__global__ __launch_bounds__(DS_WAVES * WAVE)
 void k_qmf_synthesis_ds(const float *__restrict__ g_tab, const float *__restrict__ g_X /* [n][2][32][64] */,
                         const float *g_v_in, float *g_v_out, float *__restrict__ g_out,
                         float scale, float bias, unsigned long long n)
@@ -696,8 +733,8 @@ void k_qmf_synthesis_ds(const float *__restrict__ g_tab, const float *__restrict
     __shared__ SynDsLds S;
     syn_ds_lds_init(S, g_tab);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
-    for (unsigned long long u = (unsigned long long)blockIdx.x * SYN_WAVES + wave; u < n;
-         u += (unsigned long long)gridDim.x * SYN_WAVES) {
+    for (unsigned long long u = (unsigned long long)blockIdx.x * DS_WAVES + wave; u < n;
+         u += (unsigned long long)gridDim.x * DS_WAVES) {
         float *o = g_out + u * 1024;
         synth_ds_channel<true>(S, S.vb[wave], g_X + u * 4096, g_X + u * 4096 + 2048, g_v_in + u * 576, g_v_out + u * 576,
                          scale, bias, lane, [&](int i, int nn, float v) { o[32 * i + nn] = v; });
@@ -708,7 +745,7 @@ void k_qmf_synthesis_ds(const float *__restrict__ g_tab, const float *__restrict
 // aacsbr.c:1719, 1194-1203): one wave per frame, X from the stage workspace, 1024 samples per channel.
 // The ring state is the first 576 words of the channel's synthesis state; the rest passes through.
 template <int FMT>
-__global__ __launch_bounds__(SYN_WAVES * WAVE)
+__global__ __launch_bounds__(DS_WAVES * WAVE)
 void k_synth_ds(const float *__restrict__ g_tab, const float *g_X,
                 const float *g_state_in, float *g_state_out, int state_words, int off_syn0,
                 int nout, void *__restrict__ g_pcm, float scale, float bias, unsigned long long n_frames)
@@ -716,8 +753,8 @@ void k_synth_ds(const float *__restrict__ g_tab, const float *g_X,
     __shared__ SynDsLds S;
     syn_ds_lds_init(S, g_tab);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
-    for (unsigned long long f = (unsigned long long)blockIdx.x * SYN_WAVES + wave; f < n_frames;
-         f += (unsigned long long)gridDim.x * SYN_WAVES) {
+    for (unsigned long long f = (unsigned long long)blockIdx.x * DS_WAVES + wave; f < n_frames;
+         f += (unsigned long long)gridDim.x * DS_WAVES) {
         for (int ch = 0; ch < nout; ch++) {
             const float *X0 = g_X + (f * 2 + ch) * HE_X_CHANNEL, *X1 = nullptr;
             const float *v_in = g_state_in + f * state_words + off_syn0 + ch * HEAAC_ST_SYNTH;
@@ -815,7 +852,7 @@ extern "C" int heaac_launch_he(const float *d_tab, const uint16_t *d_rev, int cf
     }
     const float scale = -1024 * sf_scale, bias = simd ? 0.0f : HEAAC_ADD_BIAS;
     if (flags & HEAAC_HE_DOWNSAMPLED) {
-        const dim3 gd(he_grid(n, SYN_WAVES)), bd(SYN_WAVES * WAVE);
+        const dim3 gd(he_grid(n, DS_WAVES)), bd(DS_WAVES * WAVE);
         char *pcm = (char *)d_pcm + pcm_frame0 * nout * 1024 * (pcm_format == HEAAC_PCM_F32_PLANAR ? 4 : 2);
         if (pcm_format == HEAAC_PCM_F32_PLANAR)
             hipLaunchKernelGGL((k_synth_ds<HEAAC_PCM_F32_PLANAR>), gd, bd, 0, s, d_tab, d_ws_X, d_state_in, d_state_out,
@@ -870,7 +907,7 @@ extern "C" int heaac_launch_qmf_synthesis_ds(const float *d_tab, const float *d_
                                             size_t n, hipStream_t s)
 {
     if (n == 0) return HEAAC_OK;
-    hipLaunchKernelGGL(k_qmf_synthesis_ds, dim3(he_grid(n, SYN_WAVES)), dim3(SYN_WAVES * WAVE), 0, s,
+    hipLaunchKernelGGL(k_qmf_synthesis_ds, dim3(he_grid(n, DS_WAVES)), dim3(DS_WAVES * WAVE), 0, s,
                        d_tab, d_X, d_v_in, d_v_out, d_out, scale, bias, (unsigned long long)n);
     return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
 }
