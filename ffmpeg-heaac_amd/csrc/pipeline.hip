@@ -33,7 +33,23 @@ struct Set {
     float parse_ms;
     unsigned char *failed;          // [n] the stream's access unit of this tick did not parse (core element): 1, or 2 where
                                     // the spectral tools still have to move its noise generator / predictors
+    unsigned *h_list, *d_list;      // [2 n] (stream, parking row) pairs of the failed streams, pinned / device
 };
+
+// Rows of the failed streams to the parking area and back (or zeroed): one block per listed stream.  A tick with
+// thousands of damaged units costs a handful of launches, not six copies per stream (tools/damage_rate.py).
+//   mode 0: park[row] = rows[stream];  1: rows[stream] = park[row];  2: rows[stream] = 0
+__global__ void k_rows(const unsigned *__restrict__ list, unsigned *rows, unsigned *park, unsigned long long row_words, int mode)
+{
+    const unsigned stream = list[2 * blockIdx.x], slot = list[2 * blockIdx.x + 1];
+    unsigned *r = rows + stream * row_words;
+    unsigned *q = park ? park + slot * row_words : nullptr;
+    for (unsigned long long w = threadIdx.x; w < row_words; w += blockDim.x) {
+        if (mode == 0) q[w] = r[w];
+        else if (mode == 1) r[w] = q[w];
+        else r[w] = 0u;
+    }
+}
 
 struct HeaacPipeline {
     HeaacAacConfig aac;
@@ -170,8 +186,8 @@ extern "C" void heaac_pipeline_destroy(HeaacPipeline *p)
     if (p->out) (void)hipStreamSynchronize(p->out);
     for (int k = 0; k < PL_DEPTH; k++) {
         Set *s = &p->set[k];
-        void *h[] = { s->h_coeffs, s->h_ics, s->h_tools, s->h_sbr, s->h_ps, s->h_pcm };
-        void *d[] = { s->d_coeffs, s->d_ics, s->d_tools, s->d_sbr, s->d_ps, s->d_pcm };
+        void *h[] = { s->h_coeffs, s->h_ics, s->h_tools, s->h_sbr, s->h_ps, s->h_pcm, s->h_list };
+        void *d[] = { s->d_coeffs, s->d_ics, s->d_tools, s->d_sbr, s->d_ps, s->d_pcm, s->d_list };
         for (void *x : h) if (x) (void)hipHostFree(x);
         for (void *x : d) if (x) (void)hipFree(x);
         hipEvent_t ev[] = { s->in_start, s->in_done, s->run_done, s->out_done };
@@ -238,6 +254,7 @@ extern "C" int heaac_pipeline_create(HeaacPipeline **out, const HeaacAacConfig *
              (!with_ps || devmem((void **)&s->d_ps, n * sizeof(HeaacPsFrame))) &&
              devmem((void **)&s->d_pcm, n * (size_t)p->nout * p->out_len * 2) &&
              (s->failed = (unsigned char *)calloc(n, 1)) != NULL &&
+             pinned((void **)&s->h_list, 4 * n * sizeof(unsigned)) && devmem((void **)&s->d_list, 4 * n * sizeof(unsigned)) &&
              hipEventCreate(&s->in_start) == hipSuccess && hipEventCreate(&s->in_done) == hipSuccess &&
              hipEventCreate(&s->run_done) == hipSuccess && hipEventCreate(&s->out_done) == hipSuccess;
         if (ok) {
@@ -380,18 +397,28 @@ extern "C" int heaac_pipeline_submit(HeaacPipeline *p, const uint8_t *const *au,
             return HEAAC_ERR_NOMEM;
         p->park_rows = rows;
     }
+    // two lists of (stream, parking row): every failed stream (its DSP state, its PCM row), and those of them whose
+    // generator and predictors stay put as well (failed == 1; 2: the tools' side of the stream moves on)
+    unsigned n_all = 0, n_full = 0;
+    unsigned *list_all = s->h_list, *list_full = s->h_list + 2 * n;
     if (n_failed) {
-        size_t j = 0;
         for (size_t i = 0; i < n; i++) {
             if (!s->failed[i]) continue;
-            HIP_OK(hipMemcpyAsync(p->d_park_state + j * p->words, p->d_state + i * p->words, p->words * 4, hipMemcpyDeviceToDevice, p->run));
-            if (s->failed[i] == 2) { j++; continue; }       // the tools' side of the stream moves on
-            HIP_OK(hipMemcpyAsync(p->d_park_rng + j, p->d_rng + i, 4, hipMemcpyDeviceToDevice, p->run));
-            if (p->d_pred)
-                HIP_OK(hipMemcpyAsync(p->d_park_pred + j * pred_row, p->d_pred + i * pred_row, pred_row * sizeof(HeaacPredictorState),
-                                      hipMemcpyDeviceToDevice, p->run));
-            j++;
+            if (s->failed[i] == 1) { list_full[2 * n_full] = (unsigned)i; list_full[2 * n_full + 1] = n_all; n_full++; }
+            list_all[2 * n_all] = (unsigned)i; list_all[2 * n_all + 1] = n_all; n_all++;
         }
+        HIP_OK(hipMemcpyAsync(s->d_list, list_all, 2 * n_all * sizeof(unsigned), hipMemcpyHostToDevice, p->run));
+        if (n_full)
+            HIP_OK(hipMemcpyAsync(s->d_list + 2 * n, list_full, 2 * n_full * sizeof(unsigned), hipMemcpyHostToDevice, p->run));
+        hipLaunchKernelGGL(k_rows, dim3(n_all), dim3(256), 0, p->run, s->d_list, (unsigned *)p->d_state, (unsigned *)p->d_park_state,
+                           (unsigned long long)p->words, 0);
+        if (n_full) {
+            hipLaunchKernelGGL(k_rows, dim3(n_full), dim3(64), 0, p->run, s->d_list + 2 * n, (unsigned *)p->d_rng, (unsigned *)p->d_park_rng, 1ull, 0);
+            if (p->d_pred)
+                hipLaunchKernelGGL(k_rows, dim3(n_full), dim3(256), 0, p->run, s->d_list + 2 * n, (unsigned *)p->d_pred, (unsigned *)p->d_park_pred,
+                                   (unsigned long long)(pred_row * sizeof(HeaacPredictorState) / 4), 0);
+        }
+        HIP_OK(hipGetLastError());
     }
     int rc = heaac_spectral_tools_batch(p->dev, p->ncore, s->d_coeffs, s->d_tools, p->d_rng, p->d_rng, p->d_pred, p->d_pred, n,
                                         (void *)p->run);
@@ -404,19 +431,18 @@ extern "C" int heaac_pipeline_submit(HeaacPipeline *p, const uint8_t *const *au,
     if (rc != HEAAC_OK) return rc;
     // ... and put them back, with silence where the decode wrote
     if (n_failed) {
-        const size_t pcm_row = (size_t)p->nout * p->out_len;
-        size_t j = 0;
-        for (size_t i = 0; i < n; i++) {
-            if (!s->failed[i]) continue;
-            HIP_OK(hipMemcpyAsync(p->d_state + i * p->words, p->d_park_state + j * p->words, p->words * 4, hipMemcpyDeviceToDevice, p->run));
-            HIP_OK(hipMemsetAsync(s->d_pcm + i * pcm_row, 0, pcm_row * 2, p->run));
-            if (s->failed[i] == 2) { j++; continue; }
-            HIP_OK(hipMemcpyAsync(p->d_rng + i, p->d_park_rng + j, 4, hipMemcpyDeviceToDevice, p->run));
+        const size_t pcm_row = (size_t)p->nout * p->out_len;           // int16: an even count, so whole 32-bit words
+        hipLaunchKernelGGL(k_rows, dim3(n_all), dim3(256), 0, p->run, s->d_list, (unsigned *)p->d_state, (unsigned *)p->d_park_state,
+                           (unsigned long long)p->words, 1);
+        hipLaunchKernelGGL(k_rows, dim3(n_all), dim3(256), 0, p->run, s->d_list, (unsigned *)s->d_pcm, (unsigned *)nullptr,
+                           (unsigned long long)(pcm_row / 2), 2);
+        if (n_full) {
+            hipLaunchKernelGGL(k_rows, dim3(n_full), dim3(64), 0, p->run, s->d_list + 2 * n, (unsigned *)p->d_rng, (unsigned *)p->d_park_rng, 1ull, 1);
             if (p->d_pred)
-                HIP_OK(hipMemcpyAsync(p->d_pred + i * pred_row, p->d_park_pred + j * pred_row, pred_row * sizeof(HeaacPredictorState),
-                                      hipMemcpyDeviceToDevice, p->run));
-            j++;
+                hipLaunchKernelGGL(k_rows, dim3(n_full), dim3(256), 0, p->run, s->d_list + 2 * n, (unsigned *)p->d_pred, (unsigned *)p->d_park_pred,
+                                   (unsigned long long)(pred_row * sizeof(HeaacPredictorState) / 4), 1);
         }
+        HIP_OK(hipGetLastError());
     }
     HIP_OK(hipEventRecord(s->run_done, p->run));
     // D2H

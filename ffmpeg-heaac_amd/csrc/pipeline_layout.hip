@@ -57,6 +57,7 @@ struct LpSet {
     float *d_ccoef_fm;                              // [n][K][1024]: the spectra frame-major, as the tools' POST half reads them
     HeaacCoupling *h_gain, *d_gain;                 // [ne][K][HEAAC_MAX_CCE_LINKS][n * len / 1024]: AFTER_IMDCT gains, call by call
     unsigned char *cpos;                            // [n][K][3]: present, outputs_before, seq of each coupling element
+    unsigned *h_list, *d_list;                      // [2][2 n] (stream, parking row) pairs of the failed streams
     // per element, [n] each; pinned host / device
     float *h_coeffs[HEAAC_MAX_ELEMENTS], *d_coeffs[HEAAC_MAX_ELEMENTS];
     HeaacIcs *h_ics[HEAAC_MAX_ELEMENTS], *d_ics[HEAAC_MAX_ELEMENTS];
@@ -88,7 +89,7 @@ struct HeaacLayoutPipeline {
     int have_order; unsigned char order[HEAAC_MAX_ELEMENTS];     // order[seq] = element at that bitstream position
     LpCoupled *cpl;                 // layouts whose program config element names coupling elements (AAC-LC / Main)
     // parked state of the streams whose unit failed
-    float *d_park; size_t park_bytes;
+    float *d_park; size_t park_bytes, park_rows;
     unsigned long submitted, collected;
     // pool
     int threads;
@@ -324,6 +325,8 @@ extern "C" void heaac_layout_pipeline_destroy(HeaacLayoutPipeline *p)
             for (void *x : h) if (x) (void)hipHostFree(x);
             for (void *x : d) if (x) (void)hipFree(x);
         }
+        if (s->h_list) (void)hipHostFree(s->h_list);
+        if (s->d_list) (void)hipFree(s->d_list);
         if (s->d_ccoef_fm) (void)hipFree(s->d_ccoef_fm);
         if (s->h_gain) (void)hipHostFree(s->h_gain);
         if (s->d_gain) (void)hipFree(s->d_gain);
@@ -493,6 +496,7 @@ extern "C" int heaac_layout_pipeline_create(HeaacLayoutPipeline **out, const Hea
         const size_t pcm_bytes = n * (size_t)p->out_channels * p->len * 2;
         ok = ok && lp_pinned((void **)&s->h_pcm, pcm_bytes) && lp_devmem((void **)&s->d_pcm, pcm_bytes) &&
              (s->failed = (unsigned char *)calloc(n, 1)) != NULL && (s->seq = (unsigned char *)calloc(n * p->ne, 1)) != NULL &&
+             lp_pinned((void **)&s->h_list, 4 * n * sizeof(unsigned)) && lp_devmem((void **)&s->d_list, 4 * n * sizeof(unsigned)) &&
              hipEventCreate(&s->done) == hipSuccess;
     }
     ok = ok && lp_devmem((void **)&p->d_rng, n * 4) && lp_devmem((void **)&p->d_hdr, LP_MAX_HDRS * sizeof(HeaacSbrHeader));
@@ -542,34 +546,43 @@ extern "C" int heaac_layout_pipeline_create(HeaacLayoutPipeline **out, const Hea
 
 #define LP_HIP(x) do { if ((x) != hipSuccess) return HEAAC_ERR_HIP; } while (0)
 
-// rows of every failed stream: element states, predictors, noise generator -- to / from the parking area
-static int lp_park(HeaacLayoutPipeline *p, LpSet *s, size_t n_failed, int restore)
+// Rows of the failed streams to the parking area and back (or zeroed): one block per listed (stream, parking row)
+// pair -- a handful of launches per tick however many units are damaged (pipeline.hip k_rows).
+//   mode 0: park[row] = rows[stream];  1: rows[stream] = park[row];  2: rows[stream] = 0
+__global__ void k_lp_rows(const unsigned *__restrict__ list, unsigned *rows, unsigned *park, unsigned long long row_words, int mode)
 {
-    char *park = (char *)p->d_park;
-    size_t off = 0;
-    for (size_t i = 0; i < p->n; i++) {
-        if (!s->failed[i]) continue;
-        for (int k = 0; k < p->ne; k++) {
-            const LpElem &e = p->e[k];
-            const size_t sb = (size_t)e.words * 4, pb = (size_t)e.channels * HEAAC_MAX_PREDICTORS * sizeof(HeaacPredictorState);
-            char *st = (char *)e.d_state + i * sb;
-            LP_HIP(restore ? hipMemcpyAsync(st, park + off, sb, hipMemcpyDeviceToDevice, p->run)
-                           : hipMemcpyAsync(park + off, st, sb, hipMemcpyDeviceToDevice, p->run));
-            off += sb;
-            if (e.d_pred && s->failed[i] != 2) {
-                char *pr = (char *)e.d_pred + i * pb;
-                LP_HIP(restore ? hipMemcpyAsync(pr, park + off, pb, hipMemcpyDeviceToDevice, p->run)
-                               : hipMemcpyAsync(park + off, pr, pb, hipMemcpyDeviceToDevice, p->run));
-                off += pb;
-            }
-        }
-        if (s->failed[i] != 2)                         // (2: the tools' side of the stream moves on)
-            LP_HIP(restore ? hipMemcpyAsync(p->d_rng + i, park + off, 4, hipMemcpyDeviceToDevice, p->run)
-                           : hipMemcpyAsync(park + off, p->d_rng + i, 4, hipMemcpyDeviceToDevice, p->run));
-        off += 4;
+    const unsigned stream = list[2 * blockIdx.x], slot = list[2 * blockIdx.x + 1];
+    unsigned *r = rows + stream * row_words;
+    unsigned *q = park ? park + slot * row_words : nullptr;
+    for (unsigned long long w = threadIdx.x; w < row_words; w += blockDim.x) {
+        if (mode == 0) q[w] = r[w];
+        else if (mode == 1) r[w] = q[w];
+        else r[w] = 0u;
     }
-    (void)n_failed;
-    return HEAAC_OK;
+}
+
+// rows of every failed stream: element states, predictors, noise generator -- to / from the parking area, which holds
+// one region of `cap` rows per array.  n_all pairs at d_list: every failed stream; n_full at d_list + 2 n: those whose
+// generator and predictors stay put as well (failed == 1; 2: the tools' side of the stream moves on).
+static int lp_park(HeaacLayoutPipeline *p, LpSet *s, unsigned n_all, unsigned n_full, size_t cap, int restore)
+{
+    char *region = (char *)p->d_park;
+    for (int k = 0; k < p->ne; k++) {
+        const LpElem &e = p->e[k];
+        const size_t sb = (size_t)e.words * 4, pb = (size_t)e.channels * HEAAC_MAX_PREDICTORS * sizeof(HeaacPredictorState);
+        hipLaunchKernelGGL(k_lp_rows, dim3(n_all), dim3(256), 0, p->run, s->d_list, (unsigned *)e.d_state, (unsigned *)region,
+                           (unsigned long long)e.words, restore);
+        region += cap * sb;
+        if (e.d_pred) {
+            if (n_full)
+                hipLaunchKernelGGL(k_lp_rows, dim3(n_full), dim3(256), 0, p->run, s->d_list + 2 * p->n, (unsigned *)e.d_pred, (unsigned *)region,
+                                   (unsigned long long)(pb / 4), restore);
+            region += cap * pb;
+        }
+    }
+    if (n_full)
+        hipLaunchKernelGGL(k_lp_rows, dim3(n_full), dim3(64), 0, p->run, s->d_list + 2 * p->n, (unsigned *)p->d_rng, (unsigned *)region, 1ull, restore);
+    return hipGetLastError() == hipSuccess ? HEAAC_OK : HEAAC_ERR_HIP;
 }
 
 extern "C" int heaac_layout_pipeline_submit(HeaacLayoutPipeline *p, const uint8_t *const *au, const int *size, int *status)
@@ -663,21 +676,31 @@ extern "C" int heaac_layout_pipeline_submit(HeaacLayoutPipeline *p, const uint8_
             if (p->he) LP_HIP(hipMemcpyAsync(s->d_csbr[k], s->h_csbr[k], n * sizeof(HeaacSbrFrame), hipMemcpyHostToDevice, p->run));
         }
     }
+    unsigned n_all = 0, n_full = 0;
     if (n_failed) {
         size_t row = 4;
         for (int k = 0; k < ne; k++)
             row += (size_t)p->e[k].words * 4 + (p->e[k].d_pred ? (size_t)p->e[k].channels * HEAAC_MAX_PREDICTORS * sizeof(HeaacPredictorState) : 0);
-        if (n_failed * row > p->park_bytes) {
+        if (n_failed > p->park_rows) {
             LP_HIP(hipStreamSynchronize(p->run));
             if (p->d_park) (void)hipFree(p->d_park);
-            p->d_park = NULL; p->park_bytes = 0;
+            p->d_park = NULL; p->park_bytes = 0; p->park_rows = 0;
             size_t rows = 16;
             while (rows < n_failed) rows *= 2;
             if (rows > n) rows = n;
             if (!lp_devmem((void **)&p->d_park, rows * row)) return HEAAC_ERR_NOMEM;
             p->park_bytes = rows * row;
+            p->park_rows = rows;
         }
-        const int rc = lp_park(p, s, n_failed, 0);
+        unsigned *list_all = s->h_list, *list_full = s->h_list + 2 * n;
+        for (size_t i = 0; i < n; i++) {
+            if (!s->failed[i]) continue;
+            if (s->failed[i] == 1) { list_full[2 * n_full] = (unsigned)i; list_full[2 * n_full + 1] = n_all; n_full++; }
+            list_all[2 * n_all] = (unsigned)i; list_all[2 * n_all + 1] = n_all; n_all++;
+        }
+        LP_HIP(hipMemcpyAsync(s->d_list, list_all, 2 * n_all * sizeof(unsigned), hipMemcpyHostToDevice, p->run));
+        if (n_full) LP_HIP(hipMemcpyAsync(s->d_list + 2 * n, list_full, 2 * n_full * sizeof(unsigned), hipMemcpyHostToDevice, p->run));
+        const int rc = lp_park(p, s, n_all, n_full, p->park_rows, 0);
         if (rc != HEAAC_OK) return rc;
     }
     // the spectral tools of the elements in bitstream order (one noise generator per stream).  A coupling element's
@@ -816,10 +839,11 @@ extern "C" int heaac_layout_pipeline_submit(HeaacLayoutPipeline *p, const uint8_
     if (rc != HEAAC_OK) return rc;
     const size_t pcm_row = (size_t)p->out_channels * p->len;
     if (n_failed) {
-        rc = lp_park(p, s, n_failed, 1);
+        rc = lp_park(p, s, n_all, n_full, p->park_rows, 1);
         if (rc != HEAAC_OK) return rc;
-        for (size_t i = 0; i < n; i++)
-            if (s->failed[i]) LP_HIP(hipMemsetAsync(s->d_pcm + i * pcm_row, 0, pcm_row * 2, p->run));
+        hipLaunchKernelGGL(k_lp_rows, dim3(n_all), dim3(256), 0, p->run, s->d_list, (unsigned *)s->d_pcm, (unsigned *)nullptr,
+                           (unsigned long long)(pcm_row / 2), 2);      // (len is a multiple of 1024: whole 32-bit words)
+        LP_HIP(hipGetLastError());
     }
     LP_HIP(hipMemcpyAsync(s->h_pcm, s->d_pcm, n * pcm_row * 2, hipMemcpyDeviceToHost, p->run));
     LP_HIP(hipEventRecord(s->done, p->run));
