@@ -57,7 +57,8 @@ struct LpSet {
     float *d_ccoef_fm;                              // [n][K][1024]: the spectra frame-major, as the tools' POST half reads them
     HeaacCoupling *h_gain, *d_gain;                 // [ne][K][HEAAC_MAX_CCE_LINKS][n * len / 1024]: AFTER_IMDCT gains, call by call
     unsigned char *cpos;                            // [n][K][3]: present, outputs_before, seq of each coupling element
-    unsigned *h_list, *d_list;                      // [2][2 n] (stream, parking row) pairs of the failed streams
+    unsigned *h_list, *d_list;                      // [2][2 n] (stream, parking row) pairs of the failed streams; then K x [2 n]:
+                                                    // per coupling slot the streams whose element couples AFTER_IMDCT
     // per element, [n] each; pinned host / device
     float *h_coeffs[HEAAC_MAX_ELEMENTS], *d_coeffs[HEAAC_MAX_ELEMENTS];
     HeaacIcs *h_ics[HEAAC_MAX_ELEMENTS], *d_ics[HEAAC_MAX_ELEMENTS];
@@ -496,7 +497,8 @@ extern "C" int heaac_layout_pipeline_create(HeaacLayoutPipeline **out, const Hea
         const size_t pcm_bytes = n * (size_t)p->out_channels * p->len * 2;
         ok = ok && lp_pinned((void **)&s->h_pcm, pcm_bytes) && lp_devmem((void **)&s->d_pcm, pcm_bytes) &&
              (s->failed = (unsigned char *)calloc(n, 1)) != NULL && (s->seq = (unsigned char *)calloc(n * p->ne, 1)) != NULL &&
-             lp_pinned((void **)&s->h_list, 4 * n * sizeof(unsigned)) && lp_devmem((void **)&s->d_list, 4 * n * sizeof(unsigned)) &&
+             lp_pinned((void **)&s->h_list, (4 + 2 * (size_t)n_cce_slots) * n * sizeof(unsigned)) &&
+             lp_devmem((void **)&s->d_list, (4 + 2 * (size_t)n_cce_slots) * n * sizeof(unsigned)) &&
              hipEventCreate(&s->done) == hipSuccess;
     }
     ok = ok && lp_devmem((void **)&p->d_rng, n * 4) && lp_devmem((void **)&p->d_hdr, LP_MAX_HDRS * sizeof(HeaacSbrHeader));
@@ -754,10 +756,20 @@ extern "C" int heaac_layout_pipeline_submit(HeaacLayoutPipeline *p, const uint8_
                 : heaac_lc_decode_batch(p->dev, 1, s->d_ccoef[k], s->d_cics[k], st, all ? st : p->cpl->d_state_tmp,
                                         p->cpl->d_ret[k], HEAAC_PCM_F32_PLANAR, n, (void *)p->run);
             if (rc != HEAAC_OK) return rc;
-            if (!all)
+            if (!all) {
+                // rows of the streams that couple there, from the scratch copy (row i of it is stream i's)
+                unsigned *lst = s->h_list + (4 + 2 * (size_t)k) * n, cnt = 0;
                 for (size_t i = 0; i < n; i++)
-                    if (!s->failed[i] && s->h_cce[0][i * K + k].present && s->h_cce[0][i * K + k].coupling_point == HEAAC_CC_AFTER_IMDCT)
-                        LP_HIP(hipMemcpyAsync(st + i * words, p->cpl->d_state_tmp + i * words, words * 4, hipMemcpyDeviceToDevice, p->run));
+                    if (!s->failed[i] && s->h_cce[0][i * K + k].present && s->h_cce[0][i * K + k].coupling_point == HEAAC_CC_AFTER_IMDCT) {
+                        lst[2 * cnt] = lst[2 * cnt + 1] = (unsigned)i;
+                        cnt++;
+                    }
+                unsigned *dl = s->d_list + (4 + 2 * (size_t)k) * n;
+                LP_HIP(hipMemcpyAsync(dl, lst, 2 * cnt * sizeof(unsigned), hipMemcpyHostToDevice, p->run));
+                hipLaunchKernelGGL(k_lp_rows, dim3(cnt), dim3(256), 0, p->run, dl, (unsigned *)st, (unsigned *)p->cpl->d_state_tmp,
+                                   (unsigned long long)words, 1);
+                LP_HIP(hipGetLastError());
+            }
         }
     }
     HeaacPlaneRef planes[HEAAC_MAX_PCM_PLANES];
