@@ -175,11 +175,13 @@ KERNEL_SOURCE_EXTRA = ("kernels.h", "tables.h", "validate.h")
 
 
 def kernel_source_files():
-    """The device sources, relative to the repository root: csrc/k_*.hip, csrc/k_*.h, kernels.h, tables.h, validate.h
-    and the record header include/heaac_dsp.h."""
+    """The device sources of the kernels bench.py's workloads launch, relative to the repository root: csrc/k_*.hip,
+    csrc/k_*.h, kernels.h, tables.h, validate.h and the record header include/heaac_dsp.h -- without k_tools.hip (the
+    spectral tools: no bench workload runs them; tools/tools_rate.py measures them by themselves)."""
     import glob
     d = os.path.join(_HERE, "csrc")
-    files = sorted(glob.glob(os.path.join(d, "k_*.hip")) + glob.glob(os.path.join(d, "k_*.h")))
+    files = sorted(f for f in glob.glob(os.path.join(d, "k_*.hip")) + glob.glob(os.path.join(d, "k_*.h"))
+                   if os.path.basename(f) != "k_tools.hip")
     files += [os.path.join(d, f) for f in KERNEL_SOURCE_EXTRA]
     files.append(os.path.join(os.path.dirname(_HERE), "include", "heaac_dsp.h"))
     return [os.path.relpath(f, os.path.dirname(_HERE)) for f in files]

@@ -174,7 +174,7 @@ __device__ __forceinline__ void tools_prediction(ToolsWave &w, int ch, const Hea
         if (k < limit) {
             // scalefactor band of line k (bands are at most 96 wide: walk from a coarse guess)
             int sfb = 0;
-            while (ics.swb_offset[sfb + 1] <= k) sfb++;
+            while (sfb < 62 && ics.swb_offset[sfb + 1] <= k) sfb++;        // (sfb < 62: a record no band table gives must not walk off)
             const bool output_enable = pr.predictor_present && pr.prediction_used[sfb];
             float coef = w.coef[ch][k];
             const float k1 = ps.var0 > 1 ? ps.cor0 * flt16_even(a / ps.var0) : 0.0f;
@@ -366,6 +366,8 @@ __device__ __forceinline__ void tools_tns_filter(ToolsWave &w, int ch, int win, 
     int inc = 1;
     if (tns.direction[win][filt]) { inc = -1; start = end - 1; }
     start += win * 128;
+    // (a record no band table gives must not become an address outside the channel's 1024 lines)
+    if (start < 0 || start >= 1024 || start + inc * (size - 1) < 0 || start + inc * (size - 1) >= 1024) return;
     const float *tc = tns.coef[win][filt];
     if (order <= 7)       tns_ar<7>(w.coef[ch], start, inc, size, order, tc);
     else if (order <= 12) tns_ar<12>(w.coef[ch], start, inc, size, order, tc);

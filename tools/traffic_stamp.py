@@ -2,9 +2,10 @@
 each merged entry with the git head it belongs to: an entry is accepted only if its kernel_sha equals the hash of the
 device sources in the working tree (so the head named is one whose kernels were measured).
 usage: python3 tools/traffic_stamp.py [round] [--same-kernels <commit>]
---same-kernels <commit>: the measurement was taken on the snapshot of <commit>, whose device sources are the working
-tree's (checked with git diff) -- used once in round 4, when the definition of the hash changed between measuring and
-stamping."""
+--same-kernels <commit>: the measurement was taken on the snapshot of <commit>, whose device CODE hashes like the working
+tree's (checked) -- used in round 4 when the definition of the hash changed between measuring and stamping (comments no
+longer count; later the spectral-tools file, which no bench workload launches, left the set).  The entry then names
+<commit> as its head and the stamping head as `stamped_at`."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -30,7 +31,12 @@ for key, rec in new.items():
     if rec.get("kernel_sha") != sha:
         print("skip %s: measured on kernel sources %s, the tree has %s" % (key, rec.get("kernel_sha"), sha))
         continue
-    rec["head"] = head + ("+uncommitted kernel changes" if dirty else "")
+    if same:
+        # measured on the snapshot of <commit>, whose kernels are today's: that is the head the entry names
+        rec["head"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", same], text=True).strip()
+        rec["stamped_at"] = head
+    else:
+        rec["head"] = head + ("+uncommitted kernel changes" if dirty else "")
     if len(sys.argv) > 1:
         rec["round"] = int(sys.argv[1])
     allrec[key] = rec
